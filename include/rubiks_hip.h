@@ -1,0 +1,123 @@
+/*
+ * rubiks_hip.h -- C ABI of librubiks_hip.so, the MI355X (gfx950) cube engine.
+ *
+ * The reference (peleiden/librubiks) is pure Python and has no FFI of its own; the boundary this
+ * library replaces is the module surface of `librubiks.cube` (librubiks/cube/__init__.py:2) and
+ * the expand-children sections of `librubiks.solving.agents`.  Each entry point below names the
+ * reference function (file:line under /root/reference) whose arithmetic it performs.  The ctypes
+ * stub a maintainer would add on the reference side is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - Every entry returns 0 on success or a negative RK_E* code; rk_last_error() gives the
+ *     thread-local message of the last failure.  No entry ever falls back to a CPU path.
+ *   - Pointers named d_* are DEVICE pointers (hipMalloc / tensor.data_ptr()); h_* are host
+ *     pointers.  The library never frees or retains caller memory.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Device-pointer entries
+ *     are stream-ordered and do not synchronise; *_host entries copy, launch, copy back and
+ *     synchronise `stream` before returning.
+ *   - A 20-byte state is int8[20]: 8 corner codes slot*3+ori then 12 edge codes slot*2+ori
+ *     (cube.py:58-65).  State arrays are dense row-major (n, 20); their base must be 4-byte
+ *     aligned (always true for rows of a 256-B aligned allocation).
+ *   - An action index a in [0,12) means face a/2, direction 1-(a%2) (cube.py:33-34).
+ *   - repr: RK_REPR_2024 = 20-byte cubie codes, RK_REPR_686 = int8 (6,8,6) one-hot, 288 bytes
+ *     (cube.py:67-71).
+ */
+#ifndef RUBIKS_HIP_H
+#define RUBIKS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RK_REPR_2024 0
+#define RK_REPR_686  1
+
+#define RK_OK          0
+#define RK_EINVAL     -1   /* bad argument (null pointer, misaligned base, unknown repr, ...) */
+#define RK_EHIP       -2   /* a HIP runtime call failed; message holds hipGetErrorString */
+#define RK_ECAPACITY  -3   /* an engine ran out of the capacity it was created with */
+#define RK_ESTATE     -4   /* call not valid in the engine's current state */
+
+#define RK_OH_F32  0
+#define RK_OH_F16  1
+#define RK_OH_BF16 2
+
+/* ---- library ------------------------------------------------------------------------------ */
+int         rk_version(void);
+const char *rk_last_error(void);
+/* Select `device` for the calling thread and check that it is a gfx950 part. */
+int         rk_init(int device);
+
+/* Move tables, written to HOST memory.
+ * RK_REPR_2024: uint8 (12,2,24) absolute table T[a][kind][v] = v + maps[dir][face][kind][v]
+ *               (maps.py:107-145).   RK_REPR_686: uint8 (12,48) sticker-slot permutation,
+ *               new[slot] = old[perm[a][slot]], slot = 8*face+pos (cube.py:330-347). */
+int rk_tables(int repr, uint8_t *h_out);
+/* Solved state in HOST memory: int8[20] (cube.py:58-65) or int8[288] (cube.py:67-71). */
+int rk_solved(int repr, int8_t *h_out);
+
+/* ---- plain device memory helpers (for hosts that do not bring their own allocator) -------- */
+int rk_malloc(void **d_ptr, size_t bytes);
+int rk_free(void *d_ptr);
+int rk_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
+int rk_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
+int rk_memset(void *d_dst, int value, size_t bytes, void *stream);
+int rk_stream_synchronize(void *stream);
+
+/* ---- cube hot path, device pointers -------------------------------------------------------- */
+
+/* multi_rotate (cube.py:49-52, 256-263; 686: cube.py:349-361): d_out[i] = move d_actions[i]
+ * applied to d_states[i].  d_out may equal d_states. */
+int rk_multi_rotate(int repr, const int8_t *d_states, const uint8_t *d_actions, int8_t *d_out,
+                    size_t n, void *stream);
+/* Same with the reference's (faces, directions) pair as two uint8 arrays. */
+int rk_multi_rotate_fd(int repr, const int8_t *d_states, const uint8_t *d_faces, const uint8_t *d_dirs,
+                       int8_t *d_out, size_t n, void *stream);
+
+/* The 12-child fan-out `multi_rotate(repeat(S,12), *iter_actions(n))` (agents.py:277-281, :513,
+ * :605; train.py:285) fused with `multi_is_solved` of the children (cube.py:88-89; agents.py:321,
+ * :540; train.py:292).  d_children is (12 n, state) parent-major / action-minor and must be 16-byte
+ * aligned.  d_solved (nullable) gets one byte per child.  d_stats (nullable) is int64[2] that the
+ * caller zero/initialises: [0] += number of solved children, [1] = min(index of a solved child,
+ * previous value) -- initialise [1] to INT64_MAX. */
+int rk_expand12(int repr, const int8_t *d_parents, int8_t *d_children, uint8_t *d_solved,
+                long long *d_stats, size_t n, void *stream);
+
+/* multi_is_solved (cube.py:88-89).  d_flags (nullable) one byte per state; d_stats as above. */
+int rk_multi_is_solved(int repr, const int8_t *d_states, uint8_t *d_flags, long long *d_stats,
+                       size_t n, void *stream);
+
+/* Move sequences from the solved state: the device half of scramble (cube.py:206-216) and
+ * sequence_scrambler (cube.py:218-232).  d_actions is (depth, games) uint8, row d = d-th move of
+ * every game (the layout of the reference's faces/dirs draws).  Game g emits `rows` =
+ * (with_solved ? 1 : 0) + moves states, where moves = depth - with_solved: optionally the solved
+ * state, then the state after each of its first `moves` moves.  If only_last != 0 just the final
+ * state of each game is written (d_out is (games, state)), else d_out is (games*rows, state)
+ * game-major. */
+int rk_apply_sequences(int repr, const uint8_t *d_actions, int depth, int games, int with_solved,
+                       int only_last, int8_t *d_out, void *stream);
+
+/* as_oh (cube.py:130-133, 265-277; 686: cube.py:363-369): one-hot encode n states into
+ * (n, 480) [2024] or (n, 288) [686] elements of out_dtype (RK_OH_*); d_out 16-byte aligned. */
+int rk_as_oh(int repr, const int8_t *d_states, void *d_out, int out_dtype, size_t n, void *stream);
+
+/* as_correct (cube.py:371-380): 686 one-hot int8 (n,288) -> float32 (n,48) of +1/-1. */
+int rk_as_correct686(const int8_t *d_states, float *d_out, size_t n, void *stream);
+
+/* ---- host-pointer conveniences (allocate scratch, copy, launch, copy back, synchronise) ---- */
+int rk_multi_rotate_host(int repr, const int8_t *h_states, const uint8_t *h_actions, int8_t *h_out,
+                         size_t n, void *stream);
+int rk_expand12_host(int repr, const int8_t *h_parents, int8_t *h_children, uint8_t *h_solved,
+                     long long *h_stats, size_t n, void *stream);
+int rk_multi_is_solved_host(int repr, const int8_t *h_states, uint8_t *h_flags, long long *h_stats,
+                            size_t n, void *stream);
+int rk_apply_sequences_host(int repr, const uint8_t *h_actions, int depth, int games, int with_solved,
+                            int only_last, int8_t *h_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RUBIKS_HIP_H */

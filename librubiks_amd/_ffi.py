@@ -1,0 +1,85 @@
+"""
+ctypes binding of librubiks_hip.so (C ABI: include/rubiks_hip.h).
+
+The library is the product; this file only declares its entry points.  If the shared object is missing
+the import of any compute module fails loudly -- there is deliberately no Python/NumPy fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (imported first so that librubiks_hip.so binds to the HIP runtime torch already loaded)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librubiks_hip.so")
+
+REPR_2024, REPR_686 = 0, 1
+OH_F32, OH_F16, OH_BF16 = 0, 1, 2
+INT64_MAX = (1 << 63) - 1
+
+_vp, _sz, _i = C.c_void_p, C.c_size_t, C.c_int
+
+#: name -> (restype, argtypes); kept in the order of include/rubiks_hip.h.  tests/test_abi.py checks that the
+#: header, this table and the built library agree symbol for symbol.
+SIGNATURES = {
+	"rk_version": (_i, []),
+	"rk_last_error": (C.c_char_p, []),
+	"rk_init": (_i, [_i]),
+	"rk_tables": (_i, [_i, _vp]),
+	"rk_solved": (_i, [_i, _vp]),
+	"rk_malloc": (_i, [C.POINTER(_vp), _sz]),
+	"rk_free": (_i, [_vp]),
+	"rk_memcpy_h2d": (_i, [_vp, _vp, _sz, _vp]),
+	"rk_memcpy_d2h": (_i, [_vp, _vp, _sz, _vp]),
+	"rk_memset": (_i, [_vp, _i, _sz, _vp]),
+	"rk_stream_synchronize": (_i, [_vp]),
+	"rk_multi_rotate": (_i, [_i, _vp, _vp, _vp, _sz, _vp]),
+	"rk_multi_rotate_fd": (_i, [_i, _vp, _vp, _vp, _vp, _sz, _vp]),
+	"rk_expand12": (_i, [_i, _vp, _vp, _vp, _vp, _sz, _vp]),
+	"rk_multi_is_solved": (_i, [_i, _vp, _vp, _vp, _sz, _vp]),
+	"rk_apply_sequences": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _vp]),
+	"rk_as_oh": (_i, [_i, _vp, _vp, _i, _sz, _vp]),
+	"rk_as_correct686": (_i, [_vp, _vp, _sz, _vp]),
+	"rk_multi_rotate_host": (_i, [_i, _vp, _vp, _vp, _sz, _vp]),
+	"rk_expand12_host": (_i, [_i, _vp, _vp, _vp, _vp, _sz, _vp]),
+	"rk_multi_is_solved_host": (_i, [_i, _vp, _vp, _vp, _sz, _vp]),
+	"rk_apply_sequences_host": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _vp]),
+}
+
+_lib = None
+
+
+class RubiksHipError(RuntimeError):
+	pass
+
+
+def lib():
+	"""The loaded library.  Raises ImportError when it has not been built (python -m librubiks_amd.build)."""
+	global _lib
+	if _lib is None:
+		if not os.path.exists(LIB_PATH):
+			raise ImportError(
+				f"{LIB_PATH} is missing: build it with `python -m librubiks_amd.build` (hipcc, gfx950). "
+				"librubiks_amd has no CPU fallback.")
+		handle = C.CDLL(LIB_PATH)
+		for name, (res, args) in SIGNATURES.items():
+			fn = getattr(handle, name)
+			fn.restype, fn.argtypes = res, args
+		_lib = handle
+	return _lib
+
+
+def check(rc: int):
+	if rc != 0:
+		raise RubiksHipError(f"librubiks_hip error {rc}: {lib().rk_last_error().decode()}")
+
+
+def require_gpu():
+	if not torch.cuda.is_available():
+		raise RubiksHipError("no HIP device visible: librubiks_amd computes only on a gfx950 GPU (no CPU fallback)")
+
+
+def stream_ptr() -> int:
+	"""hipStream_t of torch's current stream, so that kernels order with the caller's torch work."""
+	return torch.cuda.current_stream().cuda_stream

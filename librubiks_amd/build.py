@@ -1,0 +1,61 @@
+"""
+Builds librubiks_hip.so (the C-ABI HIP library) in-tree with hipcc for gfx950.
+
+    python -m librubiks_amd.build [--force]
+
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels with the gpurun snapshot.
+"""
+from __future__ import annotations
+
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "librubiks_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = [
+	"--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+	"-ffp-contract=off",          # search statistics must round like NumPy (no fused multiply-add)
+	"-Wall", "-Wno-unused-function",
+	"-Wl,-rpath,/opt/rocm/lib",
+]
+
+
+def sources():
+	return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def stale() -> bool:
+	if not os.path.exists(OUT):
+		return True
+	t = os.path.getmtime(OUT)
+	deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+	return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+	if not force and not stale():
+		return OUT
+	objs = []
+	for src in sources():
+		obj = os.path.join(CSRC, os.path.basename(src)[:-4] + ".o")
+		if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
+				[os.path.getmtime(src)] + [os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, "*.h"))]
+				+ [os.path.getmtime(h) for h in glob.glob(os.path.join(HERE, "..", "include", "*.h"))]):
+			cmd = [HIPCC] + [f for f in FLAGS if f != "-shared" and not f.startswith("-Wl")] + ["-c", src, "-o", obj]
+			if verbose:
+				print(" ".join(cmd))
+			subprocess.run(cmd, check=True)
+		objs.append(obj)
+	cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-rpath,/opt/rocm/lib", "-o", OUT] + objs
+	if verbose:
+		print(" ".join(cmd))
+	subprocess.run(cmd, check=True)
+	return OUT
+
+
+if __name__ == "__main__":
+	print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,336 @@
+// C ABI of librubiks_hip.so (declared in include/rubiks_hip.h): argument validation, error reporting and the
+// host-pointer conveniences.  Nothing in here computes on the CPU: every entry either launches a HIP kernel or
+// fails with an error code.
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <climits>
+
+#include "../../include/rubiks_hip.h"
+#include "rk_kernels.h"
+#include "rk_error.h"
+
+namespace rk {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof g_err, fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+}  // namespace rk
+
+using namespace rk;
+
+namespace {
+
+inline bool misaligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) != 0; }
+
+inline int state_bytes(int repr) { return repr == RK_REPR_2024 ? STATE_BYTES : S686_BYTES; }
+
+int check_repr(int repr)
+{
+	if (repr != RK_REPR_2024 && repr != RK_REPR_686) return fail(RK_EINVAL, "unknown representation %d", repr);
+	return RK_OK;
+}
+
+// scratch device buffer with RAII for the *_host entries
+struct DevBuf {
+	void *p = nullptr;
+	int alloc(size_t bytes)
+	{
+		RK_HIP(hipMalloc(&p, bytes ? bytes : 16));
+		return RK_OK;
+	}
+	~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+}  // namespace
+
+extern "C" {
+
+int rk_version(void) { return 100; }
+
+const char *rk_last_error(void) { return g_err; }
+
+int rk_init(int device)
+{
+	int count = 0;
+	RK_HIP(hipGetDeviceCount(&count));
+	if (device < 0 || device >= count) return fail(RK_EINVAL, "device %d out of range (%d visible)", device, count);
+	RK_HIP(hipSetDevice(device));
+	hipDeviceProp_t prop;
+	RK_HIP(hipGetDeviceProperties(&prop, device));
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+		return fail(RK_EINVAL, "device %d is %s; this library only carries gfx950 code", device, prop.gcnArchName);
+	return RK_OK;
+}
+
+int rk_tables(int repr, uint8_t *h_out)
+{
+	if (int e = check_repr(repr)) return e;
+	if (!h_out) return fail(RK_EINVAL, "rk_tables: null output");
+	const Tables &t = host_tables();
+	if (repr == RK_REPR_2024) memcpy(h_out, t.lut, sizeof t.lut);
+	else memcpy(h_out, t.perm686, sizeof t.perm686);
+	return RK_OK;
+}
+
+int rk_solved(int repr, int8_t *h_out)
+{
+	if (int e = check_repr(repr)) return e;
+	if (!h_out) return fail(RK_EINVAL, "rk_solved: null output");
+	const Tables &t = host_tables();
+	if (repr == RK_REPR_2024) memcpy(h_out, t.solved, STATE_BYTES);
+	else memcpy(h_out, t.solved686, S686_BYTES);
+	return RK_OK;
+}
+
+int rk_malloc(void **d_ptr, size_t bytes)
+{
+	if (!d_ptr) return fail(RK_EINVAL, "rk_malloc: null out pointer");
+	RK_HIP(hipMalloc(d_ptr, bytes ? bytes : 16));
+	return RK_OK;
+}
+
+int rk_free(void *d_ptr)
+{
+	RK_HIP(hipFree(d_ptr));
+	return RK_OK;
+}
+
+int rk_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream)
+{
+	RK_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+	return RK_OK;
+}
+
+int rk_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream)
+{
+	RK_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+	return RK_OK;
+}
+
+int rk_memset(void *d_dst, int value, size_t bytes, void *stream)
+{
+	RK_HIP(hipMemsetAsync(d_dst, value, bytes, (hipStream_t)stream));
+	return RK_OK;
+}
+
+int rk_stream_synchronize(void *stream)
+{
+	RK_HIP(hipStreamSynchronize((hipStream_t)stream));
+	return RK_OK;
+}
+
+// ---- device-pointer entries ---------------------------------------------------------------------------------
+
+int rk_multi_rotate(int repr, const int8_t *d_states, const uint8_t *d_actions, int8_t *d_out, size_t n, void *stream)
+{
+	if (int e = check_repr(repr)) return e;
+	if (n == 0) return RK_OK;
+	if (!d_states || !d_actions || !d_out) return fail(RK_EINVAL, "rk_multi_rotate: null pointer");
+	if (misaligned(d_states, 4) || misaligned(d_out, 4)) return fail(RK_EINVAL, "rk_multi_rotate: state arrays must be 4-byte aligned");
+	if (repr == RK_REPR_2024) launch_multi_rotate(d_states, d_actions, nullptr, d_out, n, (hipStream_t)stream);
+	else {
+		if (d_out == d_states) return fail(RK_EINVAL, "rk_multi_rotate: in-place not supported for the 6x8x6 representation");
+		launch_rotate686(d_states, d_actions, d_out, n, false, (hipStream_t)stream);
+	}
+	RK_HIP(hipGetLastError());
+	return RK_OK;
+}
+
+int rk_multi_rotate_fd(int repr, const int8_t *d_states, const uint8_t *d_faces, const uint8_t *d_dirs, int8_t *d_out,
+                       size_t n, void *stream)
+{
+	if (int e = check_repr(repr)) return e;
+	if (repr != RK_REPR_2024) return fail(RK_EINVAL, "rk_multi_rotate_fd: only the 20-byte representation; pass action indices for 6x8x6");
+	if (n == 0) return RK_OK;
+	if (!d_states || !d_faces || !d_dirs || !d_out) return fail(RK_EINVAL, "rk_multi_rotate_fd: null pointer");
+	if (misaligned(d_states, 4) || misaligned(d_out, 4)) return fail(RK_EINVAL, "rk_multi_rotate_fd: state arrays must be 4-byte aligned");
+	launch_multi_rotate(d_states, d_faces, d_dirs, d_out, n, (hipStream_t)stream);
+	RK_HIP(hipGetLastError());
+	return RK_OK;
+}
+
+int rk_expand12(int repr, const int8_t *d_parents, int8_t *d_children, uint8_t *d_solved, long long *d_stats, size_t n,
+                void *stream)
+{
+	if (int e = check_repr(repr)) return e;
+	if (n == 0) return RK_OK;
+	if (!d_parents || !d_children) return fail(RK_EINVAL, "rk_expand12: null pointer");
+	if (misaligned(d_parents, 4)) return fail(RK_EINVAL, "rk_expand12: parents must be 4-byte aligned");
+	if (misaligned(d_children, 16)) return fail(RK_EINVAL, "rk_expand12: children must be 16-byte aligned");
+	if (d_solved && misaligned(d_solved, 4)) return fail(RK_EINVAL, "rk_expand12: solved flags must be 4-byte aligned");
+	if (d_stats && misaligned(d_stats, 8)) return fail(RK_EINVAL, "rk_expand12: stats must be 8-byte aligned");
+	if (d_stats && !d_solved && repr == RK_REPR_2024) return fail(RK_EINVAL, "rk_expand12: stats need the solved-flag output");
+	if (repr == RK_REPR_2024) {
+		launch_expand12(d_parents, d_children, d_solved, d_stats, n, (hipStream_t)stream);
+	} else {
+		launch_rotate686(d_parents, nullptr, d_children, 12 * n, true, (hipStream_t)stream);
+		if (d_solved || d_stats) launch_is_solved686(d_children, d_solved, d_stats, 12 * n, (hipStream_t)stream);
+	}
+	RK_HIP(hipGetLastError());
+	return RK_OK;
+}
+
+int rk_multi_is_solved(int repr, const int8_t *d_states, uint8_t *d_flags, long long *d_stats, size_t n, void *stream)
+{
+	if (int e = check_repr(repr)) return e;
+	if (n == 0) return RK_OK;
+	if (!d_states) return fail(RK_EINVAL, "rk_multi_is_solved: null states");
+	if (misaligned(d_states, 4)) return fail(RK_EINVAL, "rk_multi_is_solved: states must be 4-byte aligned");
+	if (d_stats && misaligned(d_stats, 8)) return fail(RK_EINVAL, "rk_multi_is_solved: stats must be 8-byte aligned");
+	if (repr == RK_REPR_2024) launch_multi_is_solved(d_states, d_flags, d_stats, n, (hipStream_t)stream);
+	else launch_is_solved686(d_states, d_flags, d_stats, n, (hipStream_t)stream);
+	RK_HIP(hipGetLastError());
+	return RK_OK;
+}
+
+int rk_apply_sequences(int repr, const uint8_t *d_actions, int depth, int games, int with_solved, int only_last,
+                       int8_t *d_out, void *stream)
+{
+	if (int e = check_repr(repr)) return e;
+	if (repr != RK_REPR_2024) return fail(RK_EINVAL, "rk_apply_sequences: only the 20-byte representation is implemented");
+	if (depth < 0 || games < 0) return fail(RK_EINVAL, "rk_apply_sequences: negative size");
+	with_solved = with_solved ? 1 : 0;
+	const int moves = depth - with_solved;
+	if (games == 0 || (moves < 0)) return RK_OK;
+	if (!only_last && moves + with_solved == 0) return RK_OK;
+	if (!d_out || (moves > 0 && !d_actions)) return fail(RK_EINVAL, "rk_apply_sequences: null pointer");
+	if (misaligned(d_out, 4)) return fail(RK_EINVAL, "rk_apply_sequences: output must be 4-byte aligned");
+	launch_apply_sequences(d_actions, moves, games, with_solved, only_last ? 1 : 0, d_out, (hipStream_t)stream);
+	RK_HIP(hipGetLastError());
+	return RK_OK;
+}
+
+int rk_as_oh(int repr, const int8_t *d_states, void *d_out, int out_dtype, size_t n, void *stream)
+{
+	if (int e = check_repr(repr)) return e;
+	if (out_dtype < RK_OH_F32 || out_dtype > RK_OH_BF16) return fail(RK_EINVAL, "rk_as_oh: unknown output dtype %d", out_dtype);
+	if (n == 0) return RK_OK;
+	if (!d_states || !d_out) return fail(RK_EINVAL, "rk_as_oh: null pointer");
+	if (misaligned(d_states, 4)) return fail(RK_EINVAL, "rk_as_oh: states must be 4-byte aligned");
+	if (misaligned(d_out, 16)) return fail(RK_EINVAL, "rk_as_oh: output must be 16-byte aligned");
+	if (repr == RK_REPR_2024) launch_as_oh(d_states, d_out, out_dtype, n, (hipStream_t)stream);
+	else launch_as_oh686(d_states, d_out, out_dtype, n, (hipStream_t)stream);
+	RK_HIP(hipGetLastError());
+	return RK_OK;
+}
+
+int rk_as_correct686(const int8_t *d_states, float *d_out, size_t n, void *stream)
+{
+	if (n == 0) return RK_OK;
+	if (!d_states || !d_out) return fail(RK_EINVAL, "rk_as_correct686: null pointer");
+	launch_as_correct686(d_states, d_out, n, (hipStream_t)stream);
+	RK_HIP(hipGetLastError());
+	return RK_OK;
+}
+
+// ---- host-pointer conveniences ------------------------------------------------------------------------------
+
+static const long long STATS_INIT[2] = {0, LLONG_MAX};
+
+int rk_multi_rotate_host(int repr, const int8_t *h_states, const uint8_t *h_actions, int8_t *h_out, size_t n, void *stream)
+{
+	if (int e = check_repr(repr)) return e;
+	if (n == 0) return RK_OK;
+	if (!h_states || !h_actions || !h_out) return fail(RK_EINVAL, "rk_multi_rotate_host: null pointer");
+	for (size_t i = 0; i < n; i++)
+		if (h_actions[i] >= N_ACTIONS) return fail(RK_EINVAL, "rk_multi_rotate_host: action %u at row %zu out of range", h_actions[i], i);
+	const size_t sb = (size_t)state_bytes(repr);
+	hipStream_t st = (hipStream_t)stream;
+	DevBuf in, act, out;
+	if (int e = in.alloc(n * sb)) return e;
+	if (int e = act.alloc(n)) return e;
+	if (int e = out.alloc(n * sb)) return e;
+	RK_HIP(hipMemcpyAsync(in.p, h_states, n * sb, hipMemcpyHostToDevice, st));
+	RK_HIP(hipMemcpyAsync(act.p, h_actions, n, hipMemcpyHostToDevice, st));
+	if (int e = rk_multi_rotate(repr, (const int8_t *)in.p, (const uint8_t *)act.p, (int8_t *)out.p, n, stream)) return e;
+	RK_HIP(hipMemcpyAsync(h_out, out.p, n * sb, hipMemcpyDeviceToHost, st));
+	RK_HIP(hipStreamSynchronize(st));
+	return RK_OK;
+}
+
+int rk_expand12_host(int repr, const int8_t *h_parents, int8_t *h_children, uint8_t *h_solved, long long *h_stats, size_t n,
+                     void *stream)
+{
+	if (int e = check_repr(repr)) return e;
+	if (h_stats) { h_stats[0] = 0; h_stats[1] = -1; }
+	if (n == 0) return RK_OK;
+	if (!h_parents || !h_children) return fail(RK_EINVAL, "rk_expand12_host: null pointer");
+	const size_t sb = (size_t)state_bytes(repr);
+	hipStream_t st = (hipStream_t)stream;
+	DevBuf in, ch, fl, stt;
+	if (int e = in.alloc(n * sb)) return e;
+	if (int e = ch.alloc(12 * n * sb)) return e;
+	if (int e = fl.alloc(12 * n)) return e;
+	if (int e = stt.alloc(sizeof STATS_INIT)) return e;
+	RK_HIP(hipMemcpyAsync(in.p, h_parents, n * sb, hipMemcpyHostToDevice, st));
+	RK_HIP(hipMemcpyAsync(stt.p, STATS_INIT, sizeof STATS_INIT, hipMemcpyHostToDevice, st));
+	if (int e = rk_expand12(repr, (const int8_t *)in.p, (int8_t *)ch.p, (uint8_t *)fl.p, (long long *)stt.p, n, stream)) return e;
+	RK_HIP(hipMemcpyAsync(h_children, ch.p, 12 * n * sb, hipMemcpyDeviceToHost, st));
+	if (h_solved) RK_HIP(hipMemcpyAsync(h_solved, fl.p, 12 * n, hipMemcpyDeviceToHost, st));
+	long long stats[2];
+	RK_HIP(hipMemcpyAsync(stats, stt.p, sizeof stats, hipMemcpyDeviceToHost, st));
+	RK_HIP(hipStreamSynchronize(st));
+	if (h_stats) { h_stats[0] = stats[0]; h_stats[1] = stats[0] ? stats[1] : -1; }
+	return RK_OK;
+}
+
+int rk_multi_is_solved_host(int repr, const int8_t *h_states, uint8_t *h_flags, long long *h_stats, size_t n, void *stream)
+{
+	if (int e = check_repr(repr)) return e;
+	if (h_stats) { h_stats[0] = 0; h_stats[1] = -1; }
+	if (n == 0) return RK_OK;
+	if (!h_states) return fail(RK_EINVAL, "rk_multi_is_solved_host: null pointer");
+	const size_t sb = (size_t)state_bytes(repr);
+	hipStream_t st = (hipStream_t)stream;
+	DevBuf in, fl, stt;
+	if (int e = in.alloc(n * sb)) return e;
+	if (int e = fl.alloc(n)) return e;
+	if (int e = stt.alloc(sizeof STATS_INIT)) return e;
+	RK_HIP(hipMemcpyAsync(in.p, h_states, n * sb, hipMemcpyHostToDevice, st));
+	RK_HIP(hipMemcpyAsync(stt.p, STATS_INIT, sizeof STATS_INIT, hipMemcpyHostToDevice, st));
+	if (int e = rk_multi_is_solved(repr, (const int8_t *)in.p, (uint8_t *)fl.p, (long long *)stt.p, n, stream)) return e;
+	if (h_flags) RK_HIP(hipMemcpyAsync(h_flags, fl.p, n, hipMemcpyDeviceToHost, st));
+	long long stats[2];
+	RK_HIP(hipMemcpyAsync(stats, stt.p, sizeof stats, hipMemcpyDeviceToHost, st));
+	RK_HIP(hipStreamSynchronize(st));
+	if (h_stats) { h_stats[0] = stats[0]; h_stats[1] = stats[0] ? stats[1] : -1; }
+	return RK_OK;
+}
+
+int rk_apply_sequences_host(int repr, const uint8_t *h_actions, int depth, int games, int with_solved, int only_last,
+                            int8_t *h_out, void *stream)
+{
+	if (int e = check_repr(repr)) return e;
+	if (repr != RK_REPR_2024) return fail(RK_EINVAL, "rk_apply_sequences_host: only the 20-byte representation is implemented");
+	if (depth < 0 || games < 0) return fail(RK_EINVAL, "rk_apply_sequences_host: negative size");
+	with_solved = with_solved ? 1 : 0;
+	const int moves = depth - with_solved;
+	if (games == 0 || moves < 0) return RK_OK;
+	const size_t rows = only_last ? 1 : (size_t)(moves + with_solved);
+	if (rows == 0) return RK_OK;
+	if (!h_out || (moves > 0 && !h_actions)) return fail(RK_EINVAL, "rk_apply_sequences_host: null pointer");
+	const size_t nact = (size_t)moves * games;
+	for (size_t i = 0; i < nact; i++)
+		if (h_actions[i] >= N_ACTIONS) return fail(RK_EINVAL, "rk_apply_sequences_host: action %u out of range", h_actions[i]);
+	hipStream_t st = (hipStream_t)stream;
+	DevBuf act, out;
+	if (int e = act.alloc(nact)) return e;
+	if (int e = out.alloc((size_t)games * rows * STATE_BYTES)) return e;
+	if (nact) RK_HIP(hipMemcpyAsync(act.p, h_actions, nact, hipMemcpyHostToDevice, st));
+	if (int e = rk_apply_sequences(repr, (const uint8_t *)act.p, depth, games, with_solved, only_last, (int8_t *)out.p, stream)) return e;
+	RK_HIP(hipMemcpyAsync(h_out, out.p, (size_t)games * rows * STATE_BYTES, hipMemcpyDeviceToHost, st));
+	RK_HIP(hipStreamSynchronize(st));
+	return RK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,592 @@
+// Cube hot-path kernels for MI355X (gfx950): 12-child fan-out with fused goal test, per-state moves, goal test,
+// move sequences (scramblers), one-hot encoding; 20-byte and 6x8x6 representations.
+//
+// All of this is HBM-bound byte work (no contraction, so no MFMA).  The shape every kernel follows:
+//   global --16 B/lane coalesced--> LDS --transposed, conflict-free--> registers (one state per lane)
+//   registers --v_perm_b32 table look-ups / byte transposes--> LDS --16 B/lane coalesced--> global
+// The move tables (576..768 B) and the solved state live in the constant segment and are staged in LDS once per
+// workgroup.  LDS staging areas are private to a wave, so the streaming loops contain no s_barrier.
+#include "rk_device.h"
+#include "rk_kernels.h"
+
+namespace rk {
+
+// ================================================================================================================
+// expand12: n parents -> 12 n children (+ solved flags)                          reference: agents.py:277-281,
+//                                                                                cube.py:256-263, cube.py:88-89
+// Algorithmic HBM bytes per parent: 20 read + 240 + 12 written = 272.
+//
+// A wave owns a tile of 256 parents: five 1 KiB coalesced loads bring the 5 120 B in, the wave re-reads them one
+// state per lane (stride 5 dwords: conflict-free), then runs four rounds of 64 parents.  In a round each lane
+//   1. fetches, for each of its 20 cubies, the 16-byte row rows[kind][code] = that cubie's code in all 12
+//      children (20 ds_read_b128; the table is 768 B, codes differing by 16 share a bank: at most 2-way),
+//   2. turns the 20x12 byte matrix into 12 children x 5 dwords with 15 4x4 byte transposes (120 v_perm_b32),
+//   3. tests every child against the solved dwords,
+//   4. writes its 240 B to the wave's staging area (15 ds_write_b128, lane stride 60 dwords: conflict-free);
+//      the wave then streams the 15 360 B out as fifteen 1 KiB global_store_dwordx4.
+// ================================================================================================================
+constexpr int EXP_ROUND = 64;                  // parents per round (one per lane)
+constexpr int EXP_TILE = 256;                  // parents per wave tile (4 rounds)
+constexpr int EXP_WAVES = 4;                   // waves per workgroup
+
+struct ExpandWaveLds {
+	u32x4    stage[EXP_ROUND * 15];            // 15 360 B: children of one round; first 5 120 B double as input staging
+	uint32_t flags[EXP_ROUND * 3];             // 768 B: 12 solved bytes per parent
+};
+
+template <bool WITH_FLAGS>
+__global__ __launch_bounds__(EXP_WAVES * WAVE)
+void k_expand12(const uint32_t *__restrict__ parents, u32x4 *__restrict__ children, uint32_t *__restrict__ solved,
+                long long *__restrict__ stats, size_t n, size_t n_tiles)
+{
+	__shared__ u32x4 s_rows[48];
+	__shared__ ExpandWaveLds s_wave[EXP_WAVES];
+
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	if (tid < 48) {
+		const uint32_t *src = reinterpret_cast<const uint32_t *>(D_TAB.rows) + 4 * tid;
+		s_rows[tid] = u32x4{src[0], src[1], src[2], src[3]};
+	}
+	__syncthreads();
+
+	ExpandWaveLds &L = s_wave[wv];
+	uint32_t *stage_dw = reinterpret_cast<uint32_t *>(L.stage);
+
+	for (size_t tile = (size_t)blockIdx.x * EXP_WAVES + wv; tile < n_tiles; tile += (size_t)gridDim.x * EXP_WAVES) {
+		const size_t p0 = tile * EXP_TILE;
+		const int np = (int)((n - p0 < (size_t)EXP_TILE) ? (n - p0) : (size_t)EXP_TILE);   // parents in this tile
+
+		// ---- parents in: 5 x 1 KiB coalesced, through LDS, one state per lane per round ----
+		uint32_t par[4][5];
+		{
+			const uint32_t *src = parents + p0 * STATE_DWORDS;
+			if (np == EXP_TILE && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+				const u32x4 *src4 = reinterpret_cast<const u32x4 *>(src);
+				#pragma unroll
+				for (int k = 0; k < 5; k++) L.stage[k * 64 + lane] = src4[k * 64 + lane];
+			} else {
+				const int ndw = np * STATE_DWORDS;
+				#pragma unroll
+				for (int k = 0; k < 20; k++) {
+					const int idx = k * 64 + lane;
+					stage_dw[idx] = idx < ndw ? src[idx] : 0u;
+				}
+			}
+			wave_lds_fence();
+			#pragma unroll
+			for (int q = 0; q < 4; q++)
+				#pragma unroll
+				for (int j = 0; j < 5; j++) par[q][j] = stage_dw[(q * 64 + lane) * 5 + j];
+			wave_lds_fence();
+		}
+
+		#pragma unroll
+		for (int q = 0; q < 4; q++) {                                       // fully unrolled: par[q] stays in registers
+			const int round_first = q * EXP_ROUND;
+			if (round_first >= np) break;                                   // wave-uniform
+			const int nr = (np - round_first < EXP_ROUND) ? (np - round_first) : EXP_ROUND;
+
+			uint32_t out[60];                                               // out[a*5 + j] = dword j of child a
+			#pragma unroll
+			for (int j = 0; j < 5; j++) {
+				const uint32_t x = par[q][j];
+				const int kind_base = (j < 2) ? 0 : 24;
+				const u32x4 r0 = s_rows[kind_base + (x & 0xFF)];
+				const u32x4 r1 = s_rows[kind_base + ((x >> 8) & 0xFF)];
+				const u32x4 r2 = s_rows[kind_base + ((x >> 16) & 0xFF)];
+				const u32x4 r3 = s_rows[kind_base + (x >> 24)];
+				transpose4x4(r0.x, r1.x, r2.x, r3.x, out[0 * 5 + j], out[1 * 5 + j], out[2 * 5 + j], out[3 * 5 + j]);
+				transpose4x4(r0.y, r1.y, r2.y, r3.y, out[4 * 5 + j], out[5 * 5 + j], out[6 * 5 + j], out[7 * 5 + j]);
+				transpose4x4(r0.z, r1.z, r2.z, r3.z, out[8 * 5 + j], out[9 * 5 + j], out[10 * 5 + j], out[11 * 5 + j]);
+			}
+
+			// ---- goal test of the 12 children ----
+			uint32_t fl[3] = {0u, 0u, 0u};
+			if (WITH_FLAGS) {
+				#pragma unroll
+				for (int a = 0; a < 12; a++)
+					if (is_solved5(&out[a * 5])) fl[a >> 2] |= 1u << (8 * (a & 3));
+			}
+
+			// ---- children out: lane-major 240 B blocks -> wave-contiguous 15 x 1 KiB ----
+			#pragma unroll
+			for (int v = 0; v < 15; v++)
+				L.stage[lane * 15 + v] = u32x4{out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]};
+			if (WITH_FLAGS) {
+				L.flags[lane * 3 + 0] = fl[0];
+				L.flags[lane * 3 + 1] = fl[1];
+				L.flags[lane * 3 + 2] = fl[2];
+			}
+			wave_lds_fence();
+
+			u32x4 *dst = children + (p0 + round_first) * 15;
+			const int nvec = nr * 15;
+			#pragma unroll
+			for (int v = 0; v < 15; v++) {
+				const int idx = v * 64 + lane;
+				const u32x4 val = L.stage[idx];
+				if (idx < nvec) __builtin_nontemporal_store(val, dst + idx);
+			}
+			if (WITH_FLAGS) {
+				uint32_t *fdst = solved + (p0 + round_first) * 3;
+				if (nr == EXP_ROUND && ((reinterpret_cast<uintptr_t>(fdst) & 15) == 0)) {
+					if (lane < 48) {
+						const u32x4 val = reinterpret_cast<const u32x4 *>(L.flags)[lane];
+						__builtin_nontemporal_store(val, reinterpret_cast<u32x4 *>(fdst) + lane);
+					}
+				} else {
+					#pragma unroll
+					for (int k = 0; k < 3; k++) {
+						const int idx = k * 64 + lane;
+						if (idx < nr * 3) fdst[idx] = L.flags[idx];
+					}
+				}
+				// solved children are rare: one ballot decides whether anybody reports
+				const bool any = (fl[0] | fl[1] | fl[2]) != 0u && lane < nr;
+				if (stats != nullptr && __ballot(any) != 0ull && any) {
+					const int cnt = __popc(fl[0]) + __popc(fl[1]) + __popc(fl[2]);
+					int first = 0;
+					#pragma unroll
+					for (int a = 11; a >= 0; a--)
+						if (fl[a >> 2] & (1u << (8 * (a & 3)))) first = a;
+					atomicAdd(reinterpret_cast<unsigned long long *>(&stats[0]), (unsigned long long)cnt);
+					atomicMin(&stats[1], (long long)((p0 + round_first + lane) * 12 + first));
+				}
+			}
+			wave_lds_fence();
+		}
+	}
+}
+
+// ================================================================================================================
+// multi_rotate: out[i] = move actions[i] on states[i]                                       cube.py:256-263
+// Algorithmic bytes per state: 20 + 1 read, 20 written.
+// A wave owns 256 states (5 KiB in, 5 KiB out, all as 1 KiB dwordx4 accesses); lane l handles states 4l..4l+3 of
+// the tile, i.e. 80 contiguous LDS bytes = five conflict-free ds_read_b128.  The per-lane action selects a 48-byte
+// table (three ds_read_b128 from the 576-byte LDS copy), and each dword of the state is re-coded by lut4().
+// ================================================================================================================
+constexpr int ROW_TILE = 256;     // states per wave tile
+constexpr int ROW_WAVES = 4;
+
+template <bool SPLIT_FD>
+__global__ __launch_bounds__(ROW_WAVES * WAVE)
+void k_multi_rotate(const uint32_t *__restrict__ states, const uint8_t *__restrict__ act_or_faces,
+                    const uint8_t *__restrict__ dirs, uint32_t *__restrict__ out, size_t n, size_t n_tiles)
+{
+	__shared__ u32x4 s_act[36];
+	__shared__ u32x4 s_buf[ROW_WAVES][320];       // 5 120 B per wave
+
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	stage_action_tables(s_act, tid);
+	__syncthreads();
+
+	u32x4 *buf = s_buf[wv];
+	uint32_t *buf_dw = reinterpret_cast<uint32_t *>(buf);
+
+	for (size_t tile = (size_t)blockIdx.x * ROW_WAVES + wv; tile < n_tiles; tile += (size_t)gridDim.x * ROW_WAVES) {
+		const size_t p0 = tile * ROW_TILE;
+		const int np = (int)((n - p0 < (size_t)ROW_TILE) ? (n - p0) : (size_t)ROW_TILE);
+		const uint32_t *src = states + p0 * STATE_DWORDS;
+		uint32_t *dst = out + p0 * STATE_DWORDS;
+		const bool full = np == ROW_TILE && (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0);
+
+		if (full) {
+			const u32x4 *src4 = reinterpret_cast<const u32x4 *>(src);
+			#pragma unroll
+			for (int k = 0; k < 5; k++) buf[k * 64 + lane] = src4[k * 64 + lane];
+		} else {
+			const int ndw = np * STATE_DWORDS;
+			#pragma unroll
+			for (int k = 0; k < 20; k++) {
+				const int idx = k * 64 + lane;
+				buf_dw[idx] = idx < ndw ? src[idx] : 0u;
+			}
+		}
+		// the four actions of this lane's states
+		uint32_t act[4];
+		#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			const size_t i = p0 + 4 * lane + q;
+			uint32_t a = 0;
+			if (4 * lane + q < np) a = SPLIT_FD ? (2u * act_or_faces[i] + (1u - dirs[i])) : act_or_faces[i];
+			act[q] = a < 12u ? a : 0u;            // out-of-range actions are rejected on the host; never index past the table
+		}
+		wave_lds_fence();
+
+		u32x4 v[5];
+		#pragma unroll
+		for (int k = 0; k < 5; k++) v[k] = buf[lane * 5 + k];
+		uint32_t s[20] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w, v[2].x, v[2].y, v[2].z, v[2].w,
+		                  v[3].x, v[3].y, v[3].z, v[3].w, v[4].x, v[4].y, v[4].z, v[4].w};
+		#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			uint32_t tab[12];
+			load_action_table(s_act, act[q], tab);
+			move5(&s[5 * q], tab);
+		}
+		#pragma unroll
+		for (int k = 0; k < 5; k++) buf[lane * 5 + k] = u32x4{s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]};
+		wave_lds_fence();
+
+		if (full) {
+			u32x4 *dst4 = reinterpret_cast<u32x4 *>(dst);
+			#pragma unroll
+			for (int k = 0; k < 5; k++) dst4[k * 64 + lane] = buf[k * 64 + lane];
+		} else {
+			const int ndw = np * STATE_DWORDS;
+			#pragma unroll
+			for (int k = 0; k < 20; k++) {
+				const int idx = k * 64 + lane;
+				if (idx < ndw) dst[idx] = buf_dw[idx];
+			}
+		}
+		wave_lds_fence();
+	}
+}
+
+// ================================================================================================================
+// multi_is_solved: flags[i] = states[i] == solved                                               cube.py:88-89
+// Algorithmic bytes per state: 20 read + 1 written.  Same tile shape as multi_rotate; the four flag bytes of a lane
+// form one dword, so flags leave as one coalesced 256-byte store per tile.  Counting and "first solved index" use a
+// wave ballot so that only waves that saw a solved state touch the atomics.
+// ================================================================================================================
+__global__ __launch_bounds__(ROW_WAVES * WAVE)
+void k_multi_is_solved(const uint32_t *__restrict__ states, uint8_t *__restrict__ flags, long long *__restrict__ stats,
+                       size_t n, size_t n_tiles)
+{
+	__shared__ u32x4 s_buf[ROW_WAVES][320];
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	u32x4 *buf = s_buf[wv];
+	uint32_t *buf_dw = reinterpret_cast<uint32_t *>(buf);
+
+	for (size_t tile = (size_t)blockIdx.x * ROW_WAVES + wv; tile < n_tiles; tile += (size_t)gridDim.x * ROW_WAVES) {
+		const size_t p0 = tile * ROW_TILE;
+		const int np = (int)((n - p0 < (size_t)ROW_TILE) ? (n - p0) : (size_t)ROW_TILE);
+		const uint32_t *src = states + p0 * STATE_DWORDS;
+		if (np == ROW_TILE && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+			const u32x4 *src4 = reinterpret_cast<const u32x4 *>(src);
+			#pragma unroll
+			for (int k = 0; k < 5; k++) buf[k * 64 + lane] = src4[k * 64 + lane];
+		} else {
+			const int ndw = np * STATE_DWORDS;
+			#pragma unroll
+			for (int k = 0; k < 20; k++) {
+				const int idx = k * 64 + lane;
+				buf_dw[idx] = idx < ndw ? src[idx] : 0xFFFFFFFFu;
+			}
+		}
+		wave_lds_fence();
+		u32x4 v[5];
+		#pragma unroll
+		for (int k = 0; k < 5; k++) v[k] = buf[lane * 5 + k];
+		const uint32_t s[20] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w, v[2].x, v[2].y, v[2].z, v[2].w,
+		                        v[3].x, v[3].y, v[3].z, v[3].w, v[4].x, v[4].y, v[4].z, v[4].w};
+		uint32_t fl = 0;
+		#pragma unroll
+		for (int q = 0; q < 4; q++)
+			if (4 * lane + q < np && is_solved5(&s[5 * q])) fl |= 1u << (8 * q);
+		if (flags != nullptr) {
+			uint8_t *fdst = flags + p0;
+			if (np == ROW_TILE && ((reinterpret_cast<uintptr_t>(fdst) & 3) == 0)) {
+				reinterpret_cast<uint32_t *>(fdst)[lane] = fl;
+			} else {
+				#pragma unroll
+				for (int q = 0; q < 4; q++)
+					if (4 * lane + q < np) fdst[4 * lane + q] = (uint8_t)((fl >> (8 * q)) & 1u);
+			}
+		}
+		if (stats != nullptr && __ballot(fl != 0u) != 0ull && fl != 0u) {
+			atomicAdd(reinterpret_cast<unsigned long long *>(&stats[0]), (unsigned long long)__popc(fl));
+			const int firstq = (__ffs(fl) - 1) >> 3;
+			atomicMin(&stats[1], (long long)(p0 + 4 * lane + firstq));
+		}
+		wave_lds_fence();
+	}
+}
+
+// ================================================================================================================
+// apply_sequences: every game starts solved and applies its column of a (depth, games) action matrix
+//                                                                              cube.py:206-216, cube.py:218-232
+// One lane per game; the state never leaves registers.  Reads of the action matrix are coalesced across games.
+// ================================================================================================================
+__global__ __launch_bounds__(256)
+void k_apply_sequences(const uint8_t *__restrict__ actions, int moves, int games, int with_solved, int only_last,
+                       uint32_t *__restrict__ out)
+{
+	__shared__ u32x4 s_act[36];
+	stage_action_tables(s_act, threadIdx.x);
+	__syncthreads();
+	const int g = blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= games) return;
+	uint32_t s[5] = {SOLVED_DW[0], SOLVED_DW[1], SOLVED_DW[2], SOLVED_DW[3], SOLVED_DW[4]};
+	const int rows = moves + (with_solved ? 1 : 0);
+	uint32_t *o = out + (size_t)g * (only_last ? 1 : rows) * STATE_DWORDS;
+	if (!only_last && with_solved) {
+		#pragma unroll
+		for (int j = 0; j < 5; j++) o[j] = s[j];
+		o += STATE_DWORDS;
+	}
+	for (int d = 0; d < moves; d++) {
+		uint32_t a = actions[(size_t)d * games + g];
+		a = a < 12u ? a : 0u;
+		uint32_t tab[12];
+		load_action_table(s_act, a, tab);
+		move5(s, tab);
+		if (!only_last) {
+			#pragma unroll
+			for (int j = 0; j < 5; j++) o[j] = s[j];
+			o += STATE_DWORDS;
+		}
+	}
+	if (only_last) {
+		#pragma unroll
+		for (int j = 0; j < 5; j++) o[j] = s[j];
+	}
+}
+
+// ================================================================================================================
+// as_oh: (n, 20) int8 -> (n, 480) one-hot, oh[r][24 i + s[r][i]] = 1                            cube.py:265-277
+// Algorithmic bytes per state: 20 read + 480 * sizeof(T) written (1 920 for f32): a pure store stream.  A workgroup
+// encodes 64 states per step; each thread emits 16-byte chunks (4 f32 or 8 half/bf16 columns of one cubie).
+// ================================================================================================================
+template <typename T> struct OhOne;
+template <> struct OhOne<float>    { static constexpr uint32_t bits = 0x3F800000u; };
+template <> struct OhOne<_Float16> { static constexpr uint32_t bits = 0x3C00u; };
+struct bf16_tag {};
+template <> struct OhOne<bf16_tag> { static constexpr uint32_t bits = 0x3F80u; };
+
+template <typename T, int ELEM_BYTES>
+__global__ __launch_bounds__(256)
+void k_as_oh(const uint32_t *__restrict__ states, u32x4 *__restrict__ out, size_t n, size_t n_tiles)
+{
+	constexpr int E = 16 / ELEM_BYTES;            // columns per 16-byte chunk: 4 or 8
+	constexpr int CHUNKS_PER_ROW = 480 / E;       // 120 or 60
+	constexpr int CHUNKS_PER_CUBIE = 24 / E;      // 6 or 3
+	__shared__ uint32_t s_st[64 * STATE_DWORDS];
+	const int tid = threadIdx.x;
+	const uint8_t *s_bytes = reinterpret_cast<const uint8_t *>(s_st);
+
+	for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		const size_t p0 = tile * 64;
+		const int np = (int)((n - p0 < 64) ? (n - p0) : 64);
+		const int ndw = np * STATE_DWORDS;
+		for (int idx = tid; idx < 64 * STATE_DWORDS; idx += 256) s_st[idx] = idx < ndw ? states[p0 * STATE_DWORDS + idx] : 0u;
+		__syncthreads();
+		const int nchunks = np * CHUNKS_PER_ROW;
+		u32x4 *dst = out + p0 * CHUNKS_PER_ROW;
+		for (int c = tid; c < nchunks; c += 256) {
+			const int r = c / CHUNKS_PER_ROW, g = c - r * CHUNKS_PER_ROW;
+			const int cubie = g / CHUNKS_PER_CUBIE;
+			const int base = (g - cubie * CHUNKS_PER_CUBIE) * E;
+			const int rel = (int)s_bytes[r * STATE_BYTES + cubie] - base;     // position of the 1 inside this chunk, if any
+			u32x4 val = {0u, 0u, 0u, 0u};
+			if (ELEM_BYTES == 4) {
+				val.x = rel == 0 ? OhOne<T>::bits : 0u;
+				val.y = rel == 1 ? OhOne<T>::bits : 0u;
+				val.z = rel == 2 ? OhOne<T>::bits : 0u;
+				val.w = rel == 3 ? OhOne<T>::bits : 0u;
+			} else {
+				const uint32_t one = OhOne<T>::bits << (16 * (rel & 1));
+				val.x = (rel >> 1) == 0 && rel >= 0 ? one : 0u;
+				val.y = (rel >> 1) == 1 ? one : 0u;
+				val.z = (rel >> 1) == 2 ? one : 0u;
+				val.w = (rel >> 1) == 3 ? one : 0u;
+			}
+			dst[c] = val;
+		}
+		__syncthreads();
+	}
+}
+
+// ================================================================================================================
+// 6x8x6 representation (cube.py:311-388).  A state is 48 sticker slots x 6 one-hot int8 = 144 ushorts; a move is a
+// permutation of the slots, so every kernel is a gather of 3-ushort groups through the 576-byte slot table in LDS.
+// These are "next" rows of the scope table: correct and coalesced on the store side, not yet tuned.
+// ================================================================================================================
+__device__ __forceinline__ void stage_perm686(uint8_t *lds, int tid, int nthreads)
+{
+	const uint8_t *src = &D_TAB.perm686[0][0];
+	for (int i = tid; i < N_ACTIONS * S686_SLOTS; i += nthreads) lds[i] = src[i];
+}
+
+// FANOUT = false: out[r] = move actions[r] of states[r].  FANOUT = true: out[12 r + a] = move a of states[r].
+template <bool FANOUT>
+__global__ __launch_bounds__(256)
+void k_rotate686(const uint16_t *__restrict__ states, const uint8_t *__restrict__ actions, uint16_t *__restrict__ out, size_t n_out)
+{
+	__shared__ uint8_t s_perm[N_ACTIONS * S686_SLOTS];
+	stage_perm686(s_perm, threadIdx.x, blockDim.x);
+	__syncthreads();
+	const size_t total = n_out * 144;
+	for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+		const size_t r = idx / 144;
+		const int u = (int)(idx - r * 144), slot = u / 3, part = u - slot * 3;
+		size_t src_row;
+		uint32_t a;
+		if (FANOUT) { src_row = r / 12; a = (uint32_t)(r - src_row * 12); }
+		else        { src_row = r; a = actions[r]; a = a < 12u ? a : 0u; }
+		out[idx] = states[src_row * 144 + (int)s_perm[a * S686_SLOTS + slot] * 3 + part];
+	}
+}
+
+// one wave per state: 72 dwords against the solved pattern
+__global__ __launch_bounds__(256)
+void k_is_solved686(const uint32_t *__restrict__ states, uint8_t *__restrict__ flags, long long *__restrict__ stats, size_t n)
+{
+	const int lane = threadIdx.x & 63;
+	const uint32_t *sol = reinterpret_cast<const uint32_t *>(D_TAB.solved686);
+	const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+	for (size_t r = wave; r < n; r += nwaves) {
+		const uint32_t *s = states + r * 72;
+		bool diff = s[lane] != sol[lane];
+		if (lane < 8) diff |= s[64 + lane] != sol[64 + lane];
+		const bool ok = __ballot(diff) == 0ull;
+		if (lane == 0) {
+			if (flags != nullptr) flags[r] = ok ? 1 : 0;
+			if (ok && stats != nullptr) {
+				atomicAdd(reinterpret_cast<unsigned long long *>(&stats[0]), 1ull);
+				atomicMin(&stats[1], (long long)r);
+			}
+		}
+	}
+}
+
+// int8 one-hot -> T one-hot, elementwise widening (cube.py:363-369)
+template <typename T, int ELEM_BYTES>
+__global__ __launch_bounds__(256)
+void k_as_oh686(const uint32_t *__restrict__ states, u32x4 *__restrict__ out, size_t n_dwords)
+{
+	// each thread widens one dword (4 int8) into 4 elements
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_dwords; i += (size_t)gridDim.x * blockDim.x) {
+		const uint32_t x = states[i];
+		if (ELEM_BYTES == 4) {
+			u32x4 v;
+			v.x = (x & 0xFFu) ? OhOne<T>::bits : 0u;
+			v.y = (x & 0xFF00u) ? OhOne<T>::bits : 0u;
+			v.z = (x & 0xFF0000u) ? OhOne<T>::bits : 0u;
+			v.w = (x & 0xFF000000u) ? OhOne<T>::bits : 0u;
+			out[i] = v;
+		} else {
+			u32x2 v;
+			v.x = ((x & 0xFFu) ? OhOne<T>::bits : 0u) | ((x & 0xFF00u) ? OhOne<T>::bits << 16 : 0u);
+			v.y = ((x & 0xFF0000u) ? OhOne<T>::bits : 0u) | ((x & 0xFF000000u) ? OhOne<T>::bits << 16 : 0u);
+			reinterpret_cast<u32x2 *>(out)[i] = v;
+		}
+	}
+}
+
+// as_correct (cube.py:371-380): +1 where slot (f, p) shows colour f, else -1
+__global__ __launch_bounds__(256)
+void k_as_correct686(const int8_t *__restrict__ states, float *__restrict__ out, size_t n_slots)
+{
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (size_t)gridDim.x * blockDim.x) {
+		const int slot = (int)(i % 48), face = slot >> 3;
+		const int8_t *s = states + i * 6;
+		bool ok = true;
+		#pragma unroll
+		for (int c = 0; c < 6; c++) ok &= s[c] == (c == face ? 1 : 0);
+		out[i] = ok ? 1.0f : -1.0f;
+	}
+}
+
+// ================================================================================================================
+// launchers
+// ================================================================================================================
+static inline unsigned grid_for(size_t work_items, size_t per_block, unsigned cap)
+{
+	size_t b = (work_items + per_block - 1) / per_block;
+	if (b < 1) b = 1;
+	if (b > cap) b = cap;
+	return (unsigned)b;
+}
+
+void launch_expand12(const int8_t *parents, int8_t *children, uint8_t *solved, long long *stats, size_t n, hipStream_t st)
+{
+	const size_t n_tiles = (n + EXP_TILE - 1) / EXP_TILE;
+	const unsigned grid = grid_for(n_tiles, EXP_WAVES, 256u * 2u * 8u);
+	if (solved != nullptr)
+		hipLaunchKernelGGL(k_expand12<true>, dim3(grid), dim3(EXP_WAVES * WAVE), 0, st, (const uint32_t *)parents,
+		                   (u32x4 *)children, (uint32_t *)solved, stats, n, n_tiles);
+	else
+		hipLaunchKernelGGL(k_expand12<false>, dim3(grid), dim3(EXP_WAVES * WAVE), 0, st, (const uint32_t *)parents,
+		                   (u32x4 *)children, (uint32_t *)nullptr, (long long *)nullptr, n, n_tiles);
+}
+
+void launch_multi_rotate(const int8_t *states, const uint8_t *actions, const uint8_t *dirs, int8_t *out, size_t n, hipStream_t st)
+{
+	const size_t n_tiles = (n + ROW_TILE - 1) / ROW_TILE;
+	const unsigned grid = grid_for(n_tiles, ROW_WAVES, 256u * 8u);
+	if (dirs != nullptr)
+		hipLaunchKernelGGL(k_multi_rotate<true>, dim3(grid), dim3(ROW_WAVES * WAVE), 0, st, (const uint32_t *)states, actions, dirs,
+		                   (uint32_t *)out, n, n_tiles);
+	else
+		hipLaunchKernelGGL(k_multi_rotate<false>, dim3(grid), dim3(ROW_WAVES * WAVE), 0, st, (const uint32_t *)states, actions,
+		                   (const uint8_t *)nullptr, (uint32_t *)out, n, n_tiles);
+}
+
+void launch_multi_is_solved(const int8_t *states, uint8_t *flags, long long *stats, size_t n, hipStream_t st)
+{
+	const size_t n_tiles = (n + ROW_TILE - 1) / ROW_TILE;
+	const unsigned grid = grid_for(n_tiles, ROW_WAVES, 256u * 8u);
+	hipLaunchKernelGGL(k_multi_is_solved, dim3(grid), dim3(ROW_WAVES * WAVE), 0, st, (const uint32_t *)states, flags, stats, n, n_tiles);
+}
+
+void launch_apply_sequences(const uint8_t *actions, int moves, int games, int with_solved, int only_last, int8_t *out, hipStream_t st)
+{
+	const unsigned grid = grid_for((size_t)games, 256, 1u << 22);
+	hipLaunchKernelGGL(k_apply_sequences, dim3(grid), dim3(256), 0, st, actions, moves, games, with_solved, only_last, (uint32_t *)out);
+}
+
+void launch_as_oh(const int8_t *states, void *out, int out_dtype, size_t n, hipStream_t st)
+{
+	const size_t n_tiles = (n + 63) / 64;
+	const unsigned grid = grid_for(n_tiles, 1, 256u * 8u);
+	if (out_dtype == 0)
+		hipLaunchKernelGGL((k_as_oh<float, 4>), dim3(grid), dim3(256), 0, st, (const uint32_t *)states, (u32x4 *)out, n, n_tiles);
+	else if (out_dtype == 1)
+		hipLaunchKernelGGL((k_as_oh<_Float16, 2>), dim3(grid), dim3(256), 0, st, (const uint32_t *)states, (u32x4 *)out, n, n_tiles);
+	else
+		hipLaunchKernelGGL((k_as_oh<bf16_tag, 2>), dim3(grid), dim3(256), 0, st, (const uint32_t *)states, (u32x4 *)out, n, n_tiles);
+}
+
+void launch_rotate686(const int8_t *states, const uint8_t *actions, int8_t *out, size_t n_out, bool fanout, hipStream_t st)
+{
+	const unsigned grid = grid_for(n_out * 144, 256, 256u * 16u);
+	if (fanout)
+		hipLaunchKernelGGL(k_rotate686<true>, dim3(grid), dim3(256), 0, st, (const uint16_t *)states, actions, (uint16_t *)out, n_out);
+	else
+		hipLaunchKernelGGL(k_rotate686<false>, dim3(grid), dim3(256), 0, st, (const uint16_t *)states, actions, (uint16_t *)out, n_out);
+}
+
+void launch_is_solved686(const int8_t *states, uint8_t *flags, long long *stats, size_t n, hipStream_t st)
+{
+	const unsigned grid = grid_for(n, 4, 256u * 8u);
+	hipLaunchKernelGGL(k_is_solved686, dim3(grid), dim3(256), 0, st, (const uint32_t *)states, flags, stats, n);
+}
+
+void launch_as_oh686(const int8_t *states, void *out, int out_dtype, size_t n, hipStream_t st)
+{
+	const size_t ndw = n * 72;
+	const unsigned grid = grid_for(ndw, 256, 256u * 8u);
+	if (out_dtype == 0)
+		hipLaunchKernelGGL((k_as_oh686<float, 4>), dim3(grid), dim3(256), 0, st, (const uint32_t *)states, (u32x4 *)out, ndw);
+	else if (out_dtype == 1)
+		hipLaunchKernelGGL((k_as_oh686<_Float16, 2>), dim3(grid), dim3(256), 0, st, (const uint32_t *)states, (u32x4 *)out, ndw);
+	else
+		hipLaunchKernelGGL((k_as_oh686<bf16_tag, 2>), dim3(grid), dim3(256), 0, st, (const uint32_t *)states, (u32x4 *)out, ndw);
+}
+
+void launch_as_correct686(const int8_t *states, float *out, size_t n, hipStream_t st)
+{
+	const unsigned grid = grid_for(n * 48, 256, 256u * 8u);
+	hipLaunchKernelGGL(k_as_correct686, dim3(grid), dim3(256), 0, st, states, out, n * 48);
+}
+
+const Tables &host_tables()
+{
+	static const Tables t = make_tables();
+	return t;
+}
+
+}  // namespace rk

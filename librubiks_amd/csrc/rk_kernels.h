@@ -1,0 +1,26 @@
+// Host-callable launchers of the cube kernels (definitions in rk_cube_kernels.hip).  Arguments are validated by
+// the C-ABI layer (rk_api.hip); launchers assume non-null, aligned, in-range inputs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include "rk_tables.h"
+
+namespace rk {
+
+const Tables &host_tables();
+
+void launch_expand12(const int8_t *parents, int8_t *children, uint8_t *solved, long long *stats, size_t n, hipStream_t st);
+void launch_multi_rotate(const int8_t *states, const uint8_t *actions_or_faces, const uint8_t *dirs_or_null, int8_t *out,
+                         size_t n, hipStream_t st);
+void launch_multi_is_solved(const int8_t *states, uint8_t *flags, long long *stats, size_t n, hipStream_t st);
+void launch_apply_sequences(const uint8_t *actions, int moves, int games, int with_solved, int only_last, int8_t *out,
+                            hipStream_t st);
+void launch_as_oh(const int8_t *states, void *out, int out_dtype, size_t n, hipStream_t st);
+
+void launch_rotate686(const int8_t *states, const uint8_t *actions, int8_t *out, size_t n_out, bool fanout, hipStream_t st);
+void launch_is_solved686(const int8_t *states, uint8_t *flags, long long *stats, size_t n, hipStream_t st);
+void launch_as_oh686(const int8_t *states, void *out, int out_dtype, size_t n, hipStream_t st);
+void launch_as_correct686(const int8_t *states, float *out, size_t n, hipStream_t st);
+
+}  // namespace rk

@@ -1,0 +1,437 @@
+"""
+Drop-in for `librubiks.cube` (reference: librubiks/cube/cube.py) whose arithmetic runs on the MI355X.
+
+Same names, argument meaning, dtypes, shapes and out-of-place behaviour as the reference module; every
+function that touches cube state launches a HIP kernel of librubiks_hip.so through ctypes.  NumPy in ->
+NumPy out (host arrays are copied to the device and back); torch CUDA tensors in -> torch CUDA tensors out
+(no copies, launches are ordered on torch's current stream) -- the second form is what the search engines
+and bench.py use.
+
+Random draws (scramble, sequence_scrambler) stay on the host's legacy NumPy generator in the reference's
+draw order, so seeds reproduce the reference's scrambles exactly; the moves are applied on the device.
+"""
+from __future__ import annotations
+
+import functools
+
+import numpy as np
+import torch
+
+from librubiks_amd import gpu, _ffi
+from librubiks_amd._ffi import REPR_2024, REPR_686, INT64_MAX
+
+####################
+# Action constants #   (cube.py:29-35)
+####################
+F, B, T, D, L, R = 0, 1, 2, 3, 4, 5
+action_names = ('F', 'B', 'T', 'D', 'L', 'R')
+action_space = [(a // 2, 1 - a % 2) for a in range(12)]
+action_dim = len(action_space)
+dtype = np.int8
+
+_ITER_ACTIONS_1 = np.array([[a // 2 for a in range(12)], [1 - a % 2 for a in range(12)]], dtype=np.uint8)
+
+##################
+# Representation #   (cube.py:96-128)
+##################
+_is2024 = True
+_stored_repr: bool = True
+
+
+def set_is2024(is2024: bool):
+	global _is2024
+	assert type(is2024) is bool
+	_is2024 = is2024
+
+
+def get_is2024():
+	return _is2024
+
+
+def store_repr():
+	global _stored_repr
+	_stored_repr = _is2024
+
+
+def restore_repr():
+	global _is2024
+	_is2024 = _stored_repr
+
+
+def with_used_repr(fun):
+	"""Method decorator: run with the representation in self.is2024, restore afterwards (cube.py:115-124)."""
+	@functools.wraps(fun)
+	def wrapper(self, *args, **kwargs):
+		store_repr()
+		set_is2024(self.is2024)
+		try:
+			return fun(self, *args, **kwargs)
+		finally:
+			restore_repr()
+	return wrapper
+
+
+def _repr_id() -> int:
+	return REPR_2024 if _is2024 else REPR_686
+
+
+def shape():
+	return (20,) if _is2024 else (6, 8, 6)
+
+
+def _row_bytes() -> int:
+	return 20 if _is2024 else 288
+
+
+def get_oh_shape() -> int:
+	return 480 if _is2024 else 288
+
+
+##########
+# Solved #   (cube.py:58-89)
+##########
+def _load_solved(repr_id: int, shp) -> np.ndarray:
+	out = np.empty(shp, dtype=np.int8)
+	_ffi.check(_ffi.lib().rk_solved(repr_id, out.ctypes.data))
+	return out
+
+
+_solved2024 = _load_solved(REPR_2024, (20,))
+_solved686 = _load_solved(REPR_686, (6, 8, 6))
+
+
+def get_solved_instance() -> np.ndarray:
+	"""The shared instance -- read only by convention (cube.py:77-80)."""
+	return _solved2024 if _is2024 else _solved686
+
+
+def get_solved() -> np.ndarray:
+	return get_solved_instance().copy()
+
+
+################
+# Device plumbing
+################
+def _is_dev(x) -> bool:
+	return isinstance(x, torch.Tensor) and x.is_cuda
+
+
+def _to_dev_states(states) -> torch.Tensor:
+	"""(n, *shape) int8 on the GPU, contiguous."""
+	if isinstance(states, torch.Tensor):
+		t = states if states.dtype == torch.int8 else states.to(torch.int8)
+		return t.to(gpu, non_blocking=True).contiguous()
+	arr = np.ascontiguousarray(states, dtype=np.int8)
+	return torch.from_numpy(arr).to(gpu)
+
+
+def _to_dev_u8(x) -> torch.Tensor:
+	if isinstance(x, torch.Tensor):
+		return x.to(device=gpu, dtype=torch.uint8).contiguous()
+	return torch.from_numpy(np.ascontiguousarray(x, dtype=np.uint8)).to(gpu)
+
+
+def _actions_from(faces, dirs, n: int) -> torch.Tensor:
+	"""Validated uint8 action indices 2*face + (1-dir) on the device (cube.py:33-34)."""
+	if _is_dev(faces) or _is_dev(dirs):
+		f = torch.as_tensor(faces, device=gpu).to(torch.int64)
+		d = torch.as_tensor(dirs, device=gpu).to(torch.int64)
+		a = 2 * f + (1 - d)
+		return a.to(torch.uint8).contiguous()
+	f = np.asarray(faces).astype(np.int64).ravel()
+	d = np.asarray(dirs).astype(np.int64).ravel()
+	if len(f) != n or len(d) != n:
+		raise IndexError(f"need {n} faces and directions, got {len(f)} and {len(d)}")
+	if n and (f.min() < 0 or f.max() > 5 or d.min() < 0 or d.max() > 1):
+		raise IndexError("face must be in 0..5 and direction in 0..1")
+	return torch.from_numpy((2 * f + (1 - d)).astype(np.uint8)).to(gpu)
+
+
+def _new_stats() -> torch.Tensor:
+	return torch.tensor([0, INT64_MAX], dtype=torch.int64, device=gpu)
+
+
+class device:
+	"""
+	Device-resident forms of the hot path: torch CUDA tensors in and out, no host copies, no synchronisation.
+	`states` are int8 (n, 20) [or (n, 6, 8, 6)], contiguous.  These are thin wrappers over the C ABI.
+	"""
+
+	@staticmethod
+	def multi_rotate(states: torch.Tensor, actions: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+		"""out[i] = move actions[i] (uint8 action index) applied to states[i]   (cube.py:256-263)."""
+		_ffi.require_gpu()
+		n = len(states)
+		if out is None:
+			out = torch.empty_like(states)
+		_ffi.check(_ffi.lib().rk_multi_rotate(_repr_id(), states.data_ptr(), actions.data_ptr(), out.data_ptr(), n, _ffi.stream_ptr()))
+		return out
+
+	@staticmethod
+	def expand12(parents: torch.Tensor, children: torch.Tensor = None, solved: torch.Tensor = None,
+	             stats: torch.Tensor = None, want_flags: bool = True):
+		"""
+		All 12 children of every parent, parent-major / action-minor, with the goal test fused
+		(agents.py:277-281 + cube.py:88-89).  Returns (children int8 (12n, ...), solved uint8 (12n,) or None).
+		`stats` (int64[2] = [count, first index], initialise to [0, INT64_MAX]) is updated if given.
+		"""
+		_ffi.require_gpu()
+		n = len(parents)
+		if children is None:
+			children = torch.empty((12 * n, *parents.shape[1:]), dtype=torch.int8, device=parents.device)
+		if solved is None and want_flags:
+			solved = torch.empty(12 * n, dtype=torch.uint8, device=parents.device)
+		_ffi.check(_ffi.lib().rk_expand12(
+			_repr_id(), parents.data_ptr(), children.data_ptr(),
+			solved.data_ptr() if solved is not None else None,
+			stats.data_ptr() if stats is not None else None, n, _ffi.stream_ptr()))
+		return children, solved
+
+	@staticmethod
+	def multi_is_solved(states: torch.Tensor, flags: torch.Tensor = None, stats: torch.Tensor = None) -> torch.Tensor:
+		"""uint8 (n,) flags, 1 where the state is solved (cube.py:88-89)."""
+		_ffi.require_gpu()
+		n = len(states)
+		if flags is None:
+			flags = torch.empty(n, dtype=torch.uint8, device=states.device)
+		_ffi.check(_ffi.lib().rk_multi_is_solved(
+			_repr_id(), states.data_ptr(), flags.data_ptr(), stats.data_ptr() if stats is not None else None,
+			n, _ffi.stream_ptr()))
+		return flags
+
+	@staticmethod
+	def apply_sequences(actions: torch.Tensor, with_solved: bool, only_last: bool) -> torch.Tensor:
+		"""actions uint8 (depth, games) -> states of every game along its move sequence (cube.py:218-232)."""
+		_ffi.require_gpu()
+		depth, games = actions.shape
+		moves = depth - int(with_solved)
+		rows = 1 if only_last else moves + int(with_solved)
+		out = torch.empty((games * max(rows, 0), 20), dtype=torch.int8, device=gpu)
+		_ffi.check(_ffi.lib().rk_apply_sequences(
+			REPR_2024, actions.data_ptr(), depth, games, int(with_solved), int(only_last), out.data_ptr(), _ffi.stream_ptr()))
+		return out
+
+	@staticmethod
+	def as_oh(states: torch.Tensor, out: torch.Tensor = None, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+		"""One-hot (n, 480 | 288) of `dtype` (float32, float16 or bfloat16)   (cube.py:265-277, 363-369)."""
+		_ffi.require_gpu()
+		n = len(states)
+		code = {torch.float32: _ffi.OH_F32, torch.float16: _ffi.OH_F16, torch.bfloat16: _ffi.OH_BF16}[dtype]
+		if out is None:
+			out = torch.empty((n, get_oh_shape()), dtype=dtype, device=states.device)
+		_ffi.check(_ffi.lib().rk_as_oh(_repr_id(), states.data_ptr(), out.data_ptr(), code, n, _ffi.stream_ptr()))
+		return out
+
+
+################
+# Rotate logic #   (cube.py:41-52)
+################
+def rotate(state: np.ndarray, face: int, direction: int) -> np.ndarray:
+	"""One move on one state: face 0..5, direction 0 (negative) or 1 (positive).  Out of place."""
+	face, direction = int(face), int(direction)
+	if _is_dev(state):
+		acts = torch.tensor([2 * face + (1 - direction)], dtype=torch.uint8, device=gpu)
+		return device.multi_rotate(state.reshape(1, *shape()).contiguous(), acts)[0]
+	return multi_rotate(np.asarray(state)[None], [face], [direction])[0]
+
+
+def multi_rotate(states: np.ndarray, faces: np.ndarray, directions: np.ndarray) -> np.ndarray:
+	"""Performs action (faces[i], directions[i]) on states[i]; returns a new array."""
+	_ffi.require_gpu()
+	n = len(states)
+	if n == 0:
+		return states.clone() if isinstance(states, torch.Tensor) else np.array(states, dtype=np.int8, copy=True)
+	acts = _actions_from(faces, directions, n)
+	out = device.multi_rotate(_to_dev_states(states), acts)
+	return out if _is_dev(states) else out.cpu().numpy()
+
+
+def expand(states: np.ndarray, return_solved: bool = False):
+	"""
+	The fan-out idiom `multi_rotate(np.repeat(states, 12, 0), *iter_actions(len(states)))` as one call
+	(agents.py:277-281, train.py:285): (12 n, ...) children, parent-major.  Not in the reference's surface; the
+	search engines and the trainer's data generation call this instead of building 12 n action tuples.
+	"""
+	_ffi.require_gpu()
+	dev_in = _is_dev(states)
+	children, solved = device.expand12(_to_dev_states(states), want_flags=return_solved)
+	if not dev_in:
+		children = children.cpu().numpy()
+		solved = solved.cpu().numpy().astype(bool) if return_solved else None
+	elif return_solved:
+		solved = solved.bool()
+	return (children, solved) if return_solved else children
+
+
+#################
+# Solving logic #   (cube.py:85-89)
+#################
+def is_solved(state: np.ndarray) -> bool:
+	return bool(multi_is_solved(state.reshape(1, *shape()))[0])
+
+
+def multi_is_solved(states: np.ndarray) -> np.ndarray:
+	_ffi.require_gpu()
+	if len(states) == 0:
+		return np.zeros(0, dtype=bool)
+	flags = device.multi_is_solved(_to_dev_states(states))
+	return flags.bool() if _is_dev(states) else flags.cpu().numpy().astype(bool)
+
+
+########################
+# Representation logic #   (cube.py:130-173)
+########################
+def as_oh(states: np.ndarray) -> torch.Tensor:
+	"""n states -> (n, 480) [or (n, 288)] float32 one-hot tensor on `librubiks_amd.gpu`; one state -> (1, ...)."""
+	_ffi.require_gpu()
+	t = _to_dev_states(states)
+	if t.dim() == len(shape()):
+		t = t.unsqueeze(0)
+	return device.as_oh(t)
+
+
+def as_correct(t: torch.Tensor) -> torch.Tensor:
+	"""6x8x6 only: (n, 6, 8) float tensor, +1 where a sticker shows its face's colour, -1 elsewhere (cube.py:371-380)."""
+	assert not get_is2024(), "Correctness representation is only implemented for 20x24 representation"
+	_ffi.require_gpu()
+	n = len(t)
+	s = t.reshape(n, 288).to(device=gpu, dtype=torch.int8).contiguous()
+	out = torch.empty((n, 6, 8), dtype=torch.float32, device=gpu)
+	_ffi.check(_ffi.lib().rk_as_correct686(s.data_ptr(), out.data_ptr(), n, _ffi.stream_ptr()))
+	return out
+
+
+def repeat_state(state: np.ndarray, n: int = action_dim) -> np.ndarray:
+	"""n copies of `state` as an (n, *shape) array (cube.py:142-147)."""
+	if isinstance(state, torch.Tensor):
+		return state.unsqueeze(0).repeat(n, *[1] * state.dim())
+	state = np.asarray(state)
+	return np.tile(state, [n, *[1] * state.ndim])
+
+
+################
+# Action logic #   (cube.py:179-200)
+################
+def iter_actions(n: int = 1) -> np.ndarray:
+	"""uint8 (2, 12 n): the 12 (face, direction) pairs tiled n times, for use with multi_rotate."""
+	return np.tile(_ITER_ACTIONS_1, (1, n))
+
+
+def indices_to_actions(indices: np.ndarray):
+	faces = indices // 2
+	dirs = 1 - indices % 2
+	return faces, dirs
+
+
+def rev_action(action: int) -> int:
+	return action + 1 if action % 2 == 0 else action - 1
+
+
+def rev_actions(actions: np.ndarray) -> np.ndarray:
+	actions = np.asarray(actions)
+	return actions + 1 - 2 * (actions % 2)
+
+
+##################
+# Scramble logic #   (cube.py:206-234)
+##################
+def _apply(actions_dg: np.ndarray, with_solved: bool, only_last: bool) -> np.ndarray:
+	acts = torch.from_numpy(np.ascontiguousarray(actions_dg, dtype=np.uint8)).to(gpu)
+	return device.apply_sequences(acts, with_solved, only_last).cpu().numpy()
+
+
+def scramble(depth: int, force_not_solved=False):
+	"""Random walk of `depth` moves from solved: returns (state, faces, dirs).  Same draws as the reference."""
+	_ffi.require_gpu()
+	while True:
+		faces = np.random.randint(6, size=(depth,))
+		dirs = np.random.randint(2, size=(depth,))
+		if _is2024:
+			state = _apply((2 * faces + (1 - dirs)).reshape(depth, 1), False, True)[0] if depth else get_solved()
+		else:
+			state = get_solved()
+			for f, d in zip(faces, dirs):
+				state = rotate(state, f, d)
+		if not (force_not_solved and depth != 0 and is_solved(state)):
+			return state, faces, dirs
+
+
+def sequence_scrambler(games: int, depth: int, with_solved: bool):
+	"""
+	Out-of-place scrambler for ADI: the states along `games` random walks, game-major, and their one-hot
+	encoding -- (games*depth, *shape) int8 array and (games*depth, oh) float tensor on `gpu`.
+	"""
+	_ffi.require_gpu()
+	faces = np.random.randint(0, 6, (depth, games))
+	dirs = np.random.randint(0, 2, (depth, games))
+	if _is2024:
+		acts = torch.from_numpy((2 * faces + (1 - dirs)).astype(np.uint8)).to(gpu)
+		dev_states = device.apply_sequences(acts, bool(with_solved), False)
+		return dev_states.cpu().numpy(), device.as_oh(dev_states)
+	cur = repeat_state(get_solved_instance(), games)
+	seq = [cur] if with_solved else []
+	for d in range(depth - int(with_solved)):
+		cur = multi_rotate(cur, faces[d], dirs[d])
+		seq.append(cur)
+	states = np.stack(seq, axis=1).reshape(games * len(seq), *shape())
+	return states, as_oh(states)
+
+
+#############
+# Rendering #   (cube.py:149-173, 279-307, 382-388; maps.py:26-51) -- host-side formatting, no cube arithmetic
+#############
+def _sticker_positions():
+	f, b, t, d, l, r = F, B, T, D, L, R
+	corners = (
+		((f, 0, 0), (l, 0, 2), (t, 2, 0)), ((f, 2, 0), (d, 0, 0), (l, 2, 2)),
+		((f, 2, 2), (r, 2, 0), (d, 0, 2)), ((f, 0, 2), (t, 2, 2), (r, 0, 0)),
+		((b, 0, 2), (t, 0, 0), (l, 0, 0)), ((b, 2, 2), (l, 2, 0), (d, 2, 0)),
+		((b, 2, 0), (d, 2, 2), (r, 2, 2)), ((b, 0, 0), (r, 0, 2), (t, 0, 2)),
+	)
+	edges = (
+		((f, 0, 1), (t, 2, 1)), ((f, 1, 0), (l, 1, 2)), ((f, 2, 1), (d, 0, 1)), ((f, 1, 2), (r, 1, 0)),
+		((t, 1, 0), (l, 0, 1)), ((d, 1, 0), (l, 2, 1)), ((d, 1, 2), (r, 2, 1)), ((t, 1, 2), (r, 0, 1)),
+		((b, 0, 1), (t, 0, 1)), ((b, 1, 2), (l, 1, 0)), ((b, 2, 1), (d, 2, 1)), ((b, 1, 0), (r, 1, 2)),
+	)
+	return corners, edges
+
+
+_CORNER_POS, _EDGE_POS = _sticker_positions()
+_RING_TO_33 = np.array([0, 3, 6, 7, 8, 5, 2, 1])
+_RING_SHIFT = np.array([0, 6, 6, 4, 2, 4])
+
+
+def as633(state: np.ndarray) -> np.ndarray:
+	"""(6, 3, 3) colour picture of a state, faces in the order F, B, T, D, L, R."""
+	if isinstance(state, torch.Tensor):
+		state = state.cpu().numpy()
+	pic = np.repeat(np.arange(6), 9).reshape(6, 3, 3)
+	if _is2024:
+		for i in range(8):
+			slot, ori = divmod(int(state[i]), 3)
+			if slot in (0, 2, 5, 7):
+				ori = -ori
+			for where, col in zip(_CORNER_POS[slot], np.roll([s[0] for s in _CORNER_POS[i]], ori)):
+				pic[where] = col
+		for i in range(12):
+			slot, ori = divmod(int(state[8 + i]), 2)
+			for where, col in zip(_EDGE_POS[slot], np.roll([s[0] for s in _EDGE_POS[i]], ori)):
+				pic[where] = col
+		return pic
+	colours = np.argmax(state, axis=2)
+	flat = pic.reshape(6, 9)
+	for face in range(6):
+		flat[face, _RING_TO_33] = np.roll(colours[face], -_RING_SHIFT[face])
+	return flat.reshape(6, 3, 3)
+
+
+def as69(state: np.ndarray) -> np.ndarray:
+	return as633(state).reshape((6, 9))
+
+
+def stringify(state: np.ndarray) -> str:
+	pic = as633(state)
+	grid = np.full((9, 12), " ", dtype="<U1")
+	for face, (r, c) in {T: (0, 1), L: (1, 0), F: (1, 1), R: (1, 2), B: (1, 3), D: (2, 1)}.items():
+		grid[3 * r:3 * r + 3, 3 * c:3 * c + 3] = pic[face].astype(str)
+	return "\n".join(" ".join(row) for row in grid)

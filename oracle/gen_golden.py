@@ -1,0 +1,274 @@
+"""
+Golden-vector capture -- TEST INFRASTRUCTURE.  Runs ONLY in the build container.
+
+Imports the real reference from /root/reference (never copied, never shipped), drives it on
+seeded inputs and writes small input/output fixtures into tests/golden/.  The fixtures are data:
+arrays, hashes and strings.  The GPU box has no /root/reference; tests there read the fixtures.
+
+    PYTHONDONTWRITEBYTECODE=1 python3 oracle/gen_golden.py [--skip-1m]
+
+Fixtures
+  cube_tables.npz   delta table of the reference, the frontend's maps.json arrays, solved states
+  cube_kat.npz      known answers: scrambles K1/K2, random-walk fan-outs K3 (arrays at n=256, SHA-256
+                    at n=10 000 and n=1 000 000), sequence_scrambler K5, one-hot, 6x8x6 moves
+  cube_text.json    stringify() texts, iter_actions literals, hashes
+  astar_trace.npz   unmodified reference AStar driven by an exact-integer stub net
+  mcts_trace.npz    unmodified reference MCTS driven by the same stub
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+warnings.filterwarnings("ignore", category=DeprecationWarning)
+
+from librubiks import cube  # noqa: E402
+from librubiks.cube.cube import _Cube2024  # noqa: E402
+from librubiks.solving import agents  # noqa: E402
+
+
+def sha(a: np.ndarray) -> str:
+	return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def random_walk(n: int, depth: int):
+	"""K3 recipe: n solved states, `depth` rounds of per-row random moves."""
+	s = cube.repeat_state(cube.get_solved(), n)
+	for _ in range(depth):
+		f = np.random.randint(0, 6, n)
+		d = np.random.randint(0, 2, n)
+		s = cube.multi_rotate(s, f, d)
+	return s
+
+
+def fan_out(states: np.ndarray) -> np.ndarray:
+	"""The reference's own 12-child idiom (agents.py:277-281)."""
+	return cube.multi_rotate(np.repeat(states, 12, axis=0), *cube.iter_actions(len(states)))
+
+
+class StubNet:
+	"""
+	Exact small-integer heuristic: value = -(number of cubies whose code differs from solved),
+	policy logits all zero.  Integer-valued float32 everywhere, so search control flow is identical
+	on any hardware.
+	"""
+	def __init__(self):
+		self.solved_oh = cube.as_oh(cube.get_solved())
+
+	def eval(self):
+		return self
+
+	def __call__(self, x, policy=True, value=True):
+		out = []
+		if policy:
+			out.append(torch.zeros(len(x), 12))
+		if value:
+			out.append(-(20 - (x * self.solved_oh).sum(dim=1, keepdim=True)))
+		return out if len(out) > 1 else out[0]
+
+
+def tables():
+	with open(os.path.join(REF, "frontend", "src", "assets", "maps.json")) as f:
+		front = json.load(f)
+	cube.set_is2024(False)
+	solved686 = cube.get_solved()
+	cube.set_is2024(True)
+	np.savez_compressed(
+		os.path.join(OUT, "cube_tables.npz"),
+		delta_maps=_Cube2024.maps,
+		frontend_map_neg=np.array(front["map_neg"], dtype=np.int8),
+		frontend_map_pos=np.array(front["map_pos"], dtype=np.int8),
+		solved2024=cube.get_solved(),
+		solved686=solved686,
+		action_space=np.array(cube.action_space),
+	)
+
+
+def kats(skip_1m: bool):
+	d, text = {}, {}
+	np.random.seed(0)
+	d["k1_state"], d["k1_faces"], d["k1_dirs"] = cube.scramble(5)
+	np.random.seed(42)
+	d["k2a_state"], d["k2a_faces"], d["k2a_dirs"] = cube.scramble(1)
+	d["k2b_state"], d["k2b_faces"], d["k2b_dirs"] = cube.scramble(20)
+	np.random.seed(7)
+	d["k7_state"], d["k7_faces"], d["k7_dirs"] = cube.scramble(6, True)
+
+	# K3 small: full arrays
+	np.random.seed(1)
+	p = random_walk(256, 20)
+	d["k3_256_parents"], d["k3_256_children"] = p, fan_out(p)
+	# per-row random actions, both directions (the reference's own test only draws dir 0)
+	np.random.seed(2)
+	f, dr = np.random.randint(0, 6, 256), np.random.randint(0, 2, 256)
+	d["mr_faces"], d["mr_dirs"], d["mr_out"] = f, dr, cube.multi_rotate(p, f, dr)
+	# goal test truth table: a batch with solved rows sprinkled in
+	mix = p.copy()
+	mix[[3, 77, 200]] = cube.get_solved()
+	d["solved_mix"], d["solved_mix_flags"] = mix, cube.multi_is_solved(mix)
+	# parents one move from solved: the fan-out must flag exactly the inverse move
+	near = cube.multi_rotate(cube.repeat_state(cube.get_solved(), 12), *cube.iter_actions())
+	d["near_parents"] = near
+	d["near_children_solved"] = cube.multi_is_solved(fan_out(near))
+
+	np.random.seed(1)
+	p = random_walk(10_000, 20)
+	c = fan_out(p)
+	text["k3_10k_parents_sha256"], text["k3_10k_children_sha256"] = sha(p), sha(c)
+	text["k3_10k_solved_children"] = int(cube.multi_is_solved(c).sum())
+	d["k3_10k_parent0"], d["k3_10k_child0"] = p[0], c[0]
+
+	if not skip_1m:
+		np.random.seed(1)
+		p = random_walk(1_000_000, 20)
+		h, nsolved = hashlib.sha256(), 0
+		for lo in range(0, len(p), 100_000):
+			c = fan_out(p[lo:lo + 100_000])
+			h.update(np.ascontiguousarray(c).tobytes())
+			nsolved += int(cube.multi_is_solved(c).sum())
+		text["k3_1m_parents_sha256"], text["k3_1m_children_sha256"] = sha(p), h.hexdigest()
+		text["k3_1m_solved_children"] = nsolved
+		d["k3_1m_parent0"] = p[0]
+	else:
+		old = json.load(open(os.path.join(OUT, "cube_text.json")))
+		for k in ("k3_1m_parents_sha256", "k3_1m_children_sha256", "k3_1m_solved_children"):
+			text[k] = old[k]
+		d["k3_1m_parent0"] = np.load(os.path.join(OUT, "cube_kat.npz"))["k3_1m_parent0"]
+
+	np.random.seed(0)
+	s, oh = cube.sequence_scrambler(4, 5, True)
+	d["k5_states"], d["k5_oh"] = s, oh.numpy()
+	np.random.seed(0)
+	s, oh = cube.sequence_scrambler(3, 4, False)
+	d["k5b_states"] = s
+	d["oh_single"] = cube.as_oh(d["k1_state"]).numpy()
+
+	# rendering known answers (the three literals of tests/test_cube.py plus random states)
+	st = cube.get_solved()
+	text["str_solved"] = cube.stringify(st)
+	text["str_F"] = cube.stringify(cube.rotate(st, 0, 1))
+	for m in ((0, 0), (1, 0), (2, 0), (3, 0), (4, 0), (5, 0), (0, 1), (1, 1), (2, 1), (3, 1), (4, 1), (5, 1)):
+		st = cube.rotate(st, *m)
+	text["str_all12"] = cube.stringify(st)
+	d["as633_states"] = d["k3_256_parents"][:16]
+	d["as633_out"] = np.array([cube.as633(s) for s in d["as633_states"]])
+	text["iter_actions_2"] = cube.iter_actions(2).tolist()
+	text["rev_actions"] = cube.rev_actions(np.arange(12)).tolist()
+
+	# 6x8x6 representation
+	cube.set_is2024(False)
+	np.random.seed(5)
+	s6 = random_walk(64, 12)
+	f, dr = np.random.randint(0, 6, 64), np.random.randint(0, 2, 64)
+	d["r686_states"], d["r686_faces"], d["r686_dirs"] = s6, f, dr
+	d["r686_out"] = cube.multi_rotate(s6, f, dr)
+	d["r686_all12"] = np.array([[cube.rotate(s, *cube.action_space[a]) for a in range(12)] for s in s6[:8]])
+	d["r686_correct"] = cube.as_correct(torch.from_numpy(s6)).numpy()
+	d["r686_as633"] = np.array([cube.as633(s) for s in s6[:8]])
+	st = cube.rotate(cube.rotate(cube.get_solved(), 0, True), 5, False)
+	d["r686_correct_FRp"] = cube.as_correct(torch.from_numpy(st).unsqueeze(0)).numpy()
+	text["str686_F"] = cube.stringify(cube.rotate(cube.get_solved(), 0, 1))
+	cube.set_is2024(True)
+
+	np.savez_compressed(os.path.join(OUT, "cube_kat.npz"), **d)
+	with open(os.path.join(OUT, "cube_text.json"), "w") as f:
+		json.dump(text, f, indent=1, sort_keys=True)
+
+
+def astar_traces():
+	"""Unmodified reference AStar + exact stub; also records the pop order of every iteration."""
+	out = {}
+	cases = {
+		"a": dict(seed=7, depth=6, lambda_=0.5, expansions=10, max_states=200_000),
+		"b": dict(seed=11, depth=8, lambda_=0.2, expansions=64, max_states=3_000),   # runs out of budget
+		"c": dict(seed=3, depth=5, lambda_=1.0, expansions=1, max_states=50_000),
+		"d": dict(seed=19, depth=7, lambda_=0.1, expansions=300, max_states=60_000),
+	}
+	for tag, c in cases.items():
+		np.random.seed(c["seed"])
+		state, faces, dirs = cube.scramble(c["depth"], True)
+		agent = agents.AStar(StubNet(), lambda_=c["lambda_"], expansions=c["expansions"])
+		pops = []
+		inner = agent.expand_batch
+		agent.expand_batch = lambda idcs, inner=inner, pops=pops: (pops.append(np.array(idcs)), inner(idcs))[1]
+		solved = agent.search(state, time_limit=None, max_states=c["max_states"])
+		n = len(agent)
+		out[f"{tag}_params"] = np.array([c["seed"], c["depth"], c["expansions"], c["max_states"]])
+		out[f"{tag}_lambda"] = np.array(c["lambda_"])
+		out[f"{tag}_start"] = state
+		out[f"{tag}_solved"] = np.array(solved)
+		out[f"{tag}_n"] = np.array(n)
+		out[f"{tag}_states"] = agent.states[1:n + 1].copy()
+		out[f"{tag}_G"] = agent.G[1:n + 1].copy()
+		out[f"{tag}_parents"] = agent.parents[2:n + 1].astype(np.int64)
+		out[f"{tag}_parent_actions"] = agent.parent_actions[2:n + 1].astype(np.int64)
+		out[f"{tag}_action_queue"] = np.array(list(agent.action_queue), dtype=np.int64)
+		out[f"{tag}_pop_lens"] = np.array([len(p) for p in pops])
+		out[f"{tag}_pops"] = np.concatenate(pops) if pops else np.zeros(0, dtype=np.int64)
+		print(f"astar {tag}: solved={solved} n={n} iters={len(pops)} queue_len={len(agent.action_queue)}")
+	np.savez_compressed(os.path.join(OUT, "astar_trace.npz"), **out)
+
+
+def mcts_traces():
+	out = {}
+	cases = {
+		"a": dict(seed=7, depth=6, c=0.6, search_graph=False, max_states=4_000),
+		"b": dict(seed=2, depth=5, c=5.0, search_graph=True, max_states=10_000),    # solves at 2 474 states
+		"c": dict(seed=2, depth=4, c=5.0, search_graph=False, max_states=10_000),   # solves at 3 307 states
+		"d": dict(seed=23, depth=12, c=2.5, search_graph=False, max_states=2_500),
+		"e": dict(seed=2, depth=2, c=1.0, search_graph=True, max_states=10_000),    # solves at 1 568 states
+	}
+	for tag, c in cases.items():
+		np.random.seed(c["seed"])
+		state, faces, dirs = cube.scramble(c["depth"], True)
+		agent = agents.MCTS(StubNet(), c=c["c"], search_graph=c["search_graph"])
+		sims = [0]
+		inner = agent.expand_leaf
+		def counted(v, a, inner=inner, sims=sims):
+			sims[0] += 1
+			return inner(v, a)
+		agent.expand_leaf = counted
+		solved = agent.search(state, time_limit=None, max_states=c["max_states"])
+		n = len(agent)
+		out[f"{tag}_params"] = np.array([c["seed"], c["depth"], int(c["search_graph"]), c["max_states"]])
+		out[f"{tag}_c"] = np.array(c["c"])
+		out[f"{tag}_start"] = state
+		out[f"{tag}_solved"] = np.array(solved)
+		out[f"{tag}_n"] = np.array(n)
+		out[f"{tag}_sims"] = np.array(sims[0])
+		out[f"{tag}_states"] = agent.states[1:n + 1].copy()
+		out[f"{tag}_neighbors"] = agent.neighbors[1:n + 1].astype(np.int32)
+		out[f"{tag}_leaves"] = agent.leaves[1:n + 1].copy()
+		out[f"{tag}_N"] = agent.N[1:n + 1].astype(np.int32)
+		out[f"{tag}_W"] = agent.W[1:n + 1].astype(np.float32)   # exact: stub values are small integers
+		out[f"{tag}_L"] = agent.L[1:n + 1].astype(np.float32)
+		out[f"{tag}_V"] = agent.V[1:n + 1].astype(np.float32)
+		out[f"{tag}_action_queue"] = np.array(list(agent.action_queue), dtype=np.int64)
+		assert (agent.W[1:n + 1] == out[f"{tag}_W"]).all() and (agent.L[1:n + 1] == out[f"{tag}_L"]).all()
+		print(f"mcts {tag}: solved={solved} n={n} sims={sims[0]} queue_len={len(agent.action_queue)}")
+	np.savez_compressed(os.path.join(OUT, "mcts_trace.npz"), **out)
+
+
+if __name__ == "__main__":
+	ap = argparse.ArgumentParser()
+	ap.add_argument("--skip-1m", action="store_true", help="reuse the committed 1 M-state hashes (saves ~1 min)")
+	ap.add_argument("--only", default="")
+	args = ap.parse_args()
+	os.makedirs(OUT, exist_ok=True)
+	todo = args.only.split(",") if args.only else ["tables", "kats", "astar", "mcts"]
+	if "tables" in todo: tables()
+	if "kats" in todo: kats(args.skip_1m)
+	if "astar" in todo: astar_traces()
+	if "mcts" in todo: mcts_traces()
+	print("golden vectors written to", OUT)

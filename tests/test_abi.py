@@ -1,0 +1,132 @@
+"""
+CPU-side checks of the drop-in boundary: the C-ABI library builds, loads without a GPU, exports exactly the
+symbols include/rubiks_hip.h declares, its tables equal the reference's, and compute entries refuse to run
+(instead of falling back) when there is no device.
+"""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from librubiks_amd import _ffi, cube
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+	names = []
+	for fn in sorted(os.listdir(os.path.join(ROOT, "include"))):
+		text = open(os.path.join(ROOT, "include", fn)).read()
+		text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+		names += re.findall(r"\b(rk_[a-z0-9_]+)\s*\(", text)
+	return names
+
+
+def test_header_binding_and_library_agree():
+	declared = _header_symbols()
+	assert len(declared) == len(set(declared))
+	assert set(declared) == set(_ffi.SIGNATURES), set(declared) ^ set(_ffi.SIGNATURES)
+	out = subprocess.run(["nm", "-D", "--defined-only", _ffi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+	exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+	assert set(declared) <= exported, set(declared) - exported
+	assert {s for s in exported if s.startswith("rk_")} == set(declared)
+	lib = _ffi.lib()
+	for name in declared:
+		assert getattr(lib, name) is not None
+	assert lib.rk_version() >= 100
+
+
+def test_library_carries_gfx950_code_only():
+	blob = open(_ffi.LIB_PATH, "rb").read()
+	targets = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", blob))
+	assert targets == {b"gfx950"}, targets
+
+
+def test_tables_from_library(golden):
+	lib = _ffi.lib()
+	lut = np.empty((12, 2, 24), np.uint8)
+	_ffi.check(lib.rk_tables(_ffi.REPR_2024, lut.ctypes.data))
+	delta = golden["cube_tables"]["delta_maps"]
+	for a in range(12):
+		face, d = a // 2, 1 - a % 2
+		assert (lut[a].astype(np.int16) - np.arange(24) == delta[d, face]).all()
+	perm = np.empty((12, 48), np.uint8)
+	_ffi.check(lib.rk_tables(_ffi.REPR_686, perm.ctypes.data))
+	k = golden["cube_kat"]
+	for i in range(8):
+		flat = k["r686_states"][i].reshape(48, 6)
+		for a in range(12):
+			assert (flat[perm[a]].reshape(6, 8, 6) == k["r686_all12"][i, a]).all()
+	assert (cube.get_solved() == golden["cube_tables"]["solved2024"]).all()
+	cube.set_is2024(False)
+	assert (cube.get_solved() == golden["cube_tables"]["solved686"]).all()
+	assert cube.shape() == (6, 8, 6) and cube.get_oh_shape() == 288
+
+
+def test_error_reporting_without_fallback():
+	lib = _ffi.lib()
+	assert lib.rk_tables(7, None) == -1 and b"representation" in lib.rk_last_error()
+	assert lib.rk_expand12(0, None, None, None, None, 5, None) == -1
+	assert lib.rk_expand12(0, 4, 8, None, None, 5, None) == -1 and b"16-byte" in lib.rk_last_error()
+	assert lib.rk_as_oh(0, 4, 16, 9, 1, None) == -1
+	if not torch.cuda.is_available():
+		assert lib.rk_init(0) == -2          # no device: an error, never a CPU path
+		with pytest.raises(_ffi.RubiksHipError):
+			cube.multi_rotate(np.zeros((3, 20), np.int8), [0, 1, 2], [0, 1, 0])
+		with pytest.raises(_ffi.RubiksHipError):
+			cube.scramble(5)
+		with pytest.raises(_ffi.RubiksHipError):
+			cube.as_oh(cube.get_solved())
+
+
+def test_product_never_imports_oracle():
+	"""The shipped package must not reference the test oracle (grep over its sources)."""
+	pkg = os.path.join(ROOT, "librubiks_amd")
+	for dirpath, _, files in os.walk(pkg):
+		for fn in files:
+			if fn.endswith((".py", ".hip", ".h", ".cpp")):
+				text = open(os.path.join(dirpath, fn)).read()
+				assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), os.path.join(dirpath, fn)
+				assert "/root/reference" not in text, os.path.join(dirpath, fn)
+
+
+def test_host_side_helpers(golden):
+	text = golden["text"]
+	assert cube.iter_actions(2).tolist() == text["iter_actions_2"] and cube.iter_actions(2).dtype == np.uint8
+	assert cube.rev_actions(np.arange(12)).tolist() == text["rev_actions"]
+	assert [cube.rev_action(a) for a in range(12)] == text["rev_actions"]
+	f, d = cube.indices_to_actions(np.arange(12))
+	assert f.tolist() == [0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5] and d.tolist() == [1, 0] * 6
+	assert cube.action_space == [tuple(int(v) for v in x) for x in golden["cube_tables"]["action_space"]]
+	assert cube.action_dim == 12 and cube.dtype == np.int8
+	assert cube.repeat_state(cube.get_solved()).shape == (12, 20)
+	assert cube.get_solved_instance() is cube.get_solved_instance()
+	# rendering known answers of the reference's tests/test_cube.py:33-43
+	assert cube.stringify(cube.get_solved()) == text["str_solved"]
+	k = golden["cube_kat"]
+	for st, pic in zip(k["as633_states"], k["as633_out"]):
+		assert (cube.as633(st) == pic).all()
+	cube.set_is2024(False)
+	for i in range(8):
+		assert (cube.as633(k["r686_states"][i]) == k["r686_as633"][i]).all()
+
+
+def test_repr_switch():
+	"""tests/test_rubiks.py of the reference: store / restore / decorator."""
+	assert cube.get_is2024()
+	cube.store_repr()
+	cube.set_is2024(False)
+	assert not cube.get_is2024() and cube.get_solved_instance().shape == (6, 8, 6)
+	cube.restore_repr()
+	assert cube.get_is2024()
+
+	class User:
+		is2024 = False
+
+		@cube.with_used_repr
+		def which(self):
+			return cube.get_is2024()
+	assert User().which() is False and cube.get_is2024()

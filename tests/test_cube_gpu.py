@@ -1,0 +1,293 @@
+"""
+GPU parity tests of the cube hot path: the HIP kernels (through the C ABI / the drop-in `cube` module) against
+the committed golden vectors of the reference and against the CPU oracle on identical seeded inputs.
+Bit-exact everywhere: all of this is integer / byte work (the one-hot is exact 0/1).
+"""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from librubiks_amd import _ffi, cube
+from oracle import c_oracle, cube_oracle as orc
+from tests.helpers import random_walk, random_walk_c, sha
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _native_library_loaded():
+	"""These tests are void if anything but the in-tree HIP library does the work."""
+	lib = _ffi.lib()
+	assert lib.rk_init(0) == 0, lib.rk_last_error()
+	maps = open("/proc/self/maps").read()
+	assert "librubiks_hip.so" in maps
+
+
+def dev(a, dtype=None):
+	t = torch.from_numpy(np.ascontiguousarray(a))
+	if dtype is not None:
+		t = t.to(dtype)
+	return t.cuda()
+
+
+# ------------------------------------------------------------------------------------------------- golden vectors
+def test_golden_fanout_rotate_solved(golden):
+	k = golden["cube_kat"]
+	ch, fl = cube.expand(k["k3_256_parents"], return_solved=True)
+	assert ch.dtype == np.int8 and ch.shape == (3072, 20)
+	assert (ch == k["k3_256_children"]).all() and not fl.any()
+	# exactly the reference idiom through the drop-in surface (agents.py:277-281)
+	idiom = cube.multi_rotate(np.repeat(k["k3_256_parents"], 12, axis=0), *cube.iter_actions(256))
+	assert (idiom == k["k3_256_children"]).all()
+	out = cube.multi_rotate(k["k3_256_parents"], k["mr_faces"], k["mr_dirs"])
+	assert out.dtype == np.int8 and (out == k["mr_out"]).all()
+	assert (cube.multi_is_solved(k["solved_mix"]) == k["solved_mix_flags"]).all()
+	_, fl = cube.expand(k["near_parents"], return_solved=True)
+	assert (fl == k["near_children_solved"]).all()
+	for i in range(0, 256, 31):
+		assert (cube.rotate(k["k3_256_parents"][i], k["mr_faces"][i], k["mr_dirs"][i]) == k["mr_out"][i]).all()
+	assert cube.is_solved(cube.get_solved()) and not cube.is_solved(k["k1_state"])
+
+
+def test_golden_scramblers_and_onehot(golden):
+	k = golden["cube_kat"]
+	np.random.seed(0)
+	s, f, d = cube.scramble(5)
+	assert (s == k["k1_state"]).all() and (f == k["k1_faces"]).all() and (d == k["k1_dirs"]).all() and s.dtype == np.int8
+	np.random.seed(42)
+	s, f, d = cube.scramble(1)
+	assert (s == k["k2a_state"]).all()
+	s, f, d = cube.scramble(20)
+	assert (s == k["k2b_state"]).all() and not cube.is_solved(s)
+	for face, dr in zip(reversed(f), reversed([int(not x) for x in d])):     # tests/test_cube.py:112-114
+		s = cube.rotate(s, face, dr)
+	assert cube.is_solved(s)
+	np.random.seed(7)
+	s, f, d = cube.scramble(6, True)
+	assert (s == k["k7_state"]).all()
+	s, f, d = cube.scramble(0)
+	assert cube.is_solved(s) and len(f) == 0
+
+	np.random.seed(0)
+	states, oh = cube.sequence_scrambler(4, 5, True)
+	assert (states == k["k5_states"]).all() and oh.is_cuda and oh.dtype == torch.float32
+	assert (oh.cpu().numpy() == k["k5_oh"]).all()
+	np.random.seed(0)
+	states, _ = cube.sequence_scrambler(3, 4, False)
+	assert (states == k["k5b_states"]).all()
+	one = cube.as_oh(k["k1_state"])
+	assert one.shape == (1, 480) and (one.cpu().numpy() == k["oh_single"]).all()
+	for dt in (torch.float16, torch.bfloat16):
+		got = cube.device.as_oh(dev(k["k5_states"]), dtype=dt)
+		assert (got.float().cpu().numpy() == k["k5_oh"]).all()
+
+
+def test_reference_known_answer_test(golden):
+	"""The body of the reference's tests/test_cube.py::_rotation_tests run against the drop-in, both representations."""
+	text = golden["text"]
+	for is2024 in (True, False):
+		cube.set_is2024(is2024)
+		state = cube.get_solved()
+		assert cube.stringify(state) == text["str_solved"]
+		for m, a in zip(((0, 1), (0, 0), (0, 1), (1, 1), (2, 0), (3, 0)), (False, True, False, False, False, False)):
+			state = cube.rotate(state, *m)
+			assert a == cube.is_solved(state)
+		for m, a in zip(((3, 1), (2, 1), (1, 0), (0, 0)), (False, False, False, True)):
+			state = cube.rotate(state, *m)
+			assert a == cube.is_solved(state)
+		assert cube.stringify(cube.rotate(cube.get_solved(), 0, 1)) == text["str_F"]
+		state = cube.get_solved()
+		for m in ((0, 0), (1, 0), (2, 0), (3, 0), (4, 0), (5, 0), (0, 1), (1, 1), (2, 1), (3, 1), (4, 1), (5, 1)):
+			state = cube.rotate(state, *m)
+			assert not cube.is_solved(state)
+		assert cube.stringify(state) == text["str_all12"]
+		# _multi_rotate_test (tests/test_cube.py:94-101), both directions
+		np.random.seed(3)
+		states = np.array([cube.get_solved()] * 5)
+		for _ in range(10):
+			faces, dirs = np.random.randint(0, 6, 5), np.random.randint(0, 2, 5)
+			classic = np.array([cube.rotate(s, f, d) for s, f, d in zip(states, faces, dirs)])
+			states = cube.multi_rotate(states, faces, dirs)
+			assert (classic == states).all()
+
+
+def test_repr686_golden(golden):
+	k = golden["cube_kat"]
+	cube.set_is2024(False)
+	s6 = k["r686_states"]
+	assert (cube.multi_rotate(s6, k["r686_faces"], k["r686_dirs"]) == k["r686_out"]).all()
+	ch, fl = cube.expand(s6[:8], return_solved=True)
+	assert (ch.reshape(8, 12, 6, 8, 6) == k["r686_all12"]).all() and not fl.any()
+	assert (cube.as_correct(torch.from_numpy(s6)).cpu().numpy() == k["r686_correct"]).all()
+	st = cube.rotate(cube.rotate(cube.get_solved(), 0, True), 5, False)
+	assert (cube.as_correct(torch.from_numpy(st).unsqueeze(0)).cpu().numpy() == k["r686_correct_FRp"]).all()
+	oh = cube.as_oh(s6)
+	assert oh.shape == (64, 288) and (oh.cpu().numpy().reshape(s6.shape) == s6).all()
+	assert cube.as_oh(s6[0]).shape == (1, 288)
+	near = cube.multi_rotate(cube.repeat_state(cube.get_solved(), 12), *cube.iter_actions())
+	assert not cube.multi_is_solved(near).any()
+	_, fl = cube.expand(near, return_solved=True)
+	assert fl.sum() == 12 and all(fl[12 * a + (a ^ 1)] for a in range(12))
+	np.random.seed(11)
+	s, f, d = cube.scramble(9)
+	ref = orc.SOLVED686
+	for face, dr in zip(f, d):
+		ref = orc.rotate686(ref, face, dr)
+	assert (s == ref).all()
+
+
+# ------------------------------------------------------------------------------------------------- oracle parity
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 256, 257, 1000, 4099, 70_001])
+def test_ragged_sizes_against_oracle(n):
+	"""Tile boundaries of every kernel: 64-parent rounds, 256-state tiles, partial tails."""
+	p = random_walk(n, 12, seed=100 + n % 97)
+	# sprinkle solved states and near-solved parents so that flags / stats paths fire
+	if n > 3:
+		p[n // 3] = orc.SOLVED
+		p[-1] = orc.rotate(orc.SOLVED, 3, 1)
+	dp = dev(p)
+	stats = torch.tensor([0, _ffi.INT64_MAX], dtype=torch.int64, device="cuda")
+	ch, fl = cube.device.expand12(dp, stats=stats)
+	ref_ch, ref_fl = c_oracle.expand12(p, threads=4)
+	assert (ch.cpu().numpy() == ref_ch).all()
+	assert (fl.cpu().numpy() == ref_fl).all()
+	st = stats.cpu().numpy()
+	assert st[0] == ref_fl.sum()
+	assert st[1] == (np.flatnonzero(ref_fl)[0] if ref_fl.any() else _ffi.INT64_MAX)
+	ch2, none = cube.device.expand12(dp, want_flags=False)
+	assert none is None and (ch2.cpu().numpy() == ref_ch).all()
+
+	np.random.seed(n)
+	acts = np.random.randint(0, 12, n).astype(np.uint8)
+	out = cube.device.multi_rotate(dp, dev(acts))
+	assert (out.cpu().numpy() == c_oracle.multi_rotate(p, acts)).all()
+	assert (dp.cpu().numpy() == p).all()                                   # inputs are never mutated
+	stats = torch.tensor([0, _ffi.INT64_MAX], dtype=torch.int64, device="cuda")
+	flags = cube.device.multi_is_solved(dp, stats=stats)
+	ref_flags, cnt, first = c_oracle.multi_is_solved(p)
+	assert (flags.cpu().numpy().astype(bool) == ref_flags).all()
+	st = stats.cpu().numpy()
+	assert st[0] == cnt and st[1] == (first if cnt else _ffi.INT64_MAX)
+	assert (cube.device.as_oh(dp).cpu().numpy() == c_oracle.as_oh(p)).all()
+
+
+def test_misaligned_views_and_inplace():
+	"""Row slices of a state pool are only 4-byte aligned: the kernels must take the dword path, not fault."""
+	p = random_walk(3000, 9, seed=5)
+	pool = dev(np.concatenate([np.zeros((1, 20), np.int8), p]))
+	view = pool[1:]                                                        # base + 20 B
+	assert view.data_ptr() % 16 != 0
+	ref_ch, ref_fl = c_oracle.expand12(p)
+	ch, fl = cube.device.expand12(view)
+	assert (ch.cpu().numpy() == ref_ch).all() and (fl.cpu().numpy() == ref_fl).all()
+	acts = (np.arange(3000) % 12).astype(np.uint8)
+	ref = c_oracle.multi_rotate(p, acts)
+	out_pool = torch.zeros_like(pool)
+	cube.device.multi_rotate(view, dev(acts), out=out_pool[1:])
+	assert (out_pool[1:].cpu().numpy() == ref).all() and (out_pool[0] == 0).all()
+	# in place
+	cube.device.multi_rotate(view, dev(acts), out=view)
+	assert (view.cpu().numpy() == ref).all()
+	assert (cube.device.multi_is_solved(view).cpu().numpy() == 0).all()
+	assert (cube.device.as_oh(view).cpu().numpy() == orc.as_oh(ref)).all()
+	# flags into a view that is 4- but not 16-byte aligned
+	fl_pool = torch.zeros(12 * 3000 + 4, dtype=torch.uint8, device="cuda")
+	near = dev(np.concatenate([orc.rotate(orc.SOLVED, 2, 0)[None], ref[:2999]]))
+	_, fl = cube.device.expand12(near, solved=fl_pool[4:])
+	want = c_oracle.expand12(near.cpu().numpy())[1]
+	assert (fl.cpu().numpy() == want).all() and want.sum() >= 1 and (fl_pool[:4] == 0).all()
+
+
+def test_empty_and_errors():
+	assert cube.multi_rotate(np.zeros((0, 20), np.int8), [], []).shape == (0, 20)
+	assert cube.multi_is_solved(np.zeros((0, 20), np.int8)).shape == (0,)
+	with pytest.raises(IndexError):
+		cube.multi_rotate(np.zeros((2, 20), np.int8), [0, 6], [0, 1])
+	with pytest.raises(IndexError):
+		cube.multi_rotate(np.zeros((2, 20), np.int8), [0, 1], [0, 2])
+	lib = _ffi.lib()
+	assert lib.rk_expand12(0, None, None, None, None, 0, None) == 0          # n = 0 is a no-op
+	# the host-pointer C entries (what a ctypes-only caller would use)
+	p = random_walk(777, 8, seed=9)
+	ch = np.empty((12 * 777, 20), np.int8)
+	fl = np.empty(12 * 777, np.uint8)
+	st = np.zeros(2, np.int64)
+	_ffi.check(lib.rk_expand12_host(0, p.ctypes.data, ch.ctypes.data, fl.ctypes.data, st.ctypes.data, 777, None))
+	assert (ch == orc.expand12(p)).all() and not fl.any() and st.tolist() == [0, -1]
+	acts = (np.arange(777) % 12).astype(np.uint8)
+	out = np.empty_like(p)
+	_ffi.check(lib.rk_multi_rotate_host(0, p.ctypes.data, acts.ctypes.data, out.ctypes.data, 777, None))
+	assert (out == c_oracle.multi_rotate(p, acts)).all()
+	acts[5] = 12
+	assert lib.rk_multi_rotate_host(0, p.ctypes.data, acts.ctypes.data, out.ctypes.data, 777, None) == -1
+	p[100] = orc.SOLVED
+	_ffi.check(lib.rk_multi_is_solved_host(0, p.ctypes.data, fl.ctypes.data, st.ctypes.data, 777, None))
+	assert fl[:777].sum() == 1 and st.tolist() == [1, 100]
+	seq = np.random.randint(0, 12, (6, 9)).astype(np.uint8)
+	got = np.empty((9 * 6, 20), np.int8)
+	_ffi.check(lib.rk_apply_sequences_host(0, seq.ctypes.data, 6, 9, 0, 0, got.ctypes.data, None))
+	assert (got == orc.sequence_states(seq // 2, 1 - seq % 2, False)).all()
+
+
+def test_device_tensors_round_trip_through_dropin_surface():
+	p = random_walk(500, 7, seed=21)
+	dp = dev(p)
+	f, d = np.random.randint(0, 6, 500), np.random.randint(0, 2, 500)
+	out = cube.multi_rotate(dp, dev(f), dev(d))
+	assert out.is_cuda and (out.cpu().numpy() == orc.multi_rotate(p, f, d)).all()
+	assert cube.multi_is_solved(dp).dtype == torch.bool
+	ch = cube.expand(dp)
+	assert ch.is_cuda and (ch.cpu().numpy() == orc.expand12(p)).all()
+
+
+# ------------------------------------------------------------------------------------------------- full size
+def test_headline_1m_bit_exact(golden):
+	"""
+	BASELINE config 2: 1 M seeded scrambles x 12 moves, children bit-identical to the reference: SHA-256 of the
+	240 MB children array equals the hash the reference produced (tests/golden/cube_text.json), plus a direct
+	comparison with the C oracle and the size-independent properties.
+	"""
+	text = golden["text"]
+	n = 1_000_000
+	p = random_walk_c(n, 20, seed=1)
+	assert sha(p) == text["k3_1m_parents_sha256"]
+	dp = dev(p)
+	stats = torch.tensor([0, _ffi.INT64_MAX], dtype=torch.int64, device="cuda")
+	ch, fl = cube.device.expand12(dp, stats=stats)
+	ch_h = ch.cpu().numpy()
+	assert hashlib.sha256(ch_h.tobytes()).hexdigest() == text["k3_1m_children_sha256"]
+	assert int(fl.sum()) == text["k3_1m_solved_children"] == 0 and stats[0].item() == 0
+	ref, _ = c_oracle.expand12(p, threads=8)
+	assert (ch_h == ref).all()
+	del ref, ch_h
+
+	# property: child a, moved back by rev(a), is the parent again -- for all 12 M children
+	rev = torch.arange(12, dtype=torch.uint8, device="cuda").bitwise_xor(1).repeat(n)
+	back = cube.device.multi_rotate(ch, rev)
+	assert torch.equal(back.view(n, 12, 20), dp.view(n, 1, 20).expand(n, 12, 20))
+	# property: applying the 12 moves per row with multi_rotate gives the same children (two different kernels)
+	acts = torch.arange(12, dtype=torch.uint8, device="cuda").repeat(n)
+	via_rows = cube.device.multi_rotate(dp.repeat_interleave(12, dim=0), acts)
+	assert torch.equal(via_rows, ch)
+	# property: a depth-20 walk undone move by move ends solved everywhere
+	np.random.seed(77)
+	acts_seq = np.random.randint(0, 12, (20, n)).astype(np.uint8)
+	cur = dev(orc.repeat_state(orc.SOLVED, n))
+	for dmove in range(20):
+		cur = cube.device.multi_rotate(cur, dev(acts_seq[dmove]))
+	assert int(cube.device.multi_is_solved(cur).sum()) < n // 1000
+	walk = cube.device.apply_sequences(dev(acts_seq), with_solved=False, only_last=True)
+	assert torch.equal(walk, cur)
+	for dmove in reversed(range(20)):
+		cur = cube.device.multi_rotate(cur, dev(acts_seq[dmove] ^ 1))
+	stats = torch.tensor([0, _ffi.INT64_MAX], dtype=torch.int64, device="cuda")
+	flags = cube.device.multi_is_solved(cur, stats=stats)
+	assert int(flags.sum()) == n and stats.tolist() == [n, 0]
+	# one-hot rows: exactly 20 ones, in the right columns (checked as an index round trip)
+	oh = cube.device.as_oh(dp[:200_000])
+	assert torch.equal(oh.sum(dim=1), torch.full((200_000,), 20.0, device="cuda"))
+	cols = oh.view(200_000, 20, 24).argmax(dim=2).to(torch.int8)
+	assert torch.equal(cols, dp[:200_000])
