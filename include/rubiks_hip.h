@@ -107,6 +107,44 @@ int rk_as_oh(int repr, const int8_t *d_states, void *d_out, int out_dtype, size_
 /* as_correct (cube.py:371-380): 686 one-hot int8 (n,288) -> float32 (n,48) of +1/-1. */
 int rk_as_correct686(const int8_t *d_states, float *d_out, size_t n, void *stream);
 
+/* ---- batch weighted A* (agents.py:171-413): device-resident open set / closed set ---------------------------
+ * Replaces the expand-children loop of AStar.search / expand_batch / relax_seen_states.  The engine owns:
+ *   states (cap+1, 20) int8, G, parents, parent_actions            (agents.py:202-205; index 0 unused, root = 1)
+ *   an open-addressing hash table state -> index                    (the `indices` dict, agents.py:201)
+ *   the open queue as a device array sorted by (cost, index)        (the heapq of (cost, idx), agents.py:185)
+ * One reference iteration (agents.py:236-252 + 254-331) is two calls around the net forward that PyTorch owns:
+ *   rk_astar_expand : pop the <= n best nodes (heappop order), 12-child fan-out, membership + first-occurrence
+ *                     de-duplication in parent-major batch order (np.unique semantics, agents.py:286-295), append
+ *                     the unseen states with G / parent / action (agents.py:299-313), goal test of the new states
+ *                     (agents.py:321-323).  Synchronises; h_info = {popped, new, won, solved_index, n_states}.
+ *   rk_astar_new_states_oh : one-hot of exactly the `new` states, in index order, for the value net (agents.py:379)
+ *   rk_astar_commit : cost = lambda*G + (-value) in float64 (agents.py:383), push into the open queue
+ *                     (agents.py:316-317), then relax the already-seen children (agents.py:326-329, 333-367).
+ *                     Skip it when `won` (the reference returns before relaxing).
+ * Results are identical to the reference's arrays (same index numbering, G, parents, parent_actions) whenever the
+ * value net returns the same numbers. */
+typedef struct rk_astar rk_astar_t;
+int rk_astar_create(rk_astar_t **out, size_t capacity, int max_expansions);
+int rk_astar_destroy(rk_astar_t *h);
+int rk_astar_reset(rk_astar_t *h, const int8_t *h_start_state, double lambda, void *stream);
+int rk_astar_expand(rk_astar_t *h, int n_expand, long long *h_info /* [5] */, void *stream);
+int rk_astar_new_states_oh(rk_astar_t *h, void *d_out, int out_dtype, void *stream);
+int rk_astar_commit(rk_astar_t *h, const float *d_values, void *stream);
+/* Number of stored states (len(agent), agents.py:409-410) and of open-queue entries. */
+long long rk_astar_size(const rk_astar_t *h);
+long long rk_astar_open_size(const rk_astar_t *h);
+/* Copy rows [first, first+count) of the node arrays to HOST buffers (any may be NULL): states int8 (count,20),
+ * G float64, parents int64, parent_actions int64 -- the reference's dtypes (agents.py:390-393). */
+int rk_astar_export(rk_astar_t *h, size_t first, size_t count, int8_t *h_states, double *h_G, long long *h_parents,
+                    long long *h_parent_actions, void *stream);
+/* Action indices from the root to node `index`, by walking parents (agents.py:244-251).  Returns the path length
+ * (>= 0) or a negative error; writes at most `max_len` actions. */
+long long rk_astar_path(rk_astar_t *h, long long index, long long *h_actions, size_t max_len, void *stream);
+/* Index of a state in the closed set or 0 (the `indices` dict lookup); host state in, synchronises. */
+long long rk_astar_lookup(rk_astar_t *h, const int8_t *h_state, void *stream);
+/* The open queue in pop order: up to max_len (cost, index) pairs to HOST arrays; returns the count written. */
+long long rk_astar_export_open(rk_astar_t *h, double *h_costs, long long *h_indices, size_t max_len, void *stream);
+
 /* ---- host-pointer conveniences (allocate scratch, copy, launch, copy back, synchronise) ---- */
 int rk_multi_rotate_host(int repr, const int8_t *h_states, const uint8_t *h_actions, int8_t *h_out,
                          size_t n, void *stream);

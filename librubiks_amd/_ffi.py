@@ -41,6 +41,18 @@ SIGNATURES = {
 	"rk_apply_sequences": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _vp]),
 	"rk_as_oh": (_i, [_i, _vp, _vp, _i, _sz, _vp]),
 	"rk_as_correct686": (_i, [_vp, _vp, _sz, _vp]),
+	"rk_astar_create": (_i, [C.POINTER(_vp), _sz, _i]),
+	"rk_astar_destroy": (_i, [_vp]),
+	"rk_astar_reset": (_i, [_vp, _vp, C.c_double, _vp]),
+	"rk_astar_expand": (_i, [_vp, _i, _vp, _vp]),
+	"rk_astar_new_states_oh": (_i, [_vp, _vp, _i, _vp]),
+	"rk_astar_commit": (_i, [_vp, _vp, _vp]),
+	"rk_astar_size": (C.c_longlong, [_vp]),
+	"rk_astar_open_size": (C.c_longlong, [_vp]),
+	"rk_astar_export": (_i, [_vp, _sz, _sz, _vp, _vp, _vp, _vp, _vp]),
+	"rk_astar_path": (C.c_longlong, [_vp, C.c_longlong, _vp, _sz, _vp]),
+	"rk_astar_lookup": (C.c_longlong, [_vp, _vp, _vp]),
+	"rk_astar_export_open": (C.c_longlong, [_vp, _vp, _vp, _sz, _vp]),
 	"rk_multi_rotate_host": (_i, [_i, _vp, _vp, _vp, _sz, _vp]),
 	"rk_expand12_host": (_i, [_i, _vp, _vp, _vp, _vp, _sz, _vp]),
 	"rk_multi_is_solved_host": (_i, [_i, _vp, _vp, _vp, _sz, _vp]),

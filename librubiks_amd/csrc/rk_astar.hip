@@ -1,0 +1,593 @@
+// Device-resident batch weighted A* (reference: librubiks/solving/agents.py:171-413).
+//
+// What lives in HBM (capacity C states, N = max expansions per iteration, K = 12 N children per iteration):
+//   states  int8 (C+1, 20)   node pool, index 0 unused, root = 1              (agents.py:202, :390)
+//   G       int32 (C+1)      path cost (whole numbers; exported as float64)    (agents.py:203, :393)
+//   parents int32, pact uint8                                                  (agents.py:204-205)
+//   table   uint32 (T)       open-addressing hash table state -> index, T = pow2 >= 2C   (the `indices` dict)
+//   mark    uint32 (C+1)     per-node scratch: batch position of a seen state's first occurrence
+//   open    Rec[2][C+1]      the open queue as an array SORTED by (cost, index); ping-pong buffers
+//
+// The reference pops with heapq from a heap of (cost, idx) tuples and never re-pushes a node, so "the N smallest
+// (cost, idx) pairs in ascending order" is exactly what it expands.  A sorted array makes the pop free (take the
+// head); new nodes always carry larger indices than old ones, so pushing is: sort the <= K new records by
+// (cost, idx), then one rank-merge with the remaining queue (every element finds its output slot by a binary
+// search in the other run; all (cost, idx) keys are distinct, so there are no tie cases).
+//
+// Order-dependent semantics that are reproduced exactly:
+//   * children are generated parent-major / action-minor in pop order                      (agents.py:277-282)
+//   * np.unique(..., return_index=True) keeps the FIRST occurrence of a state in batch order; only first
+//     occurrences are appended (unseen) or relaxed (seen)                                  (agents.py:291-295)
+//   * new indices are handed out in batch order                                            (agents.py:300)
+//   * relaxation is two vectorised passes, each reading all of G before writing, the second seeing the first's
+//     writes; duplicate targets in the second pass resolve to the LAST one in batch order  (agents.py:353-367)
+#include <hip/hip_runtime.h>
+#include <climits>
+#include <cstring>
+#include <vector>
+
+#include "../../include/rubiks_hip.h"
+#include "rk_device.h"
+#include "rk_error.h"
+#include "rk_kernels.h"
+
+namespace rk {
+
+struct Rec { uint64_t key; uint64_t idx; };
+
+constexpr uint32_t TENT = 0x80000000u;          // hash slot holds a batch position, not yet an index
+constexpr uint32_t NO_MARK = 0xFFFFFFFFu;
+
+enum { CTR_NEW = 0, CTR_WON = 1, CTR_SOLVED_IDX = 2, CTR_COUNT = 4 };
+
+__device__ __forceinline__ bool rec_less(const Rec &a, const Rec &b)
+{
+	return a.key < b.key || (a.key == b.key && a.idx < b.idx);
+}
+
+// float64 -> uint64 whose unsigned order is the float order (no NaNs expected)
+__device__ __forceinline__ uint64_t sortable_key(double c)
+{
+	c = c + 0.0;                                  // -0.0 -> +0.0: Python compares them equal
+	const uint64_t u = (uint64_t)__double_as_longlong(c);
+	return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+__host__ __device__ inline double key_to_double(uint64_t k)
+{
+	const uint64_t u = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+	double d;
+	memcpy(&d, &u, sizeof d);
+	return d;
+}
+
+__device__ __forceinline__ uint32_t hash_state(const uint32_t s[5])
+{
+	uint64_t h = 0x9E3779B97F4A7C15ull;
+	#pragma unroll
+	for (int j = 0; j < 5; j++) {
+		h ^= s[j];
+		h *= 0xFF51AFD7ED558CCDull;
+		h ^= h >> 29;
+	}
+	return (uint32_t)(h ^ (h >> 32));
+}
+
+__device__ __forceinline__ void load5(const uint32_t *p, uint32_t s[5])
+{
+	#pragma unroll
+	for (int j = 0; j < 5; j++) s[j] = p[j];
+}
+
+__device__ __forceinline__ bool equal5(const uint32_t a[5], const uint32_t *p)
+{
+	return ((a[0] ^ p[0]) | (a[1] ^ p[1]) | (a[2] ^ p[2]) | (a[3] ^ p[3]) | (a[4] ^ p[4])) == 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_astar_root(uint32_t *states, int32_t *G, int32_t *parents, uint8_t *pact, uint32_t *table, uint32_t mask,
+                             Rec *open, const uint32_t *root)
+{
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	uint32_t s[5];
+	load5(root, s);
+	#pragma unroll
+	for (int j = 0; j < 5; j++) states[5 + j] = s[j];
+	G[1] = 0; parents[1] = 0; pact[1] = 0;
+	table[hash_state(s) & mask] = 1u;
+	open[0] = Rec{sortable_key(0.0), 1ull};       // heappush(open_queue, (0, 1))   agents.py:234
+}
+
+// pop: the head of the sorted queue; gather the parents' states                                 agents.py:238-239
+__global__ void k_astar_pop(const Rec *open, int n_pop, const uint32_t *states, int32_t *exp_idx, uint32_t *par_states)
+{
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= n_pop * 5) return;
+	const int i = t / 5, j = t - 5 * i;
+	const uint32_t idx = (uint32_t)open[i].idx;
+	if (j == 0) exp_idx[i] = (int32_t)idx;
+	par_states[t] = states[(size_t)idx * 5 + j];
+}
+
+// membership test + in-batch first-occurrence election through the hash table                    agents.py:286-295
+__global__ void k_astar_lookup(const uint32_t *children, int K, const uint32_t *states, uint32_t *table, uint32_t mask,
+                               uint32_t *mark, int32_t *seen, uint32_t *child_slot)
+{
+	const int c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= K) return;
+	uint32_t s[5];
+	load5(children + (size_t)c * 5, s);
+	uint32_t slot = hash_state(s) & mask;
+	for (;;) {
+		uint32_t e = __atomic_load_n(&table[slot], __ATOMIC_RELAXED);
+		if (e == 0u) {
+			e = atomicCAS(&table[slot], 0u, TENT | (uint32_t)c);
+			if (e == 0u) { seen[c] = 0; child_slot[c] = slot; return; }
+		}
+		if (e & TENT) {
+			if (equal5(s, children + (size_t)(e & ~TENT) * 5)) {
+				atomicMin(&table[slot], TENT | (uint32_t)c);          // all claimants hold the same state: smallest position wins
+				seen[c] = 0; child_slot[c] = slot;
+				return;
+			}
+		} else if (equal5(s, states + (size_t)e * 5)) {
+			seen[c] = (int32_t)e;
+			atomicMin(&mark[e], (uint32_t)c);
+			return;
+		}
+		slot = (slot + 1) & mask;
+	}
+}
+
+// first_unseen / first_seen flags and the exclusive scan of first_unseen (= rank among the new states).
+// One workgroup walks the batch in chunks of 1024; K is a few thousand in the reference's configurations.
+__global__ __launch_bounds__(1024)
+void k_astar_flags_scan(int K, const uint32_t *table, const uint32_t *mark, const int32_t *seen, const uint32_t *child_slot,
+                        uint8_t *flags, int32_t *rank, long long *counters)
+{
+	__shared__ int s_wave[16];
+	__shared__ int s_base;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	if (tid == 0) s_base = 0;
+	__syncthreads();
+	for (int c0 = 0; c0 < K; c0 += 1024) {
+		const int c = c0 + tid;
+		int fu = 0, fs = 0;
+		if (c < K) {
+			const int32_t sidx = seen[c];
+			if (sidx == 0) fu = table[child_slot[c]] == (TENT | (uint32_t)c);
+			else fs = mark[sidx] == (uint32_t)c;
+			flags[c] = (uint8_t)(fu | (fs << 1));
+		}
+		const unsigned long long b = __ballot(fu);
+		const int in_wave = __popcll(b & ((1ull << lane) - 1ull));
+		if (lane == 0) s_wave[wv] = __popcll(b);
+		__syncthreads();
+		int before = s_base;
+		for (int w = 0; w < wv; w++) before += s_wave[w];
+		if (c < K) rank[c] = before + in_wave;
+		__syncthreads();
+		if (tid == 0) {
+			int tot = 0;
+			for (int w = 0; w < 16; w++) tot += s_wave[w];
+			s_base += tot;
+		}
+		__syncthreads();
+	}
+	if (tid == 0) counters[CTR_NEW] = s_base;
+}
+
+// append the new states (agents.py:299-313), finalise their hash slots, goal test of the new states
+// (agents.py:321-323) and the read half of relaxation case 1 (agents.py:354)
+__global__ void k_astar_append(const uint32_t *children, const uint8_t *solved, int K, const uint8_t *flags, const int32_t *rank,
+                               const int32_t *seen, const uint32_t *child_slot, const int32_t *exp_idx, uint32_t n_before,
+                               uint32_t *states, int32_t *G, int32_t *parents, uint8_t *pact, uint32_t *table,
+                               uint8_t *newway, int32_t *val1, long long *counters)
+{
+	const int c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= K) return;
+	const uint8_t f = flags[c];
+	const int32_t p = exp_idx[c / 12];
+	if (f & 1) {
+		const uint32_t idx = n_before + 1u + (uint32_t)rank[c];
+		#pragma unroll
+		for (int j = 0; j < 5; j++) states[(size_t)idx * 5 + j] = children[(size_t)c * 5 + j];
+		G[idx] = G[p] + 1;
+		parents[idx] = p;
+		pact[idx] = (uint8_t)(c % 12);
+		table[child_slot[c]] = idx;
+		if (solved[c]) { counters[CTR_WON] = 1; counters[CTR_SOLVED_IDX] = idx; }
+	}
+	uint8_t nw = 0;
+	if (f & 2) {
+		const int32_t g = G[p] + 1;
+		nw = g < G[seen[c]];
+		val1[c] = g;
+	}
+	newway[c] = nw;
+}
+
+// cost = lambda * G + (-value), float64, no fused multiply-add                                      agents.py:380-383
+__global__ void k_astar_records(const float *values, int n_new, uint32_t n_before, const int32_t *G, double lambda, Rec *rec)
+{
+	const int j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= n_new) return;
+	const uint32_t idx = n_before + 1u + (uint32_t)j;
+	const double h = (double)(-values[j]);
+	const double lg = lambda * (double)G[idx];
+	rec[j] = Rec{sortable_key(lg + h), (uint64_t)idx};
+}
+
+// bitonic sort of chunks of 1024 records in LDS
+__global__ __launch_bounds__(512)
+void k_sort_chunks(Rec *rec, int n)
+{
+	__shared__ Rec s[1024];
+	const int base = blockIdx.x * 1024, tid = threadIdx.x;
+	for (int i = tid; i < 1024; i += 512) s[i] = (base + i < n) ? rec[base + i] : Rec{~0ull, ~0ull};
+	__syncthreads();
+	for (int k = 2; k <= 1024; k <<= 1)
+		for (int j = k >> 1; j > 0; j >>= 1) {
+			const int i = 2 * tid - (tid & (j - 1));              // lower index of this thread's pair
+			const int l = i + j;
+			const bool up = (i & k) == 0;
+			const Rec a = s[i], b = s[l];
+			if (rec_less(b, a) == up) { s[i] = b; s[l] = a; }
+			__syncthreads();
+		}
+	for (int i = tid; i < 1024; i += 512)
+		if (base + i < n) rec[base + i] = s[i];
+}
+
+__device__ __forceinline__ int lower_bound_rec(const Rec *a, int n, const Rec &x)
+{
+	int lo = 0, hi = n;
+	while (lo < hi) {
+		const int mid = (lo + hi) >> 1;
+		if (rec_less(a[mid], x)) lo = mid + 1; else hi = mid;
+	}
+	return lo;
+}
+
+// merge neighbouring sorted runs of length L (keys are distinct)
+__global__ void k_merge_pass(const Rec *src, Rec *dst, int n, int L)
+{
+	const int e = blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= n) return;
+	const int r = e / L, i = e - r * L;
+	const int base = (r & ~1) * L;
+	const int pstart = (r ^ 1) * L;
+	int plen = n - pstart;
+	plen = plen < 0 ? 0 : (plen > L ? L : plen);
+	const Rec x = src[e];
+	dst[base + i + lower_bound_rec(src + pstart, plen, x)] = x;
+}
+
+__global__ void k_merge_two(const Rec *a, int na, const Rec *b, int nb, Rec *out)
+{
+	const int e = blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= na + nb) return;
+	if (e < na) {
+		const Rec x = a[e];
+		out[e + lower_bound_rec(b, nb, x)] = x;
+	} else {
+		const Rec x = b[e - na];
+		out[(e - na) + lower_bound_rec(a, na, x)] = x;
+	}
+}
+
+// relaxation, case 1 write half (agents.py:357-359)
+__global__ void k_relax_1b(int K, const uint8_t *newway, const int32_t *val1, const int32_t *seen, const int32_t *exp_idx,
+                           int32_t *G, int32_t *parents, uint8_t *pact)
+{
+	const int c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= K || !newway[c]) return;
+	const int32_t s = seen[c];
+	G[s] = val1[c];
+	pact[s] = (uint8_t)(c % 12);
+	parents[s] = exp_idx[c / 12];
+}
+
+// case 2 read half (agents.py:362); also clears the marks this batch set
+__global__ void k_relax_2a(int K, const uint8_t *flags, const int32_t *seen, const int32_t *exp_idx, const int32_t *G,
+                           uint32_t *mark, uint8_t *shortcut, int32_t *val2)
+{
+	const int c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= K) return;
+	uint8_t sc = 0;
+	if (flags[c] & 2) {
+		const int32_t s = seen[c];
+		const int32_t g = G[s] + 1;
+		sc = g < G[exp_idx[c / 12]];
+		val2[c] = g;
+		mark[s] = NO_MARK;
+	}
+	shortcut[c] = sc;
+}
+
+// case 2 write half (agents.py:365-367): one thread per expanded parent walks its 12 children in order, so the
+// last shortcut child in batch order wins, as NumPy's fancy assignment with repeated indices does
+__global__ void k_relax_2b(int n_pop, const uint8_t *shortcut, const int32_t *val2, const int32_t *seen, const int32_t *exp_idx,
+                           int32_t *G, int32_t *parents, uint8_t *pact)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_pop) return;
+	const int32_t p = exp_idx[i];
+	for (int a = 0; a < 12; a++) {
+		const int c = 12 * i + a;
+		if (shortcut[c]) {
+			G[p] = val2[c];
+			pact[p] = (uint8_t)(a ^ 1);           // rev_action                                 cube.py:197-200
+			parents[p] = seen[c];
+		}
+	}
+}
+
+__global__ void k_astar_find(const uint32_t *query, const uint32_t *states, const uint32_t *table, uint32_t mask, long long *out)
+{
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	uint32_t s[5];
+	load5(query, s);
+	uint32_t slot = hash_state(s) & mask;
+	for (;;) {
+		const uint32_t e = table[slot];
+		if (e == 0u) { *out = 0; return; }
+		if (!(e & TENT) && equal5(s, states + (size_t)e * 5)) { *out = e; return; }
+		slot = (slot + 1) & mask;
+	}
+}
+
+}  // namespace rk
+
+using namespace rk;
+
+struct rk_astar {
+	size_t cap = 0;
+	int max_exp = 0;
+	uint32_t mask = 0;
+	double lambda = 0.0;
+	// node pool
+	uint32_t *states = nullptr; int32_t *G = nullptr, *parents = nullptr; uint8_t *pact = nullptr;
+	uint32_t *table = nullptr, *mark = nullptr;
+	Rec *open[2] = {nullptr, nullptr};
+	int cur = 0;
+	// per-iteration scratch, K = 12 * max_exp
+	int32_t *exp_idx = nullptr; uint32_t *par_states = nullptr, *children = nullptr; uint8_t *solved = nullptr;
+	int32_t *seen = nullptr; uint32_t *child_slot = nullptr; uint8_t *flags = nullptr; int32_t *rank = nullptr;
+	uint8_t *newway = nullptr, *shortcut = nullptr; int32_t *val1 = nullptr, *val2 = nullptr;
+	Rec *newrec[2] = {nullptr, nullptr};
+	long long *counters = nullptr;
+	uint32_t *root_dev = nullptr;
+	// host mirrors
+	size_t n_states = 0, open_len = 0;
+	size_t n_before = 0;          // n_states before the pending expand
+	int n_pop = 0, n_new = 0;
+	bool pending = false;         // expand done, commit not yet
+	std::vector<void *> allocs;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(rk_astar *h, T **p, size_t count)
+{
+	void *q = nullptr;
+	RK_HIP(hipMalloc(&q, count * sizeof(T) + 16));
+	h->allocs.push_back(q);
+	*p = static_cast<T *>(q);
+	return RK_OK;
+}
+
+inline unsigned blocks(size_t n, unsigned per = 256) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+extern "C" {
+
+int rk_astar_create(rk_astar_t **out, size_t capacity, int max_expansions)
+{
+	if (!out) return fail(RK_EINVAL, "rk_astar_create: null out pointer");
+	if (capacity < 2 || capacity > 0x3FFFFFF0ull) return fail(RK_EINVAL, "rk_astar_create: capacity %zu out of range", capacity);
+	if (max_expansions < 1 || max_expansions > (1 << 24)) return fail(RK_EINVAL, "rk_astar_create: max_expansions %d out of range", max_expansions);
+	rk_astar *h = new rk_astar();
+	h->cap = capacity;
+	h->max_exp = max_expansions;
+	uint64_t t = 1024;
+	while (t < 2 * (uint64_t)capacity + 2) t <<= 1;
+	h->mask = (uint32_t)(t - 1);
+	const size_t K = 12 * (size_t)max_expansions, C1 = capacity + 1;
+	int e = RK_OK;
+	#define A(ptr, cnt) if (!e) e = dev_alloc(h, &h->ptr, (cnt))
+	A(states, C1 * 5); A(G, C1); A(parents, C1); A(pact, C1); A(table, (size_t)t); A(mark, C1);
+	A(open[0], C1); A(open[1], C1);
+	A(exp_idx, (size_t)max_expansions); A(par_states, (size_t)max_expansions * 5); A(children, K * 5 + 64); A(solved, K + 64);
+	A(seen, K); A(child_slot, K); A(flags, K); A(rank, K); A(newway, K); A(shortcut, K); A(val1, K); A(val2, K);
+	A(newrec[0], K + 1024); A(newrec[1], K + 1024);
+	A(counters, CTR_COUNT); A(root_dev, 8);
+	#undef A
+	if (e) { rk_astar_destroy(h); return e; }
+	*out = h;
+	return RK_OK;
+}
+
+int rk_astar_destroy(rk_astar_t *h)
+{
+	if (!h) return RK_OK;
+	for (void *p : h->allocs) (void)hipFree(p);
+	delete h;
+	return RK_OK;
+}
+
+int rk_astar_reset(rk_astar_t *h, const int8_t *h_start_state, double lambda, void *stream)
+{
+	if (!h || !h_start_state) return fail(RK_EINVAL, "rk_astar_reset: null argument");
+	hipStream_t st = (hipStream_t)stream;
+	h->lambda = lambda;
+	RK_HIP(hipMemsetAsync(h->table, 0, ((size_t)h->mask + 1) * sizeof(uint32_t), st));
+	RK_HIP(hipMemsetAsync(h->mark, 0xFF, (h->cap + 1) * sizeof(uint32_t), st));
+	RK_HIP(hipMemsetAsync(h->counters, 0, CTR_COUNT * sizeof(long long), st));
+	RK_HIP(hipMemcpyAsync(h->root_dev, h_start_state, STATE_BYTES, hipMemcpyHostToDevice, st));
+	hipLaunchKernelGGL(k_astar_root, dim3(1), dim3(64), 0, st, h->states, h->G, h->parents, h->pact, h->table, h->mask, h->open[0], h->root_dev);
+	RK_HIP(hipGetLastError());
+	RK_HIP(hipStreamSynchronize(st));       // the host buffer may go away after return
+	h->cur = 0;
+	h->n_states = 1;
+	h->open_len = 1;
+	h->pending = false;
+	h->n_pop = h->n_new = 0;
+	return RK_OK;
+}
+
+int rk_astar_expand(rk_astar_t *h, int n_expand, long long *h_info, void *stream)
+{
+	if (!h || !h_info) return fail(RK_EINVAL, "rk_astar_expand: null argument");
+	if (h->n_states == 0) return fail(RK_ESTATE, "rk_astar_expand: reset the engine first");
+	if (h->pending) return fail(RK_ESTATE, "rk_astar_expand: previous expansion not committed");
+	if (n_expand < 1 || n_expand > h->max_exp) return fail(RK_EINVAL, "rk_astar_expand: n_expand %d outside 1..%d", n_expand, h->max_exp);
+	hipStream_t st = (hipStream_t)stream;
+	const int n_pop = (int)(h->open_len < (size_t)n_expand ? h->open_len : (size_t)n_expand);     // agents.py:238
+	const int K = 12 * n_pop;
+	if (h->n_states + (size_t)K > h->cap) return fail(RK_ECAPACITY, "rk_astar_expand: %zu states + %d children exceed capacity %zu", h->n_states, K, h->cap);
+	h->n_before = h->n_states;
+	h->n_pop = n_pop;
+	h->n_new = 0;
+	long long ctr[CTR_COUNT] = {0, 0, 0, 0};
+	if (n_pop > 0) {
+		RK_HIP(hipMemsetAsync(h->counters, 0, CTR_COUNT * sizeof(long long), st));
+		hipLaunchKernelGGL(k_astar_pop, dim3(blocks((size_t)n_pop * 5)), dim3(256), 0, st, h->open[h->cur], n_pop, h->states, h->exp_idx, h->par_states);
+		launch_expand12((const int8_t *)h->par_states, (int8_t *)h->children, h->solved, nullptr, (size_t)n_pop, st);
+		hipLaunchKernelGGL(k_astar_lookup, dim3(blocks(K)), dim3(256), 0, st, h->children, K, h->states, h->table, h->mask, h->mark, h->seen, h->child_slot);
+		hipLaunchKernelGGL(k_astar_flags_scan, dim3(1), dim3(1024), 0, st, K, h->table, h->mark, h->seen, h->child_slot, h->flags, h->rank, h->counters);
+		hipLaunchKernelGGL(k_astar_append, dim3(blocks(K)), dim3(256), 0, st, h->children, h->solved, K, h->flags, h->rank, h->seen, h->child_slot,
+		                   h->exp_idx, (uint32_t)h->n_before, h->states, h->G, h->parents, h->pact, h->table, h->newway, h->val1, h->counters);
+		RK_HIP(hipGetLastError());
+		RK_HIP(hipMemcpyAsync(ctr, h->counters, sizeof ctr, hipMemcpyDeviceToHost, st));
+		RK_HIP(hipStreamSynchronize(st));
+	}
+	h->n_new = (int)ctr[CTR_NEW];
+	h->n_states = h->n_before + (size_t)h->n_new;
+	h->pending = true;
+	h_info[0] = n_pop; h_info[1] = h->n_new; h_info[2] = ctr[CTR_WON]; h_info[3] = ctr[CTR_SOLVED_IDX]; h_info[4] = (long long)h->n_states;
+	return RK_OK;
+}
+
+int rk_astar_new_states_oh(rk_astar_t *h, void *d_out, int out_dtype, void *stream)
+{
+	if (!h || !h->pending) return fail(RK_ESTATE, "rk_astar_new_states_oh: no pending expansion");
+	if (h->n_new == 0) return RK_OK;
+	return rk_as_oh(RK_REPR_2024, (const int8_t *)(h->states + (h->n_before + 1) * 5), d_out, out_dtype, (size_t)h->n_new, stream);
+}
+
+int rk_astar_commit(rk_astar_t *h, const float *d_values, void *stream)
+{
+	if (!h || !h->pending) return fail(RK_ESTATE, "rk_astar_commit: no pending expansion");
+	if (h->n_new > 0 && !d_values) return fail(RK_EINVAL, "rk_astar_commit: null values");
+	hipStream_t st = (hipStream_t)stream;
+	const int n_new = h->n_new, n_pop = h->n_pop, K = 12 * n_pop;
+	Rec *sorted_new = h->newrec[0];
+	if (n_new > 0) {
+		hipLaunchKernelGGL(k_astar_records, dim3(blocks(n_new)), dim3(256), 0, st, d_values, n_new, (uint32_t)h->n_before, h->G, h->lambda, h->newrec[0]);
+		hipLaunchKernelGGL(k_sort_chunks, dim3(blocks(n_new, 1024)), dim3(512), 0, st, h->newrec[0], n_new);
+		int src = 0;
+		for (int L = 1024; L < n_new; L <<= 1) {
+			hipLaunchKernelGGL(k_merge_pass, dim3(blocks(n_new)), dim3(256), 0, st, h->newrec[src], h->newrec[src ^ 1], n_new, L);
+			src ^= 1;
+		}
+		sorted_new = h->newrec[src];
+	}
+	// push: merge what is left of the queue with the new records                                agents.py:316-317
+	const int n_left = (int)(h->open_len - (size_t)n_pop);
+	if (n_left + n_new > 0)
+		hipLaunchKernelGGL(k_merge_two, dim3(blocks((size_t)n_left + n_new)), dim3(256), 0, st, h->open[h->cur] + n_pop, n_left, sorted_new, n_new, h->open[h->cur ^ 1]);
+	h->cur ^= 1;
+	h->open_len = (size_t)n_left + (size_t)n_new;
+	if (K > 0) {
+		hipLaunchKernelGGL(k_relax_1b, dim3(blocks(K)), dim3(256), 0, st, K, h->newway, h->val1, h->seen, h->exp_idx, h->G, h->parents, h->pact);
+		hipLaunchKernelGGL(k_relax_2a, dim3(blocks(K)), dim3(256), 0, st, K, h->flags, h->seen, h->exp_idx, h->G, h->mark, h->shortcut, h->val2);
+		hipLaunchKernelGGL(k_relax_2b, dim3(blocks(n_pop)), dim3(256), 0, st, n_pop, h->shortcut, h->val2, h->seen, h->exp_idx, h->G, h->parents, h->pact);
+	}
+	RK_HIP(hipGetLastError());
+	h->pending = false;
+	return RK_OK;
+}
+
+long long rk_astar_size(const rk_astar_t *h) { return h ? (long long)h->n_states : 0; }
+
+long long rk_astar_open_size(const rk_astar_t *h) { return h ? (long long)h->open_len : 0; }
+
+int rk_astar_export(rk_astar_t *h, size_t first, size_t count, int8_t *h_states, double *h_G, long long *h_parents,
+                    long long *h_parent_actions, void *stream)
+{
+	if (!h) return fail(RK_EINVAL, "rk_astar_export: null handle");
+	if (first + count > h->cap + 1) return fail(RK_EINVAL, "rk_astar_export: rows %zu..%zu outside the pool", first, first + count);
+	if (count == 0) return RK_OK;
+	hipStream_t st = (hipStream_t)stream;
+	std::vector<int32_t> g, p;
+	std::vector<uint8_t> a;
+	if (h_states) RK_HIP(hipMemcpyAsync(h_states, h->states + first * 5, count * STATE_BYTES, hipMemcpyDeviceToHost, st));
+	if (h_G) { g.resize(count); RK_HIP(hipMemcpyAsync(g.data(), h->G + first, count * sizeof(int32_t), hipMemcpyDeviceToHost, st)); }
+	if (h_parents) { p.resize(count); RK_HIP(hipMemcpyAsync(p.data(), h->parents + first, count * sizeof(int32_t), hipMemcpyDeviceToHost, st)); }
+	if (h_parent_actions) { a.resize(count); RK_HIP(hipMemcpyAsync(a.data(), h->pact + first, count, hipMemcpyDeviceToHost, st)); }
+	RK_HIP(hipStreamSynchronize(st));
+	for (size_t i = 0; i < count; i++) {
+		if (h_G) h_G[i] = (double)g[i];
+		if (h_parents) h_parents[i] = p[i];
+		if (h_parent_actions) h_parent_actions[i] = a[i];
+	}
+	return RK_OK;
+}
+
+long long rk_astar_path(rk_astar_t *h, long long index, long long *h_actions, size_t max_len, void *stream)
+{
+	if (!h) return fail(RK_EINVAL, "rk_astar_path: null handle");
+	if (index < 1 || (size_t)index > h->n_states) return fail(RK_EINVAL, "rk_astar_path: index %lld outside 1..%zu", index, h->n_states);
+	hipStream_t st = (hipStream_t)stream;
+	const size_t n = h->n_states + 1;
+	std::vector<int32_t> p(n);
+	std::vector<uint8_t> a(n);
+	RK_HIP(hipMemcpyAsync(p.data(), h->parents, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+	RK_HIP(hipMemcpyAsync(a.data(), h->pact, n, hipMemcpyDeviceToHost, st));
+	RK_HIP(hipStreamSynchronize(st));
+	std::vector<long long> rev;
+	long long i = index;
+	while (i != 1) {                                    // agents.py:246-250
+		if (rev.size() > n) return fail(RK_ESTATE, "rk_astar_path: parent chain does not reach the root");
+		rev.push_back(a[(size_t)i]);
+		i = p[(size_t)i];
+		if (i < 1 || (size_t)i >= n) return fail(RK_ESTATE, "rk_astar_path: broken parent chain");
+	}
+	const size_t len = rev.size();
+	for (size_t k = 0; k < len && k < max_len; k++) h_actions[k] = rev[len - 1 - k];
+	return (long long)len;
+}
+
+long long rk_astar_lookup(rk_astar_t *h, const int8_t *h_state, void *stream)
+{
+	if (!h || !h_state) return fail(RK_EINVAL, "rk_astar_lookup: null argument");
+	hipStream_t st = (hipStream_t)stream;
+	long long out = 0;
+	RK_HIP(hipMemcpyAsync(h->root_dev, h_state, STATE_BYTES, hipMemcpyHostToDevice, st));
+	hipLaunchKernelGGL(k_astar_find, dim3(1), dim3(64), 0, st, h->root_dev, h->states, h->table, h->mask, h->counters + 3);
+	RK_HIP(hipGetLastError());
+	RK_HIP(hipMemcpyAsync(&out, h->counters + 3, sizeof out, hipMemcpyDeviceToHost, st));
+	RK_HIP(hipStreamSynchronize(st));
+	return out;
+}
+
+long long rk_astar_export_open(rk_astar_t *h, double *h_costs, long long *h_indices, size_t max_len, void *stream)
+{
+	if (!h) return fail(RK_EINVAL, "rk_astar_export_open: null handle");
+	hipStream_t st = (hipStream_t)stream;
+	const size_t n = h->open_len < max_len ? h->open_len : max_len;
+	if (n == 0) return 0;
+	std::vector<Rec> r(n);
+	RK_HIP(hipMemcpyAsync(r.data(), h->open[h->cur], n * sizeof(Rec), hipMemcpyDeviceToHost, st));
+	RK_HIP(hipStreamSynchronize(st));
+	for (size_t i = 0; i < n; i++) {
+		if (h_costs) h_costs[i] = key_to_double(r[i].key);
+		if (h_indices) h_indices[i] = (long long)r[i].idx;
+	}
+	return (long long)n;
+}
+
+}  // extern "C"
