@@ -145,6 +145,45 @@ long long rk_astar_lookup(rk_astar_t *h, const int8_t *h_state, void *stream);
 /* The open queue in pop order: up to max_len (cost, index) pairs to HOST arrays; returns the count written. */
 long long rk_astar_export_open(rk_astar_t *h, double *h_costs, long long *h_indices, size_t max_len, void *stream);
 
+/* ---- Monte Carlo tree search (agents.py:415-645): T independent trees, all state in HBM ----------------------
+ * Replaces MCTS.expand_leaf / find_leaf for a whole batch of searches (the reference runs one tree at a time).
+ * Per tree the engine owns the reference's arrays: states, neighbors (cap,12), leaves, P, V, N, W, L
+ * (agents.py:419-427; index 0 unused, root = 1), a hash table state -> index, and the current path
+ * (indices_visited / actions_taken, agents.py:474-475).  One wavefront serves one tree.
+ * One simulation of every live tree (agents.py:476-490) = two stream-ordered calls around the net forward:
+ *   rk_mcts_expand        loop guard `len + 12 <= max_states` (:476); the leaf's 12 children (:513), membership and
+ *                         new indices in action order (:517-529), neighbor links both ways and leaf flag (:533-536),
+ *                         goal test of ALL children, first solved wins (:540-543).  Leaves the 12 children of every
+ *                         tree in a (T*12, 20) buffer.
+ *   rk_mcts_children_oh   one-hot of that buffer, (T*12, 480): the fixed-shape net batch
+ *   rk_mcts_backup_select P, V of the new children (:556-557), W[leaf] = V[neighbors], W[new] = v, max-backup of
+ *                         max(v_new) along the path (:559-562), N += 1 once per distinct (node, action) of the path,
+ *                         virtual loss cleared (:567-570); then, unless the tree just solved, the next descent
+ *                         `find_leaf` (:575-595): U = c P sqrt(sum N)/(1+N), Q = W - L, first argmax, L += nu on both
+ *                         ends of the chosen edge.  d_probs (T*12, 12) are softmaxed policy rows, d_values (T*12).
+ * Nothing synchronises, shapes are fixed and finished trees are skipped on the device, so a simulation step can be
+ * captured in a hipGraph and replayed.  float64 statistics, no fused multiply-add: identical to NumPy. */
+typedef struct rk_mcts rk_mcts_t;
+int rk_mcts_create(rk_mcts_t **out, int n_trees, size_t capacity_per_tree, size_t max_path);
+int rk_mcts_destroy(rk_mcts_t *h);
+/* h_start_states (T,20) host; h_max_states (T) host or NULL (= capacity); c exploration constant, nu virtual loss. */
+int rk_mcts_reset(rk_mcts_t *h, const int8_t *h_start_states, const long long *h_max_states, double c, double nu, void *stream);
+/* One-hot of the T root states (T, 480) for the net; then hand back softmaxed policy (T,12) and value (T). */
+int rk_mcts_roots_oh(rk_mcts_t *h, void *d_out, int out_dtype, void *stream);
+int rk_mcts_set_root_pv(rk_mcts_t *h, const float *d_probs, const float *d_values, void *stream);
+int rk_mcts_expand(rk_mcts_t *h, void *stream);
+int rk_mcts_children_oh(rk_mcts_t *h, void *d_out, int out_dtype, void *stream);
+int rk_mcts_backup_select(rk_mcts_t *h, const float *d_probs, const float *d_values, void *stream);
+/* Synchronises.  h_status is (T, 6) int64: done, solved, n_states, simulations, path_len, error. */
+int rk_mcts_status(rk_mcts_t *h, long long *h_status, void *stream);
+/* Rows [first, first+count) of one tree's arrays to HOST buffers in the reference's dtypes (any may be NULL):
+ * states int8 (count,20), neighbors int64 (count,12), leaves uint8, P/W/L float64 (count,12), V float64, N int64. */
+int rk_mcts_export(rk_mcts_t *h, int tree, size_t first, size_t count, int8_t *h_states, long long *h_neighbors,
+                   uint8_t *h_leaves, double *h_P, double *h_V, long long *h_N, double *h_W, double *h_L, void *stream);
+/* The tree's action queue: the solving actions if it solved (agents.py:483), else the actions of its current
+ * descent (agents.py:492).  Also the visited node indices if h_nodes != NULL.  Returns the number of actions. */
+long long rk_mcts_path(rk_mcts_t *h, int tree, long long *h_actions, long long *h_nodes, size_t max_len, void *stream);
+
 /* ---- host-pointer conveniences (allocate scratch, copy, launch, copy back, synchronise) ---- */
 int rk_multi_rotate_host(int repr, const int8_t *h_states, const uint8_t *h_actions, int8_t *h_out,
                          size_t n, void *stream);

@@ -53,6 +53,17 @@ SIGNATURES = {
 	"rk_astar_path": (C.c_longlong, [_vp, C.c_longlong, _vp, _sz, _vp]),
 	"rk_astar_lookup": (C.c_longlong, [_vp, _vp, _vp]),
 	"rk_astar_export_open": (C.c_longlong, [_vp, _vp, _vp, _sz, _vp]),
+	"rk_mcts_create": (_i, [C.POINTER(_vp), _i, _sz, _sz]),
+	"rk_mcts_destroy": (_i, [_vp]),
+	"rk_mcts_reset": (_i, [_vp, _vp, _vp, C.c_double, C.c_double, _vp]),
+	"rk_mcts_roots_oh": (_i, [_vp, _vp, _i, _vp]),
+	"rk_mcts_set_root_pv": (_i, [_vp, _vp, _vp, _vp]),
+	"rk_mcts_expand": (_i, [_vp, _vp]),
+	"rk_mcts_children_oh": (_i, [_vp, _vp, _i, _vp]),
+	"rk_mcts_backup_select": (_i, [_vp, _vp, _vp, _vp]),
+	"rk_mcts_status": (_i, [_vp, _vp, _vp]),
+	"rk_mcts_export": (_i, [_vp, _i, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+	"rk_mcts_path": (C.c_longlong, [_vp, _i, _vp, _vp, _sz, _vp]),
 	"rk_multi_rotate_host": (_i, [_i, _vp, _vp, _vp, _sz, _vp]),
 	"rk_expand12_host": (_i, [_i, _vp, _vp, _vp, _vp, _sz, _vp]),
 	"rk_multi_is_solved_host": (_i, [_i, _vp, _vp, _vp, _sz, _vp]),

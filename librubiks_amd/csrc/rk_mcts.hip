@@ -1,0 +1,497 @@
+// Batched Monte Carlo tree search on the device (reference: librubiks/solving/agents.py:415-645).
+//
+// T independent trees; ONE wavefront per tree (workgroup = 64 lanes, grid = T).  Lane a < 12 owns action column a
+// of whatever node the tree is looking at, so a node's 12-wide rows (neighbors, P, N, W, L) are read and written as
+// single coalesced row accesses, the 12-way reductions (sum of N, first arg-max of U+Q, max of the new values) are
+// 16-lane shuffles, and the loops over the visited path use all 64 lanes.
+//
+// Per-tree arrays in HBM (cap = capacity + 1 rows, row 0 unused, root = 1) mirror the reference's (agents.py:419-427):
+//   states int8 (cap,20) | neighbors int32 (cap,12) | leaves uint8 | P, W, L float64 (cap,12) | V float64 | N int32 (cap,12)
+// plus stamp int32 (cap,12) (simulation number of the last N increment: NumPy's `N[path, actions] += 1` counts a
+// repeated (node, action) pair once), a hash table state -> index, and the current path.
+//
+// Statistics are float64 and this file is compiled without fused multiply-add so that U = c*P*sqrt(sum N)/(1+N),
+// Q = W - L and the arg-max reproduce NumPy's results bit for bit.
+#include <hip/hip_runtime.h>
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/rubiks_hip.h"
+#include "rk_device.h"
+#include "rk_error.h"
+#include "rk_kernels.h"
+
+namespace rk {
+
+struct MctsDev {
+	int T;
+	uint32_t cap1;            // rows per tree
+	uint32_t tmask;           // hash table size - 1 (per tree)
+	uint32_t max_path;
+	double c, nu;
+	uint32_t *states; int32_t *neighbors; uint8_t *leaves;
+	double *P, *V, *W, *L; int32_t *N, *stamp;
+	uint32_t *table;
+	int32_t *path_nodes; uint8_t *path_actions;
+	int32_t *path_len, *n_states, *max_states, *sims, *solve_action, *solve_leaf, *error;
+	uint8_t *done, *solved;
+	// per-simulation hand-off between expand and backup
+	uint32_t *children; int32_t *child_idx; uint8_t *child_new;
+};
+
+__device__ __forceinline__ uint32_t mcts_hash(const uint32_t s[5])
+{
+	uint64_t h = 0x9E3779B97F4A7C15ull;
+	#pragma unroll
+	for (int j = 0; j < 5; j++) {
+		h ^= s[j];
+		h *= 0xFF51AFD7ED558CCDull;
+		h ^= h >> 29;
+	}
+	return (uint32_t)(h ^ (h >> 32));
+}
+
+__device__ __forceinline__ bool same5(const uint32_t a[5], const uint32_t *p)
+{
+	return ((a[0] ^ p[0]) | (a[1] ^ p[1]) | (a[2] ^ p[2]) | (a[3] ^ p[3]) | (a[4] ^ p[4])) == 0;
+}
+
+__device__ __forceinline__ void fence_wave_to_wave()
+{
+	// later loads of this wave (other lanes) must see earlier stores of this wave
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64)
+void k_mcts_root(MctsDev d, const uint32_t *starts)
+{
+	const int t = blockIdx.x, lane = threadIdx.x;
+	uint32_t s[5];
+	#pragma unroll
+	for (int j = 0; j < 5; j++) s[j] = starts[(size_t)t * 5 + j];
+	if (lane == 0) {
+		uint32_t *st = d.states + ((size_t)t * d.cap1 + 1) * 5;
+		#pragma unroll
+		for (int j = 0; j < 5; j++) st[j] = s[j];
+		d.table[(size_t)t * (d.tmask + 1) + (mcts_hash(s) & d.tmask)] = 1u;
+		d.n_states[t] = 1;
+		d.path_nodes[(size_t)t * d.max_path] = 1;
+		d.path_len[t] = 1;
+		d.sims[t] = 0;
+		d.error[t] = 0;
+		d.solve_action[t] = -1;
+		d.solve_leaf[t] = -1;
+		const bool solved = is_solved5(s);            // agents.py:468: a solved start returns immediately
+		d.done[t] = solved ? 1 : 0;
+		d.solved[t] = solved ? 2 : 0;
+	}
+}
+
+__global__ void k_mcts_set_root_pv(MctsDev d, const float *probs, const float *values)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= d.T * 12) return;
+	const int t = i / 12, k = i - 12 * t;
+	d.P[((size_t)t * d.cap1 + 1) * 12 + k] = (double)probs[i];          // agents.py:472
+	if (k == 0) d.V[(size_t)t * d.cap1 + 1] = (double)values[t];        // agents.py:473
+}
+
+__global__ void k_mcts_gather_roots(MctsDev d, uint32_t *out)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= d.T * 5) return;
+	const int t = i / 5, j = i - 5 * t;
+	out[i] = d.states[((size_t)t * d.cap1 + 1) * 5 + j];
+}
+
+// expand_leaf, first half (agents.py:505-543)
+__global__ __launch_bounds__(64)
+void k_mcts_expand(MctsDev d)
+{
+	__shared__ u32x4 s_act[36];
+	const int t = blockIdx.x, lane = threadIdx.x;
+	stage_action_tables(s_act, lane);
+	__syncthreads();
+	const bool active = lane < 12;
+	const size_t cbase = (size_t)t * 12 + lane;
+	if (active) d.child_new[cbase] = 0;
+	if (d.done[t]) return;
+	const int n = d.n_states[t];
+	if (n + 12 > d.max_states[t]) {                   // loop guard of agents.py:476
+		if (lane == 0) d.done[t] = 1;
+		return;
+	}
+	const size_t node0 = (size_t)t * d.cap1;
+	const int plen = d.path_len[t];
+	const int leaf = d.path_nodes[(size_t)t * d.max_path + plen - 1];
+
+	uint32_t s[5];
+	#pragma unroll
+	for (int j = 0; j < 5; j++) s[j] = d.states[(node0 + leaf) * 5 + j];
+	uint32_t tab[12];
+	load_action_table(s_act, active ? (uint32_t)lane : 0u, tab);
+	move5(s, tab);                                    // child `lane` of the leaf                  agents.py:513
+
+	// membership (agents.py:517-520)
+	uint32_t *table = d.table + (size_t)t * (d.tmask + 1);
+	uint32_t slot = mcts_hash(s) & d.tmask;
+	int idx = 0;
+	if (active) {
+		for (;;) {
+			const uint32_t e = table[slot];
+			if (e == 0u) break;
+			if (same5(s, d.states + (node0 + e) * 5)) { idx = (int)e; break; }
+			slot = (slot + 1) & d.tmask;
+		}
+	}
+	const bool is_new = active && idx == 0;
+	const unsigned long long newmask = __ballot(is_new);
+	if (is_new) {                                     // new indices in action order              agents.py:523-529
+		idx = n + 1 + __popcll(newmask & ((1ull << lane) - 1ull));
+		while (atomicCAS(&table[slot], 0u, (uint32_t)idx) != 0u) slot = (slot + 1) & d.tmask;
+		#pragma unroll
+		for (int j = 0; j < 5; j++) d.states[(node0 + idx) * 5 + j] = s[j];
+	}
+	if (active) {
+		#pragma unroll
+		for (int j = 0; j < 5; j++) d.children[cbase * 5 + j] = s[j];
+		d.child_idx[cbase] = idx;
+		d.child_new[cbase] = is_new ? 1 : 0;
+		d.neighbors[(node0 + leaf) * 12 + lane] = idx;                     // agents.py:534
+		d.neighbors[(node0 + idx) * 12 + (lane ^ 1)] = leaf;               // agents.py:535
+	}
+	const unsigned long long solvedmask = __ballot(active && is_solved5(s));   // agents.py:540-543: first solved child
+	if (solvedmask != 0ull && lane == __ffsll((long long)solvedmask) - 1) {
+		d.solved[t] = 1;
+		d.solve_action[t] = lane;
+		d.solve_leaf[t] = idx;
+	}
+	if (lane == 0) {
+		d.leaves[node0 + leaf] = 0;                                        // agents.py:536
+		d.n_states[t] = n + __popcll(newmask);
+	}
+}
+
+// expand_leaf, second half (agents.py:546-571) + find_leaf (agents.py:575-595)
+__global__ __launch_bounds__(64)
+void k_mcts_backup_select(MctsDev d, const float *probs, const float *values)
+{
+	const int t = blockIdx.x, lane = threadIdx.x;
+	if (d.done[t]) return;
+	const bool active = lane < 12;
+	const size_t node0 = (size_t)t * d.cap1;
+	const size_t cbase = (size_t)t * 12 + lane;
+	const int32_t *pnodes = d.path_nodes + (size_t)t * d.max_path;
+	uint8_t *pacts = d.path_actions + (size_t)t * d.max_path;
+	const int plen = d.path_len[t];
+	const int leaf = pnodes[plen - 1];
+
+	const int idx = active ? d.child_idx[cbase] : 0;
+	const bool is_new = active && d.child_new[cbase] != 0;
+	const float vf = active ? values[cbase] : 0.0f;
+	const double v = (double)vf;
+	if (is_new) {
+		d.V[node0 + idx] = v;                                              // agents.py:557
+		#pragma unroll
+		for (int k = 0; k < 12; k++) {
+			d.P[(node0 + idx) * 12 + k] = (double)probs[cbase * 12 + k];   // agents.py:556
+			d.W[(node0 + idx) * 12 + k] = v;                               // agents.py:561
+		}
+	}
+	float bestf = is_new ? vf : -INFINITY;                                 // v.max() over the NEW children (:559)
+	#pragma unroll
+	for (int m = 8; m > 0; m >>= 1) bestf = fmaxf(bestf, __shfl_xor(bestf, m, 16));
+	bestf = __shfl(bestf, 0, 64);
+	const bool has_new = __ballot(is_new) != 0ull;
+	const double best = (double)bestf;
+	if (active) d.W[(node0 + leaf) * 12 + lane] = is_new ? v : d.V[node0 + idx];     // agents.py:560
+
+	const int sim = d.sims[t] + 1;
+	for (int e = lane; e < plen - 1; e += 64) {
+		const int node = pnodes[e], act = pacts[e];
+		const size_t r = (node0 + node) * 12 + act;
+		if (has_new && best > d.W[r]) d.W[r] = best;                       // agents.py:562
+		if (atomicExch(&d.stamp[r], sim) != sim) d.N[r] += 1;              // agents.py:568 (a repeated pair counts once)
+		d.L[r] = 0.0;                                                      // agents.py:569
+		d.L[(node0 + pnodes[e + 1]) * 12 + (act ^ 1)] = 0.0;               // agents.py:570
+	}
+	if (lane == 0) d.sims[t] = sim;
+	if (d.solved[t]) {                                                     // agents.py:482-487
+		if (lane == 0) {
+			pacts[plen - 1] = (uint8_t)d.solve_action[t];
+			d.done[t] = 1;
+		}
+		return;
+	}
+	fence_wave_to_wave();
+
+	// ---- find_leaf ----
+	int cur = 1, len = 1;
+	for (;;) {
+		if (d.leaves[node0 + cur]) break;
+		const size_t r = (node0 + cur) * 12 + lane;
+		const int nA = active ? d.N[r] : 0;
+		int sumN = nA;
+		#pragma unroll
+		for (int m = 8; m > 0; m >>= 1) sumN += __shfl_xor(sumN, m, 16);
+		sumN = __shfl(sumN, 0, 64);
+		double x = -INFINITY, lval = 0.0;
+		int nb = 0, best_a = lane;
+		if (active) {
+			const double sqrtN = sqrt((double)sumN);
+			double U = d.c * d.P[r];
+			U = U * sqrtN;
+			U = U / (double)(1 + nA);
+			lval = d.L[r];
+			const double Q = d.W[r] - lval;
+			x = U + Q;
+			nb = d.neighbors[r];
+		}
+		#pragma unroll
+		for (int m = 8; m > 0; m >>= 1) {                                  // first arg-max (np.argmax)
+			const double ox = __shfl_xor(x, m, 16);
+			const int oa = __shfl_xor(best_a, m, 16);
+			if (ox > x || (ox == x && oa < best_a)) { x = ox; best_a = oa; }
+		}
+		best_a = __shfl(best_a, 0, 64);
+		const int next = __shfl(nb, best_a, 64);
+		if (lane == best_a) d.L[r] = lval + d.nu;                          // agents.py:589
+		if (lane == (best_a ^ 1)) d.L[(node0 + next) * 12 + lane] += d.nu; // agents.py:591
+		if (lane == 0) {
+			pacts[len - 1] = (uint8_t)best_a;
+			d.path_nodes[(size_t)t * d.max_path + len] = next;
+		}
+		len++;
+		cur = next;
+		if (len >= (int)d.max_path || next <= 0) {
+			if (lane == 0) { d.error[t] = next <= 0 ? 2 : 1; d.done[t] = 1; }
+			break;
+		}
+	}
+	if (lane == 0) d.path_len[t] = len;
+}
+
+}  // namespace rk
+
+using namespace rk;
+
+struct rk_mcts {
+	MctsDev d{};
+	size_t capacity = 0;
+	std::vector<void *> allocs;
+	uint32_t *starts_dev = nullptr;
+	bool ready = false;
+};
+
+namespace {
+
+template <typename T>
+int mcts_alloc(rk_mcts *h, T **p, size_t count)
+{
+	void *q = nullptr;
+	RK_HIP(hipMalloc(&q, count * sizeof(T) + 16));
+	h->allocs.push_back(q);
+	*p = static_cast<T *>(q);
+	return RK_OK;
+}
+
+inline unsigned nblocks(size_t n, unsigned per = 256) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+extern "C" {
+
+int rk_mcts_create(rk_mcts_t **out, int n_trees, size_t capacity_per_tree, size_t max_path)
+{
+	if (!out) return fail(RK_EINVAL, "rk_mcts_create: null out pointer");
+	if (n_trees < 1 || n_trees > (1 << 20)) return fail(RK_EINVAL, "rk_mcts_create: n_trees %d out of range", n_trees);
+	if (capacity_per_tree < 13 || capacity_per_tree > 0x3FFFFFF0ull) return fail(RK_EINVAL, "rk_mcts_create: capacity %zu out of range", capacity_per_tree);
+	if (max_path < 2 || max_path > (1u << 30)) return fail(RK_EINVAL, "rk_mcts_create: max_path %zu out of range", max_path);
+	rk_mcts *h = new rk_mcts();
+	h->capacity = capacity_per_tree;
+	MctsDev &d = h->d;
+	d.T = n_trees;
+	d.cap1 = (uint32_t)(capacity_per_tree + 1);
+	uint64_t ts = 64;
+	while (ts < 2ull * d.cap1) ts <<= 1;
+	d.tmask = (uint32_t)(ts - 1);
+	d.max_path = (uint32_t)max_path;
+	const size_t T = (size_t)n_trees, rows = T * d.cap1;
+	int e = RK_OK;
+	#define A(ptr, cnt) if (!e) e = mcts_alloc(h, &d.ptr, (cnt))
+	A(states, rows * 5); A(neighbors, rows * 12); A(leaves, rows);
+	A(P, rows * 12); A(V, rows); A(W, rows * 12); A(L, rows * 12); A(N, rows * 12); A(stamp, rows * 12);
+	A(table, T * (size_t)ts);
+	A(path_nodes, T * max_path); A(path_actions, T * max_path);
+	A(path_len, T); A(n_states, T); A(max_states, T); A(sims, T); A(solve_action, T); A(solve_leaf, T); A(error, T);
+	A(done, T); A(solved, T);
+	A(children, T * 12 * 5 + 64); A(child_idx, T * 12); A(child_new, T * 12);
+	#undef A
+	if (!e) e = mcts_alloc(h, &h->starts_dev, T * 5);
+	if (e) { rk_mcts_destroy(h); return e; }
+	*out = h;
+	return RK_OK;
+}
+
+int rk_mcts_destroy(rk_mcts_t *h)
+{
+	if (!h) return RK_OK;
+	for (void *p : h->allocs) (void)hipFree(p);
+	delete h;
+	return RK_OK;
+}
+
+int rk_mcts_reset(rk_mcts_t *h, const int8_t *h_start_states, const long long *h_max_states, double c, double nu, void *stream)
+{
+	if (!h || !h_start_states) return fail(RK_EINVAL, "rk_mcts_reset: null argument");
+	hipStream_t st = (hipStream_t)stream;
+	MctsDev &d = h->d;
+	const size_t T = (size_t)d.T, rows = T * d.cap1;
+	d.c = c;
+	d.nu = nu;
+	std::vector<int32_t> ms(T);
+	for (size_t t = 0; t < T; t++) {
+		long long m = h_max_states ? h_max_states[t] : (long long)h->capacity;
+		if (m > (long long)h->capacity) m = (long long)h->capacity;       // never index past the pool
+		ms[t] = (int32_t)(m < 0 ? 0 : m);
+	}
+	RK_HIP(hipMemsetAsync(d.neighbors, 0, rows * 12 * sizeof(int32_t), st));      // agents.py:441
+	RK_HIP(hipMemsetAsync(d.leaves, 1, rows, st));                                 // agents.py:442
+	RK_HIP(hipMemsetAsync(d.P, 0, rows * 12 * sizeof(double), st));
+	RK_HIP(hipMemsetAsync(d.V, 0, rows * sizeof(double), st));
+	RK_HIP(hipMemsetAsync(d.W, 0, rows * 12 * sizeof(double), st));               // agents.py:446
+	RK_HIP(hipMemsetAsync(d.L, 0, rows * 12 * sizeof(double), st));               // agents.py:447
+	RK_HIP(hipMemsetAsync(d.N, 0, rows * 12 * sizeof(int32_t), st));              // agents.py:445
+	RK_HIP(hipMemsetAsync(d.stamp, 0, rows * 12 * sizeof(int32_t), st));
+	RK_HIP(hipMemsetAsync(d.table, 0, T * ((size_t)d.tmask + 1) * sizeof(uint32_t), st));
+	RK_HIP(hipMemsetAsync(d.child_new, 0, T * 12, st));
+	RK_HIP(hipMemsetAsync(d.child_idx, 0, T * 12 * sizeof(int32_t), st));
+	RK_HIP(hipMemsetAsync(d.children, 0, (T * 12 * 5) * sizeof(uint32_t), st));
+	RK_HIP(hipMemcpyAsync(d.max_states, ms.data(), T * sizeof(int32_t), hipMemcpyHostToDevice, st));
+	RK_HIP(hipMemcpyAsync(h->starts_dev, h_start_states, T * STATE_BYTES, hipMemcpyHostToDevice, st));
+	hipLaunchKernelGGL(k_mcts_root, dim3(d.T), dim3(64), 0, st, d, h->starts_dev);
+	RK_HIP(hipGetLastError());
+	RK_HIP(hipStreamSynchronize(st));           // host buffers may go away after return
+	h->ready = true;
+	return RK_OK;
+}
+
+int rk_mcts_roots_oh(rk_mcts_t *h, void *d_out, int out_dtype, void *stream)
+{
+	if (!h || !h->ready) return fail(RK_ESTATE, "rk_mcts_roots_oh: reset the engine first");
+	MctsDev &d = h->d;
+	hipLaunchKernelGGL(k_mcts_gather_roots, dim3(nblocks((size_t)d.T * 5)), dim3(256), 0, (hipStream_t)stream, d, d.children);
+	RK_HIP(hipGetLastError());
+	return rk_as_oh(RK_REPR_2024, (const int8_t *)d.children, d_out, out_dtype, (size_t)d.T, stream);
+}
+
+int rk_mcts_set_root_pv(rk_mcts_t *h, const float *d_probs, const float *d_values, void *stream)
+{
+	if (!h || !h->ready) return fail(RK_ESTATE, "rk_mcts_set_root_pv: reset the engine first");
+	if (!d_probs || !d_values) return fail(RK_EINVAL, "rk_mcts_set_root_pv: null pointer");
+	hipLaunchKernelGGL(k_mcts_set_root_pv, dim3(nblocks((size_t)h->d.T * 12)), dim3(256), 0, (hipStream_t)stream, h->d, d_probs, d_values);
+	RK_HIP(hipGetLastError());
+	return RK_OK;
+}
+
+int rk_mcts_expand(rk_mcts_t *h, void *stream)
+{
+	if (!h || !h->ready) return fail(RK_ESTATE, "rk_mcts_expand: reset the engine first");
+	hipLaunchKernelGGL(k_mcts_expand, dim3(h->d.T), dim3(64), 0, (hipStream_t)stream, h->d);
+	RK_HIP(hipGetLastError());
+	return RK_OK;
+}
+
+int rk_mcts_children_oh(rk_mcts_t *h, void *d_out, int out_dtype, void *stream)
+{
+	if (!h || !h->ready) return fail(RK_ESTATE, "rk_mcts_children_oh: reset the engine first");
+	return rk_as_oh(RK_REPR_2024, (const int8_t *)h->d.children, d_out, out_dtype, (size_t)h->d.T * 12, stream);
+}
+
+int rk_mcts_backup_select(rk_mcts_t *h, const float *d_probs, const float *d_values, void *stream)
+{
+	if (!h || !h->ready) return fail(RK_ESTATE, "rk_mcts_backup_select: reset the engine first");
+	if (!d_probs || !d_values) return fail(RK_EINVAL, "rk_mcts_backup_select: null pointer");
+	hipLaunchKernelGGL(k_mcts_backup_select, dim3(h->d.T), dim3(64), 0, (hipStream_t)stream, h->d, d_probs, d_values);
+	RK_HIP(hipGetLastError());
+	return RK_OK;
+}
+
+int rk_mcts_status(rk_mcts_t *h, long long *h_status, void *stream)
+{
+	if (!h || !h->ready || !h_status) return fail(RK_EINVAL, "rk_mcts_status: bad argument");
+	hipStream_t st = (hipStream_t)stream;
+	const MctsDev &d = h->d;
+	const size_t T = (size_t)d.T;
+	std::vector<uint8_t> done(T), solved(T);
+	std::vector<int32_t> n(T), sims(T), plen(T), err(T);
+	RK_HIP(hipMemcpyAsync(done.data(), d.done, T, hipMemcpyDeviceToHost, st));
+	RK_HIP(hipMemcpyAsync(solved.data(), d.solved, T, hipMemcpyDeviceToHost, st));
+	RK_HIP(hipMemcpyAsync(n.data(), d.n_states, T * 4, hipMemcpyDeviceToHost, st));
+	RK_HIP(hipMemcpyAsync(sims.data(), d.sims, T * 4, hipMemcpyDeviceToHost, st));
+	RK_HIP(hipMemcpyAsync(plen.data(), d.path_len, T * 4, hipMemcpyDeviceToHost, st));
+	RK_HIP(hipMemcpyAsync(err.data(), d.error, T * 4, hipMemcpyDeviceToHost, st));
+	RK_HIP(hipStreamSynchronize(st));
+	for (size_t t = 0; t < T; t++) {
+		long long *r = h_status + 6 * t;
+		r[0] = done[t]; r[1] = solved[t]; r[2] = n[t]; r[3] = sims[t]; r[4] = plen[t]; r[5] = err[t];
+	}
+	return RK_OK;
+}
+
+int rk_mcts_export(rk_mcts_t *h, int tree, size_t first, size_t count, int8_t *h_states, long long *h_neighbors,
+                   uint8_t *h_leaves, double *h_P, double *h_V, long long *h_N, double *h_W, double *h_L, void *stream)
+{
+	if (!h || !h->ready) return fail(RK_ESTATE, "rk_mcts_export: reset the engine first");
+	const MctsDev &d = h->d;
+	if (tree < 0 || tree >= d.T) return fail(RK_EINVAL, "rk_mcts_export: tree %d out of range", tree);
+	if (first + count > d.cap1) return fail(RK_EINVAL, "rk_mcts_export: rows outside the pool");
+	if (count == 0) return RK_OK;
+	hipStream_t st = (hipStream_t)stream;
+	const size_t r0 = (size_t)tree * d.cap1 + first;
+	std::vector<int32_t> nb, nn;
+	if (h_states) RK_HIP(hipMemcpyAsync(h_states, d.states + r0 * 5, count * STATE_BYTES, hipMemcpyDeviceToHost, st));
+	if (h_leaves) RK_HIP(hipMemcpyAsync(h_leaves, d.leaves + r0, count, hipMemcpyDeviceToHost, st));
+	if (h_P) RK_HIP(hipMemcpyAsync(h_P, d.P + r0 * 12, count * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
+	if (h_V) RK_HIP(hipMemcpyAsync(h_V, d.V + r0, count * sizeof(double), hipMemcpyDeviceToHost, st));
+	if (h_W) RK_HIP(hipMemcpyAsync(h_W, d.W + r0 * 12, count * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
+	if (h_L) RK_HIP(hipMemcpyAsync(h_L, d.L + r0 * 12, count * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
+	if (h_neighbors) { nb.resize(count * 12); RK_HIP(hipMemcpyAsync(nb.data(), d.neighbors + r0 * 12, count * 12 * 4, hipMemcpyDeviceToHost, st)); }
+	if (h_N) { nn.resize(count * 12); RK_HIP(hipMemcpyAsync(nn.data(), d.N + r0 * 12, count * 12 * 4, hipMemcpyDeviceToHost, st)); }
+	RK_HIP(hipStreamSynchronize(st));
+	for (size_t i = 0; i < count * 12; i++) {
+		if (h_neighbors) h_neighbors[i] = nb[i];
+		if (h_N) h_N[i] = nn[i];
+	}
+	return RK_OK;
+}
+
+long long rk_mcts_path(rk_mcts_t *h, int tree, long long *h_actions, long long *h_nodes, size_t max_len, void *stream)
+{
+	if (!h || !h->ready) return fail(RK_ESTATE, "rk_mcts_path: reset the engine first");
+	const MctsDev &d = h->d;
+	if (tree < 0 || tree >= d.T) return fail(RK_EINVAL, "rk_mcts_path: tree %d out of range", tree);
+	hipStream_t st = (hipStream_t)stream;
+	int32_t plen = 0;
+	uint8_t solved = 0;
+	RK_HIP(hipMemcpyAsync(&plen, d.path_len + tree, 4, hipMemcpyDeviceToHost, st));
+	RK_HIP(hipMemcpyAsync(&solved, d.solved + tree, 1, hipMemcpyDeviceToHost, st));
+	RK_HIP(hipStreamSynchronize(st));
+	if (plen < 1) return fail(RK_ESTATE, "rk_mcts_path: empty path");
+	std::vector<int32_t> nodes((size_t)plen);
+	std::vector<uint8_t> acts((size_t)plen);
+	RK_HIP(hipMemcpyAsync(nodes.data(), d.path_nodes + (size_t)tree * d.max_path, (size_t)plen * 4, hipMemcpyDeviceToHost, st));
+	RK_HIP(hipMemcpyAsync(acts.data(), d.path_actions + (size_t)tree * d.max_path, (size_t)plen, hipMemcpyDeviceToHost, st));
+	RK_HIP(hipStreamSynchronize(st));
+	// solved during a simulation: the descent's actions plus the solving one; solved at the root: nothing; else the descent
+	const size_t n_act = solved == 1 ? (size_t)plen : (solved == 2 ? 0 : (size_t)plen - 1);
+	for (size_t i = 0; i < n_act && i < max_len; i++) if (h_actions) h_actions[i] = acts[i];
+	for (size_t i = 0; i < (size_t)plen && i < max_len; i++) if (h_nodes) h_nodes[i] = nodes[i];
+	return (long long)n_act;
+}
+
+}  // extern "C"

@@ -224,3 +224,259 @@ class AStar(DeepAgent):
 
 	def __str__(self) -> str:
 		return f'AStar (lambda={self.lambda_}, N={self.expansions})'
+
+
+def _policy_value_f32(out):
+	"""(softmaxed policy (B,12), value (B,)) as contiguous float32 GPU tensors from the net's [logits, value]."""
+	p, v = out
+	p = p.detach().to(device=gpu, dtype=torch.float32).softmax(dim=1).contiguous()
+	v = v.detach().to(device=gpu, dtype=torch.float32).reshape(-1).contiguous()
+	return p, v
+
+
+class MCTSBatch(DeepAgent):
+	"""
+	T independent Monte Carlo tree searches advanced in lock-step on the GPU (engine rk_mcts_*).  Each tree follows
+	the reference's MCTS exactly (agents.py:415-645): same node numbering, neighbors, P, V, N, W, L and action queue
+	as running the reference on that start state alone, whenever the net returns the same numbers.
+
+	One simulation of all trees = expand kernel, one-hot kernel, net forward on the fixed (12 T, 480) batch,
+	backup+select kernel.  Nothing in a step synchronises, so `use_graph=True` captures the step in a hipGraph
+	(through torch.cuda.CUDAGraph) and replays it; the host only polls every `poll` simulations.
+	"""
+
+	def __init__(self, net, c: float, n_trees: int, capacity: int = 50_000, max_path: int = None, nu: float = 100.0):
+		super().__init__(net)
+		self.c, self.nu, self.n_trees = float(c), float(nu), int(n_trees)
+		self.capacity = int(capacity)
+		self.max_path = int(max_path or max(4096, 2 * self.capacity))
+		self._h = None
+		self._shape = None
+		self.status = None
+		self.simulations = 0
+
+	def _engine(self):
+		shape = (self.n_trees, self.capacity, self.max_path)
+		if self._h is None or self._shape != shape:
+			self._free()
+			h = C.c_void_p()
+			_ffi.check(_ffi.lib().rk_mcts_create(C.byref(h), *shape))
+			self._h, self._shape = h, shape
+		return self._h
+
+	def _free(self):
+		if getattr(self, "_h", None) is not None:
+			_ffi.lib().rk_mcts_destroy(self._h)
+			self._h = None
+
+	def __del__(self):
+		try:
+			self._free()
+		except Exception:
+			pass
+
+	def _poll(self):
+		st = np.zeros((self.n_trees, 6), np.int64)
+		_ffi.check(_ffi.lib().rk_mcts_status(self._h, st.ctypes.data, _ffi.stream_ptr()))
+		if (st[:, 5] != 0).any():
+			raise _ffi.RubiksHipError(f"MCTS engine error codes {st[:, 5].tolist()}: path longer than max_path={self.max_path}")
+		self.status = st
+		return st
+
+	def _step(self, oh, h):
+		lib = _ffi.lib()
+		_ffi.check(lib.rk_mcts_expand(h, _ffi.stream_ptr()))
+		_ffi.check(lib.rk_mcts_children_oh(h, oh.data_ptr(), _ffi.OH_F32, _ffi.stream_ptr()))
+		p, v = _policy_value_f32(self.net(oh))
+		self._keep = (p, v)            # the kernels read these after this call returns
+		_ffi.check(lib.rk_mcts_backup_select(h, p.data_ptr(), v.data_ptr(), _ffi.stream_ptr()))
+
+	@no_grad
+	def search(self, states: np.ndarray, time_limit: float = None, max_states=None, max_sims: int = None,
+	           use_graph: bool = False, poll: int = 16) -> np.ndarray:
+		"""Runs all trees until each is solved or out of budget; returns the bool vector `solved` (T,)."""
+		_ffi.require_gpu()
+		t0 = time.perf_counter()
+		assert time_limit or max_states is not None or max_sims
+		self.net.eval()
+		time_limit = time_limit or 1e10
+		states = np.ascontiguousarray(states, dtype=np.int8).reshape(self.n_trees, 20)
+		if max_states is None:
+			max_states = self.capacity
+		ms = np.minimum(np.broadcast_to(np.asarray(max_states, dtype=np.int64), (self.n_trees,)), self.capacity).copy()
+		h, lib = self._engine(), _ffi.lib()
+		_ffi.check(lib.rk_mcts_reset(h, states.ctypes.data, ms.ctypes.data, self.c, self.nu, _ffi.stream_ptr()))
+		root_oh = torch.empty((self.n_trees, 480), dtype=torch.float32, device=gpu)
+		_ffi.check(lib.rk_mcts_roots_oh(h, root_oh.data_ptr(), _ffi.OH_F32, _ffi.stream_ptr()))
+		p, v = _policy_value_f32(self.net(root_oh))                      # agents.py:470-473
+		_ffi.check(lib.rk_mcts_set_root_pv(h, p.data_ptr(), v.data_ptr(), _ffi.stream_ptr()))
+		oh = torch.empty((12 * self.n_trees, 480), dtype=torch.float32, device=gpu)
+		self.simulations = 0
+		graph = None
+		if use_graph:
+			side = torch.cuda.Stream()
+			side.wait_stream(torch.cuda.current_stream())
+			with torch.cuda.stream(side):
+				for _ in range(2):                                     # real simulations; they also warm the allocator
+					self._step(oh, h)
+					self.simulations += 1
+			torch.cuda.current_stream().wait_stream(side)
+			graph = torch.cuda.CUDAGraph()
+			with torch.cuda.graph(graph):
+				self._step(oh, h)
+		while time.perf_counter() - t0 < time_limit and (max_sims is None or self.simulations < max_sims):
+			burst = poll if max_sims is None else min(poll, max_sims - self.simulations)
+			for _ in range(burst):
+				if graph is not None:
+					graph.replay()
+				else:
+					self._step(oh, h)
+			self.simulations += burst
+			if self._poll()[:, 0].all():
+				break
+		st = self._poll()
+		return st[:, 1] != 0
+
+	# -- results ------------------------------------------------------------------------------------------------
+	def action_queue_of(self, tree: int) -> deque:
+		buf = (C.c_longlong * self.max_path)()
+		n = _ffi.lib().rk_mcts_path(self._h, tree, buf, None, self.max_path, _ffi.stream_ptr())
+		if n < 0:
+			_ffi.check(int(n))
+		return deque(int(a) for a in buf[:n])
+
+	def path_nodes_of(self, tree: int) -> list:
+		acts = (C.c_longlong * self.max_path)()
+		nodes = (C.c_longlong * self.max_path)()
+		_ffi.lib().rk_mcts_path(self._h, tree, acts, nodes, self.max_path, _ffi.stream_ptr())
+		return [int(x) for x in nodes[:int(self.status[tree, 4])]]
+
+	def tree_arrays(self, tree: int) -> dict:
+		"""The reference's arrays of one tree, rows 0..n (row 0 unused), in the reference's dtypes."""
+		n = int(self._poll()[tree, 2])
+		out = dict(
+			states=np.zeros((n + 1, 20), np.int8), neighbors=np.zeros((n + 1, 12), np.int64), leaves=np.ones(n + 1, np.uint8),
+			P=np.zeros((n + 1, 12)), V=np.zeros(n + 1), N=np.zeros((n + 1, 12), np.int64), W=np.zeros((n + 1, 12)), L=np.zeros((n + 1, 12)))
+		_ffi.check(_ffi.lib().rk_mcts_export(
+			self._h, tree, 1, n, out["states"][1:].ctypes.data, out["neighbors"][1:].ctypes.data, out["leaves"][1:].ctypes.data,
+			out["P"][1:].ctypes.data, out["V"][1:].ctypes.data, out["N"][1:].ctypes.data, out["W"][1:].ctypes.data,
+			out["L"][1:].ctypes.data, _ffi.stream_ptr()))
+		out["leaves"] = out["leaves"].astype(bool)
+		out["n"] = n
+		return out
+
+	def __len__(self):
+		return int(self.status[:, 2].sum()) if self.status is not None else 0
+
+	def __str__(self):
+		return f"Batched MCTS x{self.n_trees} (c={self.c})"
+
+
+class MCTS(DeepAgent):
+	"""
+	The reference's single-tree agent (agents.py:415-645) on the device engine: `MCTS(net, c, search_graph)`,
+	`search(state, time_limit, max_states)`, `action_queue`, `len(agent)`, and the arrays `states, neighbors, leaves,
+	P, V, N, W, L, indices` for inspection (tests/test_agents.py:49-94).
+	"""
+	default_capacity = 200_000
+
+	def __init__(self, net, c: float, search_graph: bool, capacity: int = None):
+		super().__init__(net)
+		self.c = c
+		self.search_graph = search_graph
+		self.nu = 100
+		self.capacity = capacity
+		self._batch = None
+		self._arrays = None
+		self._n = 0
+
+	def reset(self, time_limit: float, max_states: int):
+		time_limit, max_states = super().reset(time_limit, max_states)
+		self._arrays, self._n = None, 0
+		return time_limit, max_states
+
+	@no_grad
+	def search(self, state: np.ndarray, time_limit: float = None, max_states: int = None) -> bool:
+		time_limit, max_states = self.reset(time_limit, max_states)
+		cap = int(min(max_states, self.capacity or self.default_capacity))
+		if self._batch is None or self._batch.capacity != cap or self._batch.c != float(self.c):
+			self._batch = MCTSBatch(self.net, self.c, 1, capacity=cap, nu=self.nu)
+		self._batch.net = self.net
+		solved = bool(self._batch.search(np.asarray(state)[None], time_limit=time_limit, max_states=cap, poll=8)[0])
+		self._n = int(self._batch.status[0, 2])
+		self.action_queue = self._batch.action_queue_of(0)
+		if solved and self.search_graph and len(self.action_queue):
+			solve_leaf = self.index_of_solved()
+			self._complete_graph()
+			self._shorten_action_queue(solve_leaf)
+		return solved
+
+	# -- graph post-processing of a solved search (agents.py:597-633); runs once, on the exported arrays ---------
+	def index_of_solved(self) -> int:
+		return self.indices[cube.get_solved().tobytes()]
+
+	def _complete_graph(self):
+		"""Link every leaf to those of its 12 children that are already in the graph (agents.py:597-611)."""
+		a = self._export()
+		n, idx = self._n, self.indices
+		leaf_idx = np.flatnonzero(a["leaves"][:n + 1])[1:]
+		if not len(leaf_idx):
+			return
+		children = cube.expand(a["states"][leaf_idx])
+		child_idx = np.array([idx.get(c.tobytes(), 0) for c in children], dtype=np.int64)
+		rep = np.repeat(leaf_idx, 12)
+		acts = np.tile(np.arange(12), len(leaf_idx))
+		a["neighbors"][rep, acts] = child_idx
+		a["neighbors"][child_idx, acts ^ 1] = rep
+		a["neighbors"][0] = 0
+
+	def _shorten_action_queue(self, solved_index: int):
+		"""Breadth-first search for the shortest known path root -> solved state (agents.py:613-633)."""
+		if solved_index == 1:
+			return
+		nb = self._export()["neighbors"]
+		back = {1: (0, 0)}
+		frontier = deque([1])
+		while frontier:
+			v = frontier.popleft()
+			for a in range(12):
+				w = int(nb[v, a])
+				if w == 0 or w in back:
+					continue
+				back[w] = (v, a)
+				if w == solved_index:
+					queue = deque()
+					while w != 1:
+						w, act = back[w]
+						queue.appendleft(act)
+					self.action_queue = queue
+					return
+				frontier.append(w)
+
+	# -- inspection -------------------------------------------------------------------------------------------
+	def _export(self) -> dict:
+		if self._arrays is None:
+			self._arrays = self._batch.tree_arrays(0) if self._batch is not None and self._n else dict(
+				states=np.zeros((1, 20), np.int8), neighbors=np.zeros((1, 12), np.int64), leaves=np.ones(1, bool),
+				P=np.zeros((1, 12)), V=np.zeros(1), N=np.zeros((1, 12), np.int64), W=np.zeros((1, 12)), L=np.zeros((1, 12)), n=0)
+		return self._arrays
+
+	states = property(lambda self: self._export()["states"])
+	neighbors = property(lambda self: self._export()["neighbors"])
+	leaves = property(lambda self: self._export()["leaves"])
+	P = property(lambda self: self._export()["P"])
+	V = property(lambda self: self._export()["V"])
+	N = property(lambda self: self._export()["N"])
+	W = property(lambda self: self._export()["W"])
+	L = property(lambda self: self._export()["L"])
+
+	@property
+	def indices(self) -> dict:
+		st = self.states
+		return {st[i].tobytes(): i for i in range(1, self._n + 1)}
+
+	def __str__(self):
+		return ("BFS" if self.search_graph else "Naive") + f" MCTS (c={self.c})"
+
+	def __len__(self):
+		return self._n

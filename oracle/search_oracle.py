@@ -27,6 +27,7 @@ class StubNet:
 	"""
 	def __init__(self):
 		self.solved_oh = orc.as_oh(orc.SOLVED)[0]
+		self._dev = {}                       # device -> solved one-hot tensor (no copies inside a graph capture)
 
 	def eval(self):
 		return self
@@ -35,7 +36,9 @@ class StubNet:
 		import torch
 		is_torch = isinstance(x, torch.Tensor)
 		if is_torch:
-			sol = torch.from_numpy(self.solved_oh).to(x.device)
+			if x.device not in self._dev:
+				self._dev[x.device] = torch.from_numpy(self.solved_oh).to(x.device)
+			sol = self._dev[x.device]
 			v = -(20 - (x.float() * sol).sum(dim=1, keepdim=True))
 			p = torch.zeros(len(x), 12, device=x.device)
 		else:

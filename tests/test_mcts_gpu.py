@@ -1,0 +1,127 @@
+"""
+GPU parity of the batched MCTS engine (rk_mcts_*, librubiks_amd.solving.agents.MCTS / MCTSBatch):
+  * replays the traces of the UNMODIFIED reference MCTS (tests/golden/mcts_trace.npz, exact-integer stub net);
+  * a batch of trees advanced in lock-step equals the CPU oracle run on every start state alone, eager and as a
+    replayed hipGraph;
+  * with a float net: the structural invariants of the reference's tests/test_agents.py:49-94.
+"""
+import numpy as np
+import pytest
+import torch
+
+from librubiks_amd import cube
+from librubiks_amd.solving.agents import MCTS, MCTSBatch
+from oracle import cube_oracle as orc
+from oracle.search_oracle import MCTSOracle, StubNet
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_tree(arrs: dict, ref: MCTSOracle):
+	n = len(ref)
+	assert arrs["n"] == n
+	assert (arrs["states"][1:n + 1] == ref.states[1:n + 1]).all()
+	assert (arrs["neighbors"][1:n + 1] == ref.neighbors[1:n + 1]).all()
+	assert (arrs["leaves"][1:n + 1] == ref.leaves[1:n + 1]).all()
+	assert (arrs["N"][1:n + 1] == ref.N[1:n + 1]).all()
+	assert (arrs["W"][1:n + 1] == ref.W[1:n + 1]).all()
+	assert (arrs["L"][1:n + 1] == ref.L[1:n + 1]).all()
+	assert (arrs["V"][1:n + 1] == ref.V[1:n + 1]).all()
+	assert (arrs["P"][1:n + 1] == ref.P[1:n + 1]).all()
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e"])
+def test_reference_traces(golden, tag):
+	t = golden["mcts_trace"]
+	_, _, search_graph, max_states = (int(x) for x in t[f"{tag}_params"])
+	start = t[f"{tag}_start"]
+	agent = MCTS(StubNet(), float(t[f"{tag}_c"]), bool(search_graph))
+	solved = agent.search(start, time_limit=None, max_states=max_states)
+	n = int(t[f"{tag}_n"])
+	assert solved == bool(t[f"{tag}_solved"]) and len(agent) == n
+	assert int(agent._batch.status[0, 3]) == int(t[f"{tag}_sims"])
+	assert (agent.states[1:n + 1] == t[f"{tag}_states"]).all()
+	assert (agent.neighbors[1:n + 1] == t[f"{tag}_neighbors"]).all() and agent.neighbors.dtype == np.int64
+	assert (agent.leaves[1:n + 1] == t[f"{tag}_leaves"]).all()
+	assert (agent.N[1:n + 1] == t[f"{tag}_N"]).all()
+	assert (agent.W[1:n + 1] == t[f"{tag}_W"]).all() and agent.W.dtype == np.float64
+	assert (agent.L[1:n + 1] == t[f"{tag}_L"]).all()
+	assert (agent.V[1:n + 1] == t[f"{tag}_V"]).all()
+	assert list(agent.action_queue) == t[f"{tag}_action_queue"].tolist()
+	if solved:
+		s = start
+		for a in agent.action_queue:
+			s = cube.rotate(s, *cube.action_space[a])
+		assert cube.is_solved(s)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_batch_equals_oracle_per_tree(use_graph):
+	"""12 trees with different depths and budgets in one engine; each must equal the oracle run alone."""
+	T, c = 12, 5.0
+	starts, budgets = [], []
+	for i in range(T):
+		np.random.seed(200 + i)
+		s, _, _ = orc.scramble(2 + i % 5, True)
+		starts.append(s)
+		budgets.append(600 + 250 * i)
+	starts = np.array(starts)
+	starts[7] = orc.SOLVED                       # a start that is already solved (agents.py:468)
+	agent = MCTSBatch(StubNet(), c, T, capacity=4000)
+	solved = agent.search(starts, max_states=np.array(budgets), use_graph=use_graph, poll=32)
+	n_solved = 0
+	for i in range(T):
+		ref = MCTSOracle(StubNet(), c, False)
+		ref_solved = ref.search(starts[i], budgets[i])
+		assert bool(solved[i]) == ref_solved, i
+		assert list(agent.action_queue_of(i)) == list(ref.action_queue), i
+		if i != 7:
+			_same_tree(agent.tree_arrays(i), ref)
+			assert int(agent.status[i, 3]) == ref.sims
+		n_solved += ref_solved
+	assert 0 < n_solved <= T and solved[7]
+
+
+class TinyNet(torch.nn.Module):
+	def __init__(self):
+		super().__init__()
+		torch.manual_seed(1)
+		self.body = torch.nn.Sequential(torch.nn.Linear(480, 128), torch.nn.ELU(), torch.nn.Linear(128, 64), torch.nn.ELU())
+		self.p, self.v = torch.nn.Linear(64, 12), torch.nn.Linear(64, 1)
+
+	def forward(self, x, policy=True, value=True):
+		h = self.body(x)
+		out = ([self.p(h)] if policy else []) + ([self.v(h)] if value else [])
+		return out if len(out) > 1 else out[0]
+
+
+def test_real_net_invariants():
+	"""tests/test_agents.py:49-94 of the reference with a float net on the GPU."""
+	net = TinyNet().cuda().eval()
+	np.random.seed(4)
+	for depth, sg in ((50, False), (3, False), (3, True)):
+		state, _, _ = cube.scramble(depth)
+		agent = MCTS(net, c=1, search_graph=sg)
+		solved = agent.search(state, time_limit=None, max_states=3000)
+		idx = agent.indices
+		n = len(agent)
+		assert idx[state.tobytes()] == 1 and sorted(idx.values()) == list(range(1, n + 1))
+		assert (agent.states[1] == state).all()
+		used = np.arange(1, n + 1)
+		if not sg:
+			nb = agent.neighbors
+			for i in np.random.randint(1, n + 1, 200):
+				for j in range(12):
+					if nb[i, j]:
+						assert (agent.states[nb[i, j]] == orc.rotate(agent.states[i], j // 2, 1 - j % 2)).all()
+			assert (agent.neighbors[used].all(axis=1) != agent.leaves[used]).all()
+		with torch.no_grad():
+			p, v = net(cube.as_oh(agent.states[used]))
+		p, v = p.softmax(dim=1).cpu().numpy(), v.squeeze().cpu().numpy()
+		assert np.isclose(agent.P[used], p, atol=1e-5).all()
+		assert np.isclose(agent.V[used], v, atol=1e-5).all()
+		assert agent.W[used].all()
+		s = state
+		for a in agent.action_queue:
+			s = cube.rotate(s, *cube.action_space[a])
+		assert cube.is_solved(s) == solved
