@@ -1,0 +1,94 @@
+"""
+Per-kernel roofline sweep on one MI355X: every cube kernel on 1 M states (device-resident, back-to-back launches,
+HIP events on the launch stream), plus the PCIe-inclusive cost of the NumPy drop-in surface.
+
+    python benchmarks/kernels.py [--n 1000000] [--reps 100]
+
+Prints one JSON object per kernel: algorithmic bytes per state, time per launch, GB/s, fraction of the
+8 TB/s HBM peak.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from librubiks_amd import _ffi, cube  # noqa: E402
+
+PEAK = 8000.0
+
+
+def timed(fn, reps, warm=10):
+	for _ in range(warm):
+		fn()
+	e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+	torch.cuda.synchronize()
+	e0.record()
+	for _ in range(reps):
+		fn()
+	e1.record()
+	torch.cuda.synchronize()
+	return e0.elapsed_time(e1) / reps * 1e-3
+
+
+def main():
+	ap = argparse.ArgumentParser()
+	ap.add_argument("--n", type=int, default=1_000_000)
+	ap.add_argument("--reps", type=int, default=100)
+	args = ap.parse_args()
+	n = args.n
+	_ffi.check(_ffi.lib().rk_init(0))
+	g = torch.Generator(device="cuda")
+	g.manual_seed(1)
+	acts20 = torch.randint(0, 12, (20, n), device="cuda", dtype=torch.uint8, generator=g)
+	states = cube.device.apply_sequences(acts20, False, True)
+	acts = acts20[0].contiguous()
+	children = torch.empty((12 * n, 20), dtype=torch.int8, device="cuda")
+	solved = torch.empty(12 * n, dtype=torch.uint8, device="cuda")
+	out = torch.empty_like(states)
+	flags = torch.empty(n, dtype=torch.uint8, device="cuda")
+	n_oh = min(n, 500_000)
+	oh = torch.empty((n_oh, 480), dtype=torch.float32, device="cuda")
+	oh16 = torch.empty((n_oh, 480), dtype=torch.bfloat16, device="cuda")
+	a = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+	b = torch.empty_like(a)
+
+	rows = []
+
+	def report(name, bytes_per_launch, t, units, unit_name):
+		gbs = bytes_per_launch / t / 1e9
+		rows.append({"kernel": name, "ms": t * 1e3, "GB/s": round(gbs, 1), "frac_of_8TBs": round(gbs / PEAK, 4),
+		             "algorithmic_bytes": bytes_per_launch, f"{unit_name}/s": units / t})
+		print(json.dumps(rows[-1]), flush=True)
+
+	report("device copy 256 MiB (torch, reference point)", 2 * a.numel(), timed(lambda: b.copy_(a), 50), a.numel(), "bytes")
+	report("expand12 + goal test", 272 * n, timed(lambda: cube.device.expand12(states, children, solved), args.reps), n, "expansions")
+	report("expand12 without flags", 260 * n, timed(lambda: cube.device.expand12(states, children, want_flags=False), args.reps), n, "expansions")
+	report("multi_rotate (per-state action)", 41 * n, timed(lambda: cube.device.multi_rotate(states, acts, out), args.reps), n, "transitions")
+	report("multi_rotate on 12 M rows", 41 * 12 * n, timed(lambda: cube.device.multi_rotate(children, acts.repeat(12), children), 20), 12 * n, "transitions")
+	report("multi_is_solved", 21 * n, timed(lambda: cube.device.multi_is_solved(states, flags), args.reps), n, "states")
+	report("multi_is_solved on 12 M rows", 21 * 12 * n, timed(lambda: cube.device.multi_is_solved(children, solved), 50), 12 * n, "states")
+	report("as_oh f32", (20 + 1920) * n_oh, timed(lambda: cube.device.as_oh(states[:n_oh], oh), 50), n_oh, "states")
+	report("as_oh bf16", (20 + 960) * n_oh, timed(lambda: cube.device.as_oh(states[:n_oh], oh16, torch.bfloat16), 50), n_oh, "states")
+	report("apply_sequences depth 20 (last state only)", (20 + 20) * n, timed(lambda: cube.device.apply_sequences(acts20, False, True), 50), 20 * n, "transitions")
+
+	# PCIe-inclusive: the NumPy drop-in surface (host array in, host array out)
+	host = states.cpu().numpy()
+	t0 = time.perf_counter()
+	ch = cube.expand(host)
+	t_expand = time.perf_counter() - t0
+	f, d = np.random.randint(0, 6, n), np.random.randint(0, 2, n)
+	t0 = time.perf_counter()
+	cube.multi_rotate(host, f, d)
+	t_rot = time.perf_counter() - t0
+	print(json.dumps({"host_path": "cube.expand(numpy 1M) incl. H2D 20 MB + D2H 240 MB", "s": t_expand, "expansions/s": n / t_expand,
+	                  "multi_rotate(numpy 1M) s": t_rot, "transitions/s": n / t_rot}), flush=True)
+	del ch
+
+
+if __name__ == "__main__":
+	main()
