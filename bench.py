@@ -87,6 +87,14 @@ def pmc_traffic():
 		return None
 
 
+def max_over_ranks(elapsed: float, dist, device) -> float:
+	"""The slowest rank's time: what divides the whole job's units (weak scaling, no data-path collective)."""
+	t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+	if dist is not None:
+		dist.all_reduce(t, op=dist.ReduceOp.MAX)
+	return float(t.item())
+
+
 def main():
 	ap = argparse.ArgumentParser()
 	ap.add_argument("--gpus", type=int, default=1)
@@ -135,10 +143,7 @@ def main():
 	fence()
 	elapsed = time.perf_counter() - t0
 
-	t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-	if dist is not None:
-		dist.all_reduce(t, op=dist.ReduceOp.MAX)
-	elapsed_max = float(t.item())
+	elapsed_max = max_over_ranks(elapsed, dist, torch.device("cuda"))
 	kernel_ms = ev0.elapsed_time(ev1) / args.steps          # HIP events on the launch stream: back-to-back launches
 
 	# sanity of the timed work: the children of the last step are a real fan-out (spot check on the device)

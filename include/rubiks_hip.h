@@ -145,6 +145,30 @@ long long rk_astar_lookup(rk_astar_t *h, const int8_t *h_state, void *stream);
 /* The open queue in pop order: up to max_len (cost, index) pairs to HOST arrays; returns the count written. */
 long long rk_astar_export_open(rk_astar_t *h, double *h_costs, long long *h_indices, size_t max_len, void *stream);
 
+/* ---- hash-sharded A* across the GPUs of a node (BASELINE config 5; no counterpart in the reference) ------------
+ * One engine per GPU/rank holds the states it owns, owner(state) = rk_shard_owner(state, world).  The host drives
+ * one iteration as: pick the globally best N open nodes (all-gather of the queue heads) -> rk_astar_shard_pop
+ * (expand, bucket the 12 n children by owner as 32-byte records) -> all-to-all of the buckets (RCCL over xGMI) ->
+ * rk_astar_shard_insert on what was received (same membership / first-occurrence / append / relaxation-case-1
+ * semantics as rk_astar_expand+commit, in arrival order) -> net on the new states -> rk_astar_shard_push ->
+ * all-to-all of the 16-byte shortcut offers (relaxation case 2) -> rk_astar_shard_apply_shortcuts.
+ * With world = 1 this reproduces the single-GPU engine exactly.  librubiks_amd/solving/sharded.py is the driver. */
+int rk_astar_create_sharded(rk_astar_t **out, size_t capacity, int max_expansions, int rank, int world);
+int rk_shard_owner(const int8_t *h_state, int world);
+int rk_astar_shard_reset(rk_astar_t *h, const int8_t *h_start_state, double lambda, void *stream);
+/* Pops n_pop nodes, writes their 12 n_pop child records grouped by owner into d_send (32 B each) and the per-owner
+ * record counts into h_send_counts[world].  Synchronises. */
+int rk_astar_shard_pop(rk_astar_t *h, int n_pop, void *d_send, long long *h_send_counts, void *stream);
+/* Inserts n_recv received records (grouped by sending rank, each group in the sender's order).  Writes shortcut
+ * offers (16 B each, grouped by destination rank) to d_shortcuts_out and their per-rank counts to
+ * h_shortcut_counts[world]; h_info as rk_astar_expand.  Synchronises. */
+int rk_astar_shard_insert(rk_astar_t *h, const void *d_recv, long long n_recv, void *d_shortcuts_out,
+                          long long *h_shortcut_counts, long long *h_info, void *stream);
+int rk_astar_shard_push(rk_astar_t *h, const float *d_values, void *stream);
+int rk_astar_shard_apply_shortcuts(rk_astar_t *h, const void *d_shortcuts, long long n, void *stream);
+/* h_out = {parent rank, parent index, action} of node `index` on this rank (for the cross-rank path walk). */
+int rk_astar_shard_parent(rk_astar_t *h, long long index, long long *h_out, void *stream);
+
 /* ---- Monte Carlo tree search (agents.py:415-645): T independent trees, all state in HBM ----------------------
  * Replaces MCTS.expand_leaf / find_leaf for a whole batch of searches (the reference runs one tree at a time).
  * Per tree the engine owns the reference's arrays: states, neighbors (cap,12), leaves, P, V, N, W, L

@@ -53,6 +53,14 @@ SIGNATURES = {
 	"rk_astar_path": (C.c_longlong, [_vp, C.c_longlong, _vp, _sz, _vp]),
 	"rk_astar_lookup": (C.c_longlong, [_vp, _vp, _vp]),
 	"rk_astar_export_open": (C.c_longlong, [_vp, _vp, _vp, _sz, _vp]),
+	"rk_astar_create_sharded": (_i, [C.POINTER(_vp), _sz, _i, _i, _i]),
+	"rk_shard_owner": (_i, [_vp, _i]),
+	"rk_astar_shard_reset": (_i, [_vp, _vp, C.c_double, _vp]),
+	"rk_astar_shard_pop": (_i, [_vp, _i, _vp, _vp, _vp]),
+	"rk_astar_shard_insert": (_i, [_vp, _vp, C.c_longlong, _vp, _vp, _vp, _vp]),
+	"rk_astar_shard_push": (_i, [_vp, _vp, _vp]),
+	"rk_astar_shard_apply_shortcuts": (_i, [_vp, _vp, C.c_longlong, _vp]),
+	"rk_astar_shard_parent": (_i, [_vp, C.c_longlong, _vp, _vp]),
 	"rk_mcts_create": (_i, [C.POINTER(_vp), _i, _sz, _sz]),
 	"rk_mcts_destroy": (_i, [_vp]),
 	"rk_mcts_reset": (_i, [_vp, _vp, _vp, C.c_double, C.c_double, _vp]),

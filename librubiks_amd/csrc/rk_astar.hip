@@ -61,7 +61,7 @@ __host__ __device__ inline double key_to_double(uint64_t k)
 	return d;
 }
 
-__device__ __forceinline__ uint32_t hash_state(const uint32_t s[5])
+__host__ __device__ inline uint32_t hash_state(const uint32_t s[5])
 {
 	uint64_t h = 0x9E3779B97F4A7C15ull;
 	#pragma unroll
@@ -71,6 +71,13 @@ __device__ __forceinline__ uint32_t hash_state(const uint32_t s[5])
 		h ^= h >> 29;
 	}
 	return (uint32_t)(h ^ (h >> 32));
+}
+
+// owner rank of a state in a hash-sharded search: a remix of the hash, so that it is independent of the table slot
+__host__ __device__ inline uint32_t owner_of(const uint32_t s[5], uint32_t world)
+{
+	const uint32_t h = hash_state(s) * 0x9E3779B1u;
+	return (uint32_t)(((uint64_t)h * world) >> 32);
 }
 
 __device__ __forceinline__ void load5(const uint32_t *p, uint32_t s[5])
@@ -110,13 +117,14 @@ __global__ void k_astar_pop(const Rec *open, int n_pop, const uint32_t *states, 
 }
 
 // membership test + in-batch first-occurrence election through the hash table                    agents.py:286-295
-__global__ void k_astar_lookup(const uint32_t *children, int K, const uint32_t *states, uint32_t *table, uint32_t mask,
+// `stride` = dwords between consecutive child states: 5 for a plain (K,20) array, 8 for 32-byte exchange records
+__global__ void k_astar_lookup(const uint32_t *children, int stride, int K, const uint32_t *states, uint32_t *table, uint32_t mask,
                                uint32_t *mark, int32_t *seen, uint32_t *child_slot)
 {
 	const int c = blockIdx.x * blockDim.x + threadIdx.x;
 	if (c >= K) return;
 	uint32_t s[5];
-	load5(children + (size_t)c * 5, s);
+	load5(children + (size_t)c * stride, s);
 	uint32_t slot = hash_state(s) & mask;
 	for (;;) {
 		uint32_t e = __atomic_load_n(&table[slot], __ATOMIC_RELAXED);
@@ -125,7 +133,7 @@ __global__ void k_astar_lookup(const uint32_t *children, int K, const uint32_t *
 			if (e == 0u) { seen[c] = 0; child_slot[c] = slot; return; }
 		}
 		if (e & TENT) {
-			if (equal5(s, children + (size_t)(e & ~TENT) * 5)) {
+			if (equal5(s, children + (size_t)(e & ~TENT) * stride)) {
 				atomicMin(&table[slot], TENT | (uint32_t)c);          // all claimants hold the same state: smallest position wins
 				seen[c] = 0; child_slot[c] = slot;
 				return;
@@ -178,29 +186,49 @@ void k_astar_flags_scan(int K, const uint32_t *table, const uint32_t *mark, cons
 }
 
 // append the new states (agents.py:299-313), finalise their hash slots, goal test of the new states
-// (agents.py:321-323) and the read half of relaxation case 1 (agents.py:354)
+// (agents.py:321-323) and the read half of relaxation case 1 (agents.py:354).
+// SHARDED = false: children is a (K,20) array, the parent of child c is exp_idx[c/12], its action c%12.
+// SHARDED = true : children are 32-byte records {state[5], parent_idx, g | action<<16 | parent_rank<<24, pad}
+//                  received from the ranks that expanded them; the parent lives on rank parent_rank.
+template <bool SHARDED>
 __global__ void k_astar_append(const uint32_t *children, const uint8_t *solved, int K, const uint8_t *flags, const int32_t *rank,
                                const int32_t *seen, const uint32_t *child_slot, const int32_t *exp_idx, uint32_t n_before,
-                               uint32_t *states, int32_t *G, int32_t *parents, uint8_t *pact, uint32_t *table,
+                               uint32_t *states, int32_t *G, int32_t *parents, uint8_t *pact, uint8_t *prank, uint32_t *table,
                                uint8_t *newway, int32_t *val1, long long *counters)
 {
 	const int c = blockIdx.x * blockDim.x + threadIdx.x;
 	if (c >= K) return;
+	constexpr int STRIDE = SHARDED ? 8 : 5;
 	const uint8_t f = flags[c];
-	const int32_t p = exp_idx[c / 12];
+	const uint32_t *cs = children + (size_t)c * STRIDE;
+	int32_t p, g;
+	uint8_t act, pr = 0;
+	if (SHARDED) {
+		p = (int32_t)cs[5];
+		g = (int32_t)(cs[6] & 0xFFFFu);
+		act = (uint8_t)((cs[6] >> 16) & 0xFFu);
+		pr = (uint8_t)(cs[6] >> 24);
+	} else {
+		p = exp_idx[c / 12];
+		g = G[p] + 1;
+		act = (uint8_t)(c % 12);
+	}
 	if (f & 1) {
 		const uint32_t idx = n_before + 1u + (uint32_t)rank[c];
+		uint32_t s[5];
+		load5(cs, s);
 		#pragma unroll
-		for (int j = 0; j < 5; j++) states[(size_t)idx * 5 + j] = children[(size_t)c * 5 + j];
-		G[idx] = G[p] + 1;
+		for (int j = 0; j < 5; j++) states[(size_t)idx * 5 + j] = s[j];
+		G[idx] = g;
 		parents[idx] = p;
-		pact[idx] = (uint8_t)(c % 12);
+		pact[idx] = act;
+		prank[idx] = pr;
 		table[child_slot[c]] = idx;
-		if (solved[c]) { counters[CTR_WON] = 1; counters[CTR_SOLVED_IDX] = idx; }
+		const bool is_goal = SHARDED ? is_solved5(s) : (solved[c] != 0);
+		if (is_goal) { counters[CTR_WON] = 1; counters[CTR_SOLVED_IDX] = idx; }
 	}
 	uint8_t nw = 0;
 	if (f & 2) {
-		const int32_t g = G[p] + 1;
 		nw = g < G[seen[c]];
 		val1[c] = g;
 	}
@@ -277,15 +305,24 @@ __global__ void k_merge_two(const Rec *a, int na, const Rec *b, int nb, Rec *out
 }
 
 // relaxation, case 1 write half (agents.py:357-359)
+template <bool SHARDED>
 __global__ void k_relax_1b(int K, const uint8_t *newway, const int32_t *val1, const int32_t *seen, const int32_t *exp_idx,
-                           int32_t *G, int32_t *parents, uint8_t *pact)
+                           const uint32_t *recs, int32_t *G, int32_t *parents, uint8_t *pact, uint8_t *prank, const long long *counters)
 {
 	const int c = blockIdx.x * blockDim.x + threadIdx.x;
 	if (c >= K || !newway[c]) return;
+	if (SHARDED && counters[CTR_WON]) return;       // the reference returns before relaxing once it has won (agents.py:321-323)
 	const int32_t s = seen[c];
 	G[s] = val1[c];
-	pact[s] = (uint8_t)(c % 12);
-	parents[s] = exp_idx[c / 12];
+	if (SHARDED) {
+		const uint32_t *r = recs + (size_t)c * 8;
+		pact[s] = (uint8_t)((r[6] >> 16) & 0xFFu);
+		parents[s] = (int32_t)r[5];
+		prank[s] = (uint8_t)(r[6] >> 24);
+	} else {
+		pact[s] = (uint8_t)(c % 12);
+		parents[s] = exp_idx[c / 12];
+	}
 }
 
 // case 2 read half (agents.py:362); also clears the marks this batch set
@@ -323,6 +360,147 @@ __global__ void k_relax_2b(int n_pop, const uint8_t *shortcut, const int32_t *va
 	}
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Hash-sharded search (one engine per GPU, owner(state) = owner_of(state, world)).  Per iteration a rank expands its
+// share of the globally best nodes, buckets the 12 n children by owner (stable: batch order inside a bucket), the
+// host exchanges the buckets (all-to-all), and every owner inserts what it received with exactly the single-GPU
+// semantics above.  Relaxation case 2 (a seen child offers its parent a shortcut) becomes a second, small exchange
+// of 16-byte records back to the parent's owner.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_shard_records(const uint32_t *children, int K, const int32_t *exp_idx, const int32_t *G, uint32_t my_rank,
+                                uint32_t world, uint32_t *recs, uint8_t *owner)
+{
+	const int c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= K) return;
+	uint32_t s[5];
+	load5(children + (size_t)c * 5, s);
+	const int32_t p = exp_idx[c / 12];
+	uint32_t *r = recs + (size_t)c * 8;
+	#pragma unroll
+	for (int j = 0; j < 5; j++) r[j] = s[j];
+	r[5] = (uint32_t)p;
+	r[6] = ((uint32_t)(G[p] + 1) & 0xFFFFu) | ((uint32_t)(c % 12) << 16) | (my_rank << 24);
+	r[7] = (uint32_t)c;
+	owner[c] = (uint8_t)owner_of(s, world);
+}
+
+// stable partition of the K records by owner into `send`; counts[w] = records for rank w.  One workgroup.
+__global__ __launch_bounds__(1024)
+void k_shard_bucket(int K, uint32_t world, const uint32_t *recs, const uint8_t *owner, u32x4 *send, long long *counts)
+{
+	__shared__ int s_wave[16];
+	__shared__ int s_base;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	if (tid == 0) s_base = 0;
+	__syncthreads();
+	const u32x4 *src = reinterpret_cast<const u32x4 *>(recs);
+	for (uint32_t w = 0; w < world; w++) {
+		const int start = s_base;
+		for (int c0 = 0; c0 < K; c0 += 1024) {
+			const int c = c0 + tid;
+			const bool mine = c < K && owner[c] == w;
+			const unsigned long long b = __ballot(mine);
+			const int in_wave = __popcll(b & ((1ull << lane) - 1ull));
+			if (lane == 0) s_wave[wv] = __popcll(b);
+			__syncthreads();
+			int before = s_base;
+			for (int k = 0; k < wv; k++) before += s_wave[k];
+			if (mine) {
+				send[2 * (size_t)(before + in_wave)] = src[2 * (size_t)c];
+				send[2 * (size_t)(before + in_wave) + 1] = src[2 * (size_t)c + 1];
+			}
+			__syncthreads();
+			if (tid == 0) {
+				int tot = 0;
+				for (int k = 0; k < 16; k++) tot += s_wave[k];
+				s_base += tot;
+			}
+			__syncthreads();
+		}
+		if (tid == 0) counts[w] = s_base - start;
+		__syncthreads();
+	}
+}
+
+// receiver side of relaxation case 2: a first-seen child whose own G is at least two below its would-be parent's
+// offers the parent a shortcut.  Candidates keep receive order (= grouped by the rank that sent the child).
+// Shortcut record (16 B): {parent_idx, new G for the parent, index of the child on this rank, this rank | rev(action) << 8}
+__global__ __launch_bounds__(1024)
+void k_shard_shortcuts(int K, const uint8_t *flags, const int32_t *seen, const uint32_t *recs, const int32_t *G, uint32_t my_rank,
+                       uint32_t *mark, u32x4 *out, long long *counts)
+{
+	__shared__ int s_wave[16];
+	__shared__ int s_base;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	if (tid == 0) s_base = 0;
+	__syncthreads();
+	for (int c0 = 0; c0 < K; c0 += 1024) {
+		const int c = c0 + tid;
+		bool cand = false;
+		u32x4 rec = {0u, 0u, 0u, 0u};
+		uint32_t dst = 0;
+		if (c < K && (flags[c] & 2)) {
+			const uint32_t *r = recs + (size_t)c * 8;
+			const int32_t s = seen[c];
+			const int32_t g_parent = (int32_t)(r[6] & 0xFFFFu) - 1;
+			const int32_t g_new = G[s] + 1;
+			cand = g_new < g_parent;
+			dst = r[6] >> 24;
+			rec = u32x4{r[5], (uint32_t)g_new, (uint32_t)s, my_rank | ((((r[6] >> 16) & 0xFFu) ^ 1u) << 8)};
+			mark[s] = NO_MARK;
+		}
+		const unsigned long long b = __ballot(cand);
+		const int in_wave = __popcll(b & ((1ull << lane) - 1ull));
+		if (lane == 0) s_wave[wv] = __popcll(b);
+		__syncthreads();
+		int before = s_base;
+		for (int k = 0; k < wv; k++) before += s_wave[k];
+		if (cand) {
+			out[before + in_wave] = rec;
+			atomicAdd(reinterpret_cast<unsigned long long *>(&counts[dst]), 1ull);
+		}
+		__syncthreads();
+		if (tid == 0) {
+			int tot = 0;
+			for (int k = 0; k < 16; k++) tot += s_wave[k];
+			s_base += tot;
+		}
+		__syncthreads();
+	}
+}
+
+// parent side of case 2 (agents.py:362-367): evaluate every offer against G as it stands, then let the LAST hit per
+// parent (in arrival order) win -- what NumPy's fancy assignment with repeated indices does.
+__global__ void k_shard_shortcut_eval(const u32x4 *recs, int n, const int32_t *G, uint32_t *mark, uint8_t *hit)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const u32x4 r = recs[i];
+	const bool h = (int32_t)r.y < G[r.x];
+	hit[i] = h;
+	if (h) atomicMin(&mark[r.x], ~(uint32_t)i);
+}
+
+__global__ void k_shard_shortcut_apply(const u32x4 *recs, int n, const uint8_t *hit, int32_t *G, int32_t *parents, uint8_t *pact,
+                                       uint8_t *prank, uint32_t *mark)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n || !hit[i]) return;
+	const u32x4 r = recs[i];
+	if (mark[r.x] != ~(uint32_t)i) return;
+	G[r.x] = (int32_t)r.y;
+	parents[r.x] = (int32_t)r.z;
+	prank[r.x] = (uint8_t)(r.w & 0xFFu);
+	pact[r.x] = (uint8_t)((r.w >> 8) & 0xFFu);
+}
+
+__global__ void k_shard_shortcut_clear(const u32x4 *recs, int n, uint32_t *mark)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) mark[recs[i].x] = NO_MARK;
+}
+
 __global__ void k_astar_find(const uint32_t *query, const uint32_t *states, const uint32_t *table, uint32_t mask, long long *out)
 {
 	if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -347,17 +525,24 @@ struct rk_astar {
 	uint32_t mask = 0;
 	double lambda = 0.0;
 	// node pool
-	uint32_t *states = nullptr; int32_t *G = nullptr, *parents = nullptr; uint8_t *pact = nullptr;
+	uint32_t *states = nullptr; int32_t *G = nullptr, *parents = nullptr; uint8_t *pact = nullptr, *prank = nullptr;
 	uint32_t *table = nullptr, *mark = nullptr;
 	Rec *open[2] = {nullptr, nullptr};
 	int cur = 0;
 	// per-iteration scratch, K = 12 * max_exp
 	int32_t *exp_idx = nullptr; uint32_t *par_states = nullptr, *children = nullptr; uint8_t *solved = nullptr;
-	int32_t *seen = nullptr; uint32_t *child_slot = nullptr; uint8_t *flags = nullptr; int32_t *rank = nullptr;
+	int32_t *seen = nullptr; uint32_t *child_slot = nullptr; uint8_t *flags = nullptr; int32_t *rank_ = nullptr;
 	uint8_t *newway = nullptr, *shortcut = nullptr; int32_t *val1 = nullptr, *val2 = nullptr;
 	Rec *newrec[2] = {nullptr, nullptr};
 	long long *counters = nullptr;
 	uint32_t *root_dev = nullptr;
+	// hash-sharded mode
+	int rank = 0, world = 1;
+	size_t k_in = 0;              // capacity (records) of the per-iteration scratch: 12 * max_exp * world
+	uint32_t *recs = nullptr; uint8_t *owner = nullptr, *hit = nullptr;
+	long long *dev_counts = nullptr;
+	const uint32_t *pending_recs = nullptr;   // received records of the pending insert (caller memory)
+	int n_in = 0;
 	// host mirrors
 	size_t n_states = 0, open_len = 0;
 	size_t n_before = 0;          // n_states before the pending expand
@@ -384,30 +569,46 @@ inline unsigned blocks(size_t n, unsigned per = 256) { return (unsigned)((n + pe
 
 extern "C" {
 
-int rk_astar_create(rk_astar_t **out, size_t capacity, int max_expansions)
+static int astar_create_impl(rk_astar_t **out, size_t capacity, int max_expansions, int rank, int world)
 {
 	if (!out) return fail(RK_EINVAL, "rk_astar_create: null out pointer");
 	if (capacity < 2 || capacity > 0x3FFFFFF0ull) return fail(RK_EINVAL, "rk_astar_create: capacity %zu out of range", capacity);
 	if (max_expansions < 1 || max_expansions > (1 << 24)) return fail(RK_EINVAL, "rk_astar_create: max_expansions %d out of range", max_expansions);
+	if (world < 1 || world > 255 || rank < 0 || rank >= world) return fail(RK_EINVAL, "rk_astar_create: rank %d / world %d out of range", rank, world);
 	rk_astar *h = new rk_astar();
 	h->cap = capacity;
 	h->max_exp = max_expansions;
+	h->rank = rank;
+	h->world = world;
 	uint64_t t = 1024;
 	while (t < 2 * (uint64_t)capacity + 2) t <<= 1;
 	h->mask = (uint32_t)(t - 1);
 	const size_t K = 12 * (size_t)max_expansions, C1 = capacity + 1;
+	const size_t KI = K * (size_t)world;          // a rank can receive every rank's children
+	h->k_in = KI;
 	int e = RK_OK;
 	#define A(ptr, cnt) if (!e) e = dev_alloc(h, &h->ptr, (cnt))
-	A(states, C1 * 5); A(G, C1); A(parents, C1); A(pact, C1); A(table, (size_t)t); A(mark, C1);
+	A(states, C1 * 5); A(G, C1); A(parents, C1); A(pact, C1); A(prank, C1); A(table, (size_t)t); A(mark, C1);
 	A(open[0], C1); A(open[1], C1);
 	A(exp_idx, (size_t)max_expansions); A(par_states, (size_t)max_expansions * 5); A(children, K * 5 + 64); A(solved, K + 64);
-	A(seen, K); A(child_slot, K); A(flags, K); A(rank, K); A(newway, K); A(shortcut, K); A(val1, K); A(val2, K);
-	A(newrec[0], K + 1024); A(newrec[1], K + 1024);
+	A(seen, KI); A(child_slot, KI); A(flags, KI); A(rank_, KI); A(newway, KI); A(shortcut, KI); A(val1, KI); A(val2, KI);
+	A(newrec[0], KI + 1024); A(newrec[1], KI + 1024);
 	A(counters, CTR_COUNT); A(root_dev, 8);
+	if (world > 1 || true) { A(recs, K * 8 + 64); A(owner, K + 64); A(hit, KI + 64); A(dev_counts, 256); }
 	#undef A
 	if (e) { rk_astar_destroy(h); return e; }
 	*out = h;
 	return RK_OK;
+}
+
+int rk_astar_create(rk_astar_t **out, size_t capacity, int max_expansions)
+{
+	return astar_create_impl(out, capacity, max_expansions, 0, 1);
+}
+
+int rk_astar_create_sharded(rk_astar_t **out, size_t capacity, int max_expansions, int rank, int world)
+{
+	return astar_create_impl(out, capacity, max_expansions, rank, world);
 }
 
 int rk_astar_destroy(rk_astar_t *h)
@@ -456,10 +657,10 @@ int rk_astar_expand(rk_astar_t *h, int n_expand, long long *h_info, void *stream
 		RK_HIP(hipMemsetAsync(h->counters, 0, CTR_COUNT * sizeof(long long), st));
 		hipLaunchKernelGGL(k_astar_pop, dim3(blocks((size_t)n_pop * 5)), dim3(256), 0, st, h->open[h->cur], n_pop, h->states, h->exp_idx, h->par_states);
 		launch_expand12((const int8_t *)h->par_states, (int8_t *)h->children, h->solved, nullptr, (size_t)n_pop, st);
-		hipLaunchKernelGGL(k_astar_lookup, dim3(blocks(K)), dim3(256), 0, st, h->children, K, h->states, h->table, h->mask, h->mark, h->seen, h->child_slot);
-		hipLaunchKernelGGL(k_astar_flags_scan, dim3(1), dim3(1024), 0, st, K, h->table, h->mark, h->seen, h->child_slot, h->flags, h->rank, h->counters);
-		hipLaunchKernelGGL(k_astar_append, dim3(blocks(K)), dim3(256), 0, st, h->children, h->solved, K, h->flags, h->rank, h->seen, h->child_slot,
-		                   h->exp_idx, (uint32_t)h->n_before, h->states, h->G, h->parents, h->pact, h->table, h->newway, h->val1, h->counters);
+		hipLaunchKernelGGL(k_astar_lookup, dim3(blocks(K)), dim3(256), 0, st, h->children, 5, K, h->states, h->table, h->mask, h->mark, h->seen, h->child_slot);
+		hipLaunchKernelGGL(k_astar_flags_scan, dim3(1), dim3(1024), 0, st, K, h->table, h->mark, h->seen, h->child_slot, h->flags, h->rank_, h->counters);
+		hipLaunchKernelGGL(k_astar_append<false>, dim3(blocks(K)), dim3(256), 0, st, h->children, h->solved, K, h->flags, h->rank_, h->seen, h->child_slot,
+		                   h->exp_idx, (uint32_t)h->n_before, h->states, h->G, h->parents, h->pact, h->prank, h->table, h->newway, h->val1, h->counters);
 		RK_HIP(hipGetLastError());
 		RK_HIP(hipMemcpyAsync(ctr, h->counters, sizeof ctr, hipMemcpyDeviceToHost, st));
 		RK_HIP(hipStreamSynchronize(st));
@@ -478,12 +679,10 @@ int rk_astar_new_states_oh(rk_astar_t *h, void *d_out, int out_dtype, void *stre
 	return rk_as_oh(RK_REPR_2024, (const int8_t *)(h->states + (h->n_before + 1) * 5), d_out, out_dtype, (size_t)h->n_new, stream);
 }
 
-int rk_astar_commit(rk_astar_t *h, const float *d_values, void *stream)
+// cost of the pending new states, sort, merge into the open queue (agents.py:315-317); n_pop entries leave the head
+static int astar_push(rk_astar_t *h, const float *d_values, hipStream_t st)
 {
-	if (!h || !h->pending) return fail(RK_ESTATE, "rk_astar_commit: no pending expansion");
-	if (h->n_new > 0 && !d_values) return fail(RK_EINVAL, "rk_astar_commit: null values");
-	hipStream_t st = (hipStream_t)stream;
-	const int n_new = h->n_new, n_pop = h->n_pop, K = 12 * n_pop;
+	const int n_new = h->n_new, n_pop = h->n_pop;
 	Rec *sorted_new = h->newrec[0];
 	if (n_new > 0) {
 		hipLaunchKernelGGL(k_astar_records, dim3(blocks(n_new)), dim3(256), 0, st, d_values, n_new, (uint32_t)h->n_before, h->G, h->lambda, h->newrec[0]);
@@ -495,19 +694,159 @@ int rk_astar_commit(rk_astar_t *h, const float *d_values, void *stream)
 		}
 		sorted_new = h->newrec[src];
 	}
-	// push: merge what is left of the queue with the new records                                agents.py:316-317
 	const int n_left = (int)(h->open_len - (size_t)n_pop);
 	if (n_left + n_new > 0)
 		hipLaunchKernelGGL(k_merge_two, dim3(blocks((size_t)n_left + n_new)), dim3(256), 0, st, h->open[h->cur] + n_pop, n_left, sorted_new, n_new, h->open[h->cur ^ 1]);
 	h->cur ^= 1;
 	h->open_len = (size_t)n_left + (size_t)n_new;
+	RK_HIP(hipGetLastError());
+	return RK_OK;
+}
+
+int rk_astar_commit(rk_astar_t *h, const float *d_values, void *stream)
+{
+	if (!h || !h->pending) return fail(RK_ESTATE, "rk_astar_commit: no pending expansion");
+	if (h->world != 1) return fail(RK_ESTATE, "rk_astar_commit: sharded engines use rk_astar_shard_push");
+	if (h->n_new > 0 && !d_values) return fail(RK_EINVAL, "rk_astar_commit: null values");
+	hipStream_t st = (hipStream_t)stream;
+	const int n_pop = h->n_pop, K = 12 * n_pop;
+	if (int e = astar_push(h, d_values, st)) return e;
 	if (K > 0) {
-		hipLaunchKernelGGL(k_relax_1b, dim3(blocks(K)), dim3(256), 0, st, K, h->newway, h->val1, h->seen, h->exp_idx, h->G, h->parents, h->pact);
+		hipLaunchKernelGGL(k_relax_1b<false>, dim3(blocks(K)), dim3(256), 0, st, K, h->newway, h->val1, h->seen, h->exp_idx, (const uint32_t *)nullptr,
+		                   h->G, h->parents, h->pact, h->prank, h->counters);
 		hipLaunchKernelGGL(k_relax_2a, dim3(blocks(K)), dim3(256), 0, st, K, h->flags, h->seen, h->exp_idx, h->G, h->mark, h->shortcut, h->val2);
 		hipLaunchKernelGGL(k_relax_2b, dim3(blocks(n_pop)), dim3(256), 0, st, n_pop, h->shortcut, h->val2, h->seen, h->exp_idx, h->G, h->parents, h->pact);
 	}
 	RK_HIP(hipGetLastError());
 	h->pending = false;
+	return RK_OK;
+}
+
+// ---- hash-sharded mode ---------------------------------------------------------------------------------------------
+
+int rk_shard_owner(const int8_t *h_state, int world)
+{
+	if (!h_state || world < 1) return fail(RK_EINVAL, "rk_shard_owner: bad argument");
+	uint32_t s[5];
+	memcpy(s, h_state, STATE_BYTES);
+	return (int)owner_of(s, (uint32_t)world);
+}
+
+int rk_astar_shard_reset(rk_astar_t *h, const int8_t *h_start_state, double lambda, void *stream)
+{
+	if (!h || !h_start_state) return fail(RK_EINVAL, "rk_astar_shard_reset: null argument");
+	if (int e = rk_astar_reset(h, h_start_state, lambda, stream)) return e;
+	if (rk_shard_owner(h_start_state, h->world) != h->rank) {
+		// not the root's owner: start empty (the root record written by reset is dropped again)
+		hipStream_t st = (hipStream_t)stream;
+		RK_HIP(hipMemsetAsync(h->table, 0, ((size_t)h->mask + 1) * sizeof(uint32_t), st));
+		RK_HIP(hipStreamSynchronize(st));
+		h->n_states = 0;
+		h->open_len = 0;
+	}
+	h->pending = false;
+	return RK_OK;
+}
+
+int rk_astar_shard_pop(rk_astar_t *h, int n_pop, void *d_send, long long *h_send_counts, void *stream)
+{
+	if (!h || !h_send_counts) return fail(RK_EINVAL, "rk_astar_shard_pop: null argument");
+	if (h->pending) return fail(RK_ESTATE, "rk_astar_shard_pop: previous iteration not finished");
+	if (n_pop < 0 || n_pop > h->max_exp || (size_t)n_pop > h->open_len) return fail(RK_EINVAL, "rk_astar_shard_pop: n_pop %d out of range", n_pop);
+	hipStream_t st = (hipStream_t)stream;
+	for (int w = 0; w < h->world; w++) h_send_counts[w] = 0;
+	h->n_pop = n_pop;
+	const int K = 12 * n_pop;
+	if (K > 0) {
+		if (!d_send) return fail(RK_EINVAL, "rk_astar_shard_pop: null send buffer");
+		RK_HIP(hipMemsetAsync(h->dev_counts, 0, 256 * sizeof(long long), st));
+		hipLaunchKernelGGL(k_astar_pop, dim3(blocks((size_t)n_pop * 5)), dim3(256), 0, st, h->open[h->cur], n_pop, h->states, h->exp_idx, h->par_states);
+		launch_expand12((const int8_t *)h->par_states, (int8_t *)h->children, nullptr, nullptr, (size_t)n_pop, st);
+		hipLaunchKernelGGL(k_shard_records, dim3(blocks(K)), dim3(256), 0, st, h->children, K, h->exp_idx, h->G, (uint32_t)h->rank, (uint32_t)h->world, h->recs, h->owner);
+		hipLaunchKernelGGL(k_shard_bucket, dim3(1), dim3(1024), 0, st, K, (uint32_t)h->world, h->recs, h->owner, (u32x4 *)d_send, h->dev_counts);
+		RK_HIP(hipGetLastError());
+		RK_HIP(hipMemcpyAsync(h_send_counts, h->dev_counts, (size_t)h->world * sizeof(long long), hipMemcpyDeviceToHost, st));
+		RK_HIP(hipStreamSynchronize(st));
+	}
+	return RK_OK;
+}
+
+int rk_astar_shard_insert(rk_astar_t *h, const void *d_recv, long long n_recv, void *d_shortcuts_out, long long *h_shortcut_counts,
+                          long long *h_info, void *stream)
+{
+	if (!h || !h_info || !h_shortcut_counts) return fail(RK_EINVAL, "rk_astar_shard_insert: null argument");
+	if (h->pending) return fail(RK_ESTATE, "rk_astar_shard_insert: previous iteration not finished");
+	if (n_recv < 0 || (size_t)n_recv > h->k_in) return fail(RK_ECAPACITY, "rk_astar_shard_insert: %lld records exceed the scratch capacity %zu", n_recv, h->k_in);
+	if (h->n_states + (size_t)n_recv > h->cap) return fail(RK_ECAPACITY, "rk_astar_shard_insert: %zu states + %lld records exceed capacity %zu", h->n_states, n_recv, h->cap);
+	hipStream_t st = (hipStream_t)stream;
+	const int K = (int)n_recv;
+	h->n_before = h->n_states;
+	h->n_in = K;
+	h->pending_recs = (const uint32_t *)d_recv;
+	long long ctr[CTR_COUNT] = {0, 0, 0, 0};
+	for (int w = 0; w < h->world; w++) h_shortcut_counts[w] = 0;
+	if (K > 0) {
+		if (!d_recv || !d_shortcuts_out) return fail(RK_EINVAL, "rk_astar_shard_insert: null buffer");
+		const uint32_t *recs = (const uint32_t *)d_recv;
+		RK_HIP(hipMemsetAsync(h->counters, 0, CTR_COUNT * sizeof(long long), st));
+		RK_HIP(hipMemsetAsync(h->dev_counts, 0, 256 * sizeof(long long), st));
+		hipLaunchKernelGGL(k_astar_lookup, dim3(blocks(K)), dim3(256), 0, st, recs, 8, K, h->states, h->table, h->mask, h->mark, h->seen, h->child_slot);
+		hipLaunchKernelGGL(k_astar_flags_scan, dim3(1), dim3(1024), 0, st, K, h->table, h->mark, h->seen, h->child_slot, h->flags, h->rank_, h->counters);
+		hipLaunchKernelGGL(k_astar_append<true>, dim3(blocks(K)), dim3(256), 0, st, recs, (const uint8_t *)nullptr, K, h->flags, h->rank_, h->seen, h->child_slot,
+		                   (const int32_t *)nullptr, (uint32_t)h->n_before, h->states, h->G, h->parents, h->pact, h->prank, h->table, h->newway, h->val1, h->counters);
+		hipLaunchKernelGGL(k_relax_1b<true>, dim3(blocks(K)), dim3(256), 0, st, K, h->newway, h->val1, h->seen, (const int32_t *)nullptr, recs,
+		                   h->G, h->parents, h->pact, h->prank, h->counters);
+		hipLaunchKernelGGL(k_shard_shortcuts, dim3(1), dim3(1024), 0, st, K, h->flags, h->seen, recs, h->G, (uint32_t)h->rank, h->mark,
+		                   (u32x4 *)d_shortcuts_out, h->dev_counts);
+		RK_HIP(hipGetLastError());
+		RK_HIP(hipMemcpyAsync(ctr, h->counters, sizeof ctr, hipMemcpyDeviceToHost, st));
+		RK_HIP(hipMemcpyAsync(h_shortcut_counts, h->dev_counts, (size_t)h->world * sizeof(long long), hipMemcpyDeviceToHost, st));
+		RK_HIP(hipStreamSynchronize(st));
+	}
+	h->n_new = (int)ctr[CTR_NEW];
+	h->n_states = h->n_before + (size_t)h->n_new;
+	h->pending = true;
+	h_info[0] = h->n_pop; h_info[1] = h->n_new; h_info[2] = ctr[CTR_WON]; h_info[3] = ctr[CTR_SOLVED_IDX]; h_info[4] = (long long)h->n_states;
+	return RK_OK;
+}
+
+int rk_astar_shard_push(rk_astar_t *h, const float *d_values, void *stream)
+{
+	if (!h || !h->pending) return fail(RK_ESTATE, "rk_astar_shard_push: no pending insert");
+	if (h->n_new > 0 && !d_values) return fail(RK_EINVAL, "rk_astar_shard_push: null values");
+	if (int e = astar_push(h, d_values, (hipStream_t)stream)) return e;
+	h->pending = false;
+	h->n_pop = 0;
+	return RK_OK;
+}
+
+int rk_astar_shard_apply_shortcuts(rk_astar_t *h, const void *d_shortcuts, long long n, void *stream)
+{
+	if (!h) return fail(RK_EINVAL, "rk_astar_shard_apply_shortcuts: null handle");
+	if (n == 0) return RK_OK;
+	if (n < 0 || (size_t)n > h->k_in || !d_shortcuts) return fail(RK_EINVAL, "rk_astar_shard_apply_shortcuts: bad record count %lld", n);
+	hipStream_t st = (hipStream_t)stream;
+	const u32x4 *r = (const u32x4 *)d_shortcuts;
+	hipLaunchKernelGGL(k_shard_shortcut_eval, dim3(blocks((size_t)n)), dim3(256), 0, st, r, (int)n, h->G, h->mark, h->hit);
+	hipLaunchKernelGGL(k_shard_shortcut_apply, dim3(blocks((size_t)n)), dim3(256), 0, st, r, (int)n, h->hit, h->G, h->parents, h->pact, h->prank, h->mark);
+	hipLaunchKernelGGL(k_shard_shortcut_clear, dim3(blocks((size_t)n)), dim3(256), 0, st, r, (int)n, h->mark);
+	RK_HIP(hipGetLastError());
+	return RK_OK;
+}
+
+/* One hop of a cross-rank parent walk: (parent rank, parent index, action) of node `index` on this rank. */
+int rk_astar_shard_parent(rk_astar_t *h, long long index, long long *h_out /* [3] */, void *stream)
+{
+	if (!h || !h_out) return fail(RK_EINVAL, "rk_astar_shard_parent: null argument");
+	if (index < 1 || (size_t)index > h->n_states) return fail(RK_EINVAL, "rk_astar_shard_parent: index %lld outside 1..%zu", index, h->n_states);
+	hipStream_t st = (hipStream_t)stream;
+	int32_t p = 0;
+	uint8_t a = 0, r = 0;
+	RK_HIP(hipMemcpyAsync(&p, h->parents + index, sizeof p, hipMemcpyDeviceToHost, st));
+	RK_HIP(hipMemcpyAsync(&a, h->pact + index, 1, hipMemcpyDeviceToHost, st));
+	RK_HIP(hipMemcpyAsync(&r, h->prank + index, 1, hipMemcpyDeviceToHost, st));
+	RK_HIP(hipStreamSynchronize(st));
+	h_out[0] = r; h_out[1] = p; h_out[2] = a;
 	return RK_OK;
 }
 

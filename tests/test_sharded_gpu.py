@@ -1,0 +1,125 @@
+"""
+GPU tests of the hash-sharded A* (librubiks_amd/solving/sharded.py, rk_astar_shard_*).
+  * world = 1 (no process group): the sharded code path -- records, bucketing, insert in arrival order, shortcut
+    offers -- must reproduce the reference traces and the single-GPU engine exactly;
+  * world = 2 and 3: several ranks share the one GPU of the test box and exchange through gloo (host-staged):
+    every rank reports the same verdict and a valid action queue, every stored state sits on its owner rank exactly
+    once, G is consistent along parent links inside a shard, results are deterministic.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from librubiks_amd import _ffi, cube
+from librubiks_amd.solving.agents import AStar
+from librubiks_amd.solving.sharded import ShardedAStar
+from oracle import cube_oracle as orc
+from oracle.search_oracle import AStarOracle, StubNet
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "d"])
+def test_world1_reproduces_reference_traces(golden, tag):
+	t = golden["astar_trace"]
+	_, _, expansions, max_states = (int(x) for x in t[f"{tag}_params"])
+	agent = ShardedAStar(StubNet(), float(t[f"{tag}_lambda"]), expansions, capacity=max_states + 16)
+	solved = agent.search(t[f"{tag}_start"], None, max_states)
+	n = int(t[f"{tag}_n"])
+	assert solved == bool(t[f"{tag}_solved"]) and len(agent) == n
+	states, G, parents, pact = agent.local_arrays()
+	assert (states[1:] == t[f"{tag}_states"]).all() and (G[1:] == t[f"{tag}_G"]).all()
+	assert (parents[2:] == t[f"{tag}_parents"]).all() and (pact[2:] == t[f"{tag}_parent_actions"]).all()
+	assert list(agent.action_queue) == t[f"{tag}_action_queue"].tolist()
+
+
+@pytest.mark.parametrize("seed,depth,lam,n,budget", [(103, 9, 1.0, 128, 30_000), (104, 6, 0.05, 1000, 40_000), (107, 12, 0.2, 400, 120_000)])
+def test_world1_equals_oracle(seed, depth, lam, n, budget):
+	np.random.seed(seed)
+	start, _, _ = orc.scramble(depth, True)
+	ref = AStarOracle(StubNet(), lam, n)
+	ref_solved = ref.search(start, budget)
+	agent = ShardedAStar(StubNet(), lam, n, capacity=budget + 16)
+	assert agent.search(start, None, budget) == ref_solved
+	states, G, parents, pact = agent.local_arrays()
+	rs, rG, rp, ra = ref.arrays()
+	assert (states[1:] == rs).all() and (G[1:] == rG).all() and (parents[2:] == rp).all() and (pact[2:] == ra).all()
+	assert list(agent.action_queue) == list(ref.action_queue)
+
+
+def _free_port():
+	with socket.socket() as s:
+		s.bind(("127.0.0.1", 0))
+		return s.getsockname()[1]
+
+
+def _rank_main(rank, world, port, out_dir, cases):
+	import torch.distributed as dist
+	os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+	dist.init_process_group("gloo", rank=rank, world_size=world)
+	try:
+		torch.cuda.set_device(0)
+		for ci, (seed, depth, lam, n, budget) in enumerate(cases):
+			np.random.seed(seed)
+			start, _, _ = orc.scramble(depth, True)
+			agent = ShardedAStar(StubNet(), lam, n, capacity=budget)
+			solved = agent.search(start, None, budget)
+			states, G, parents, pact = agent.local_arrays()
+			np.savez(os.path.join(out_dir, f"c{ci}_r{rank}.npz"), solved=solved, queue=np.array(agent.action_queue, dtype=np.int64),
+			         states=states[1:], G=G[1:], n=len(agent), total=agent.total_states, iters=agent.iterations, start=start)
+	finally:
+		dist.destroy_process_group()
+
+
+CASES = [(7, 6, 0.5, 10, 30_000), (19, 7, 0.1, 300, 60_000), (402, 6, 1.0, 50, 30_000), (404, 5, 0.2, 200, 40_000), (405, 8, 0.5, 30, 40_000)]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_rank_on_one_gpu(world, tmp_path):
+	for attempt in range(2):                      # run twice: results must be deterministic
+		d = tmp_path / f"run{attempt}"
+		d.mkdir()
+		mp.spawn(_rank_main, args=(world, _free_port(), str(d), CASES), nprocs=world, join=True)
+	lib = _ffi.lib()
+	n_solved = 0
+	for ci, (seed, depth, lam, n, budget) in enumerate(CASES):
+		runs = [[np.load(tmp_path / f"run{a}" / f"c{ci}_r{r}.npz") for r in range(world)] for a in range(2)]
+		first = runs[0]
+		start = first[0]["start"]
+		# same verdict and action queue on every rank, both runs
+		for run in runs:
+			for z in run:
+				assert bool(z["solved"]) == bool(first[0]["solved"]) and z["queue"].tolist() == first[0]["queue"].tolist()
+				assert int(z["total"]) == int(first[0]["total"])
+		for r in range(world):
+			assert (runs[0][r]["states"] == runs[1][r]["states"]).all() and (runs[0][r]["G"] == runs[1][r]["G"]).all()
+		# the action queue solves the cube
+		if first[0]["solved"]:
+			n_solved += 1
+			s = start
+			for a in first[0]["queue"]:
+				s = orc.rotate(s, a // 2, 1 - a % 2)
+			assert orc.is_solved(s)
+			# never worse than what the oracle's single-queue search finds under the same budget, if it finds one
+			ref = AStarOracle(StubNet(), lam, n)
+			if ref.search(start, budget):
+				assert len(first[0]["queue"]) <= len(ref.action_queue) + 2
+		# every state lives on its owner rank, exactly once overall; G is the length of a real path bound
+		seen = set()
+		total = 0
+		for r in range(world):
+			st = first[r]["states"]
+			total += len(st)
+			assert len(st) == int(first[r]["n"])
+			owners = np.array([lib.rk_shard_owner(np.ascontiguousarray(x).ctypes.data, world) for x in st[:: max(1, len(st) // 500)]])
+			assert (owners == r).all()
+			keys = {x.tobytes() for x in st}
+			assert len(keys) == len(st) and not (keys & seen)
+			seen |= keys
+		assert total == int(first[0]["total"]) and start.tobytes() in seen
+		assert total <= budget
+	assert n_solved >= 3
