@@ -1,0 +1,121 @@
+"""
+Search-loop benchmarks on one MI355X (BASELINE.json configs[2] and configs[3]); random-init fc_small net.
+
+    python benchmarks/search.py astar [--games 5] [--depth 14] [--expansions 1000] [--max-states 150000]
+    python benchmarks/search.py mcts  [--trees 256] [--sims 4096] [--graph 1]
+
+Prints one JSON object per benchmark.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from benchmarks.nets import FcSmall  # noqa: E402
+from librubiks_amd import _ffi, cube  # noqa: E402
+from librubiks_amd.solving.agents import AStar, MCTSBatch  # noqa: E402
+
+
+class TimedNet(torch.nn.Module):
+	"""Wraps the net to separate its share of the wall time (adds a sync per call: use only for the breakdown)."""
+	def __init__(self, net):
+		super().__init__()
+		self.net, self.seconds, self.rows = net, 0.0, 0
+
+	def forward(self, x, policy=True, value=True):
+		torch.cuda.synchronize()
+		t0 = time.perf_counter()
+		out = self.net(x, policy=policy, value=value)
+		torch.cuda.synchronize()
+		self.seconds += time.perf_counter() - t0
+		self.rows += len(x)
+		return out
+
+
+def bench_astar(args):
+	net = FcSmall().cuda().eval()
+	if args.bf16:
+		net = net.to(torch.bfloat16)
+		base = net
+		class Cast(torch.nn.Module):
+			def forward(self, x, policy=True, value=True):
+				out = base(x.to(torch.bfloat16), policy=policy, value=value)
+				return [o.float() for o in out] if isinstance(out, list) else out.float()
+		net = Cast()
+	rows = []
+	for timed in (False, True):
+		use = TimedNet(net) if timed else net
+		agent = AStar(use, args.lam, args.expansions)
+		tot_t = tot_states = tot_iter = solved = 0
+		for g in range(args.games):
+			np.random.seed(g)
+			state, _, _ = cube.scramble(args.depth, True)
+			torch.cuda.synchronize()
+			t0 = time.perf_counter()
+			ok = agent.search(state, time_limit=None, max_states=args.max_states)
+			torch.cuda.synchronize()
+			tot_t += time.perf_counter() - t0
+			tot_states += len(agent)
+			tot_iter += agent.iterations
+			solved += ok
+		row = {"bench": "astar", "config": f"depth-{args.depth} scrambles, lambda={args.lam}, N={args.expansions}, max_states={args.max_states}, fc_small random init"
+		       + (" bf16" if args.bf16 else " fp32"), "games": args.games, "solved": solved, "states": tot_states, "iterations": tot_iter,
+		       "seconds": tot_t, "states_per_s": tot_states / tot_t, "expansions_per_s": tot_iter * args.expansions / tot_t,
+		       "ms_per_iteration": tot_t / max(tot_iter, 1) * 1e3}
+		if timed:
+			row["net_seconds"] = use.seconds
+			row["net_share"] = use.seconds / tot_t
+			row["note"] = "breakdown run (sync around every net call)"
+		rows.append(row)
+		print(json.dumps(row), flush=True)
+	return rows
+
+
+def bench_mcts(args):
+	net = FcSmall().cuda().eval()
+	T = args.trees
+	starts = []
+	for g in range(T):
+		np.random.seed(g)
+		s, _, _ = cube.scramble(args.depth, True)
+		starts.append(s)
+	starts = np.array(starts)
+	cap = args.sims * 12 + 64
+	agent = MCTSBatch(net, args.c, T, capacity=cap, max_path=args.max_path)
+	torch.cuda.synchronize()
+	t0 = time.perf_counter()
+	solved = agent.search(starts, max_states=cap, max_sims=args.sims, use_graph=bool(args.graph), poll=args.poll)
+	torch.cuda.synchronize()
+	dt = time.perf_counter() - t0
+	st = agent.status
+	row = {"bench": "mcts", "config": f"{T} trees x {args.sims} sims, depth-{args.depth} scrambles, c={args.c}, fc_small random init fp32, "
+	       f"hipGraph={'on' if args.graph else 'off'}", "seconds": dt, "tree_sims": int(st[:, 3].sum()), "tree_sims_per_s": float(st[:, 3].sum()) / dt,
+	       "steps": agent.simulations, "ms_per_step": dt / agent.simulations * 1e3, "solved": int(solved.sum()), "states": int(st[:, 2].sum()),
+	       "states_per_s": float(st[:, 2].sum()) / dt, "max_path_len": int(st[:, 4].max())}
+	print(json.dumps(row), flush=True)
+	return row
+
+
+if __name__ == "__main__":
+	ap = argparse.ArgumentParser()
+	ap.add_argument("what", choices=["astar", "mcts"])
+	ap.add_argument("--games", type=int, default=5)
+	ap.add_argument("--depth", type=int, default=14)
+	ap.add_argument("--expansions", type=int, default=1000)
+	ap.add_argument("--max-states", type=int, default=150_000)
+	ap.add_argument("--lam", type=float, default=0.16)
+	ap.add_argument("--bf16", type=int, default=0)
+	ap.add_argument("--trees", type=int, default=256)
+	ap.add_argument("--sims", type=int, default=4096)
+	ap.add_argument("--c", type=float, default=0.6)
+	ap.add_argument("--graph", type=int, default=1)
+	ap.add_argument("--poll", type=int, default=64)
+	ap.add_argument("--max-path", type=int, default=16384)
+	a = ap.parse_args()
+	_ffi.check(_ffi.lib().rk_init(0))
+	bench_astar(a) if a.what == "astar" else bench_mcts(a)

@@ -180,6 +180,18 @@ int rk_expand12(int repr, const int8_t *d_parents, int8_t *d_children, uint8_t *
 	return RK_OK;
 }
 
+/* Tuning hook, deliberately outside the public header: other shapes of the fan-out kernel (benchmarks/tune_expand.py). */
+int rkx_expand12_variant(int variant, const int8_t *d_parents, int8_t *d_children, uint8_t *d_solved, long long *d_stats, size_t n,
+                         unsigned int *d_counter, int grid_blocks, void *stream)
+{
+	if (!d_parents || !d_children || !d_solved || misaligned(d_children, 16)) return fail(RK_EINVAL, "rkx_expand12_variant: bad argument");
+	if ((variant & 4) && !d_counter) return fail(RK_EINVAL, "rkx_expand12_variant: dynamic variants need a counter");
+	if (variant & 4) RK_HIP(hipMemsetAsync(d_counter, 0, sizeof(unsigned int), (hipStream_t)stream));
+	launch_expand12_variant(variant, d_parents, d_children, d_solved, d_stats, n, d_counter, grid_blocks, (hipStream_t)stream);
+	RK_HIP(hipGetLastError());
+	return RK_OK;
+}
+
 int rk_multi_is_solved(int repr, const int8_t *d_states, uint8_t *d_flags, long long *d_stats, size_t n, void *stream)
 {
 	if (int e = check_repr(repr)) return e;

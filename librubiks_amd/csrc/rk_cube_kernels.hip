@@ -16,8 +16,9 @@ namespace rk {
 //                                                                                cube.py:256-263, cube.py:88-89
 // Algorithmic HBM bytes per parent: 20 read + 240 + 12 written = 272.
 //
-// A wave owns a tile of 256 parents: five 1 KiB coalesced loads bring the 5 120 B in, the wave re-reads them one
-// state per lane (stride 5 dwords: conflict-free), then runs four rounds of 64 parents.  In a round each lane
+// A wave owns a tile of 64 parents (one per lane; a 256-parent shape with four rounds and 16 B/lane loads is kept as a
+// template variant): coalesced loads bring the tile's 1 280 B in, the wave re-reads them one state per lane through
+// LDS (stride 5 dwords: conflict-free).  Then each lane
 //   1. fetches, for each of its 20 cubies, the 16-byte row rows[kind][code] = that cubie's code in all 12
 //      children (20 ds_read_b128; the table is 768 B, codes differing by 16 share a bank: at most 2-way),
 //   2. turns the 20x12 byte matrix into 12 children x 5 dwords with 15 4x4 byte transposes (120 v_perm_b32),
@@ -26,7 +27,6 @@ namespace rk {
 //      the wave then streams the 15 360 B out as fifteen 1 KiB global_store_dwordx4.
 // ================================================================================================================
 constexpr int EXP_ROUND = 64;                  // parents per round (one per lane)
-constexpr int EXP_TILE = 256;                  // parents per wave tile (4 rounds)
 constexpr int EXP_WAVES = 4;                   // waves per workgroup
 
 struct ExpandWaveLds {
@@ -34,11 +34,14 @@ struct ExpandWaveLds {
 	uint32_t flags[EXP_ROUND * 3];             // 768 B: 12 solved bytes per parent
 };
 
-template <bool WITH_FLAGS>
+// ROUNDS = rounds of 64 parents per wave tile (4 -> 256-parent tiles with 16 B/lane input loads, 1 -> 64-parent tiles);
+// NT = non-temporal output stores; DYNAMIC = tiles handed out by an atomic counter to a persistent grid.
+template <bool WITH_FLAGS, int ROUNDS = 4, bool NT = true, bool DYNAMIC = false>
 __global__ __launch_bounds__(EXP_WAVES * WAVE)
 void k_expand12(const uint32_t *__restrict__ parents, u32x4 *__restrict__ children, uint32_t *__restrict__ solved,
-                long long *__restrict__ stats, size_t n, size_t n_tiles)
+                long long *__restrict__ stats, size_t n, size_t n_tiles, unsigned int *__restrict__ tile_counter = nullptr)
 {
+	constexpr int EXP_TILE = EXP_ROUND * ROUNDS;
 	__shared__ u32x4 s_rows[48];
 	__shared__ ExpandWaveLds s_wave[EXP_WAVES];
 
@@ -52,36 +55,43 @@ void k_expand12(const uint32_t *__restrict__ parents, u32x4 *__restrict__ childr
 	ExpandWaveLds &L = s_wave[wv];
 	uint32_t *stage_dw = reinterpret_cast<uint32_t *>(L.stage);
 
-	for (size_t tile = (size_t)blockIdx.x * EXP_WAVES + wv; tile < n_tiles; tile += (size_t)gridDim.x * EXP_WAVES) {
+	size_t tile = (size_t)blockIdx.x * EXP_WAVES + wv;
+	for (;;) {
+		if (DYNAMIC) {
+			unsigned int t = 0;
+			if (lane == 0) t = atomicAdd(tile_counter, 1u);
+			tile = __shfl(t, 0, 64);
+		}
+		if (tile >= n_tiles) break;
 		const size_t p0 = tile * EXP_TILE;
 		const int np = (int)((n - p0 < (size_t)EXP_TILE) ? (n - p0) : (size_t)EXP_TILE);   // parents in this tile
 
-		// ---- parents in: 5 x 1 KiB coalesced, through LDS, one state per lane per round ----
-		uint32_t par[4][5];
+		// ---- parents in: coalesced (16 B/lane when the tile is 256 parents), through LDS, one state per lane per round ----
+		uint32_t par[ROUNDS][5];
 		{
 			const uint32_t *src = parents + p0 * STATE_DWORDS;
-			if (np == EXP_TILE && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+			if (ROUNDS == 4 && np == EXP_TILE && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
 				const u32x4 *src4 = reinterpret_cast<const u32x4 *>(src);
 				#pragma unroll
 				for (int k = 0; k < 5; k++) L.stage[k * 64 + lane] = src4[k * 64 + lane];
 			} else {
 				const int ndw = np * STATE_DWORDS;
 				#pragma unroll
-				for (int k = 0; k < 20; k++) {
+				for (int k = 0; k < 5 * ROUNDS; k++) {
 					const int idx = k * 64 + lane;
 					stage_dw[idx] = idx < ndw ? src[idx] : 0u;
 				}
 			}
 			wave_lds_fence();
 			#pragma unroll
-			for (int q = 0; q < 4; q++)
+			for (int q = 0; q < ROUNDS; q++)
 				#pragma unroll
 				for (int j = 0; j < 5; j++) par[q][j] = stage_dw[(q * 64 + lane) * 5 + j];
 			wave_lds_fence();
 		}
 
 		#pragma unroll
-		for (int q = 0; q < 4; q++) {                                       // fully unrolled: par[q] stays in registers
+		for (int q = 0; q < ROUNDS; q++) {                                  // fully unrolled: par[q] stays in registers
 			const int round_first = q * EXP_ROUND;
 			if (round_first >= np) break;                                   // wave-uniform
 			const int nr = (np - round_first < EXP_ROUND) ? (np - round_first) : EXP_ROUND;
@@ -125,14 +135,18 @@ void k_expand12(const uint32_t *__restrict__ parents, u32x4 *__restrict__ childr
 			for (int v = 0; v < 15; v++) {
 				const int idx = v * 64 + lane;
 				const u32x4 val = L.stage[idx];
-				if (idx < nvec) __builtin_nontemporal_store(val, dst + idx);
+				if (idx < nvec) {
+					if (NT) __builtin_nontemporal_store(val, dst + idx);
+					else dst[idx] = val;
+				}
 			}
 			if (WITH_FLAGS) {
 				uint32_t *fdst = solved + (p0 + round_first) * 3;
 				if (nr == EXP_ROUND && ((reinterpret_cast<uintptr_t>(fdst) & 15) == 0)) {
 					if (lane < 48) {
 						const u32x4 val = reinterpret_cast<const u32x4 *>(L.flags)[lane];
-						__builtin_nontemporal_store(val, reinterpret_cast<u32x4 *>(fdst) + lane);
+						if (NT) __builtin_nontemporal_store(val, reinterpret_cast<u32x4 *>(fdst) + lane);
+						else reinterpret_cast<u32x4 *>(fdst)[lane] = val;
 					}
 				} else {
 					#pragma unroll
@@ -155,6 +169,7 @@ void k_expand12(const uint32_t *__restrict__ parents, u32x4 *__restrict__ childr
 			}
 			wave_lds_fence();
 		}
+		if (!DYNAMIC) tile += (size_t)gridDim.x * EXP_WAVES;
 	}
 }
 
@@ -501,16 +516,43 @@ static inline unsigned grid_for(size_t work_items, size_t per_block, unsigned ca
 	return (unsigned)b;
 }
 
+// tuning aid (benchmarks/tune_expand.py): the same kernel in its other shapes.  variant bits: 1 = plain stores,
+// 2 = 64-parent tiles, 4 = persistent grid with a dynamic tile counter (needs a zeroed uint32 at `counter`).
+void launch_expand12_variant(int variant, const int8_t *parents, int8_t *children, uint8_t *solved, long long *stats, size_t n,
+                             unsigned int *counter, int grid_blocks, hipStream_t st)
+{
+	const bool small = variant & 2;
+	const size_t n_tiles = small ? (n + 63) / 64 : (n + 255) / 256;
+	unsigned grid = grid_for(n_tiles, EXP_WAVES, 1u << 20);
+	if (grid_blocks > 0) grid = (unsigned)grid_blocks;
+	#define RK_LAUNCH(R, NTS, DYN) hipLaunchKernelGGL((k_expand12<true, R, NTS, DYN>), dim3(grid), dim3(EXP_WAVES * WAVE), 0, st, \
+		(const uint32_t *)parents, (u32x4 *)children, (uint32_t *)solved, stats, n, n_tiles, counter)
+	switch (variant & 7) {
+		case 0: RK_LAUNCH(4, true, false); break;
+		case 1: RK_LAUNCH(4, false, false); break;
+		case 2: RK_LAUNCH(1, true, false); break;
+		case 3: RK_LAUNCH(1, false, false); break;
+		case 4: RK_LAUNCH(4, true, true); break;
+		case 5: RK_LAUNCH(4, false, true); break;
+		case 6: RK_LAUNCH(1, true, true); break;
+		default: RK_LAUNCH(1, false, true); break;
+	}
+	#undef RK_LAUNCH
+}
+
+// Shipping shape (benchmarks/tune_expand.py, profiles/r01_tune_expand.json): 64-parent wave tiles + non-temporal
+// stores stream at the same 6.1 TB/s whether or not the output buffer is reused; plain stores only win when the
+// 252 MB output is rewritten in place launch after launch (Infinity-Cache hits), and lose with 64-parent tiles.
 void launch_expand12(const int8_t *parents, int8_t *children, uint8_t *solved, long long *stats, size_t n, hipStream_t st)
 {
-	const size_t n_tiles = (n + EXP_TILE - 1) / EXP_TILE;
-	const unsigned grid = grid_for(n_tiles, EXP_WAVES, 256u * 2u * 8u);
+	const size_t n_tiles = (n + EXP_ROUND - 1) / EXP_ROUND;
+	const unsigned grid = grid_for(n_tiles, EXP_WAVES, 1u << 20);
 	if (solved != nullptr)
-		hipLaunchKernelGGL(k_expand12<true>, dim3(grid), dim3(EXP_WAVES * WAVE), 0, st, (const uint32_t *)parents,
-		                   (u32x4 *)children, (uint32_t *)solved, stats, n, n_tiles);
+		hipLaunchKernelGGL((k_expand12<true, 1, true, false>), dim3(grid), dim3(EXP_WAVES * WAVE), 0, st, (const uint32_t *)parents,
+		                   (u32x4 *)children, (uint32_t *)solved, stats, n, n_tiles, (unsigned int *)nullptr);
 	else
-		hipLaunchKernelGGL(k_expand12<false>, dim3(grid), dim3(EXP_WAVES * WAVE), 0, st, (const uint32_t *)parents,
-		                   (u32x4 *)children, (uint32_t *)nullptr, (long long *)nullptr, n, n_tiles);
+		hipLaunchKernelGGL((k_expand12<false, 1, true, false>), dim3(grid), dim3(EXP_WAVES * WAVE), 0, st, (const uint32_t *)parents,
+		                   (u32x4 *)children, (uint32_t *)nullptr, (long long *)nullptr, n, n_tiles, (unsigned int *)nullptr);
 }
 
 void launch_multi_rotate(const int8_t *states, const uint8_t *actions, const uint8_t *dirs, int8_t *out, size_t n, hipStream_t st)
