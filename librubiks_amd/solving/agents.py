@@ -24,14 +24,28 @@ from librubiks_amd import cube
 
 
 class Agent:
-	"""Protocol of the reference's agents (agents.py:14-64)."""
+	"""Protocol of the reference's agents (agents.py:14-64): one-step agents implement `_step`."""
 	eps = np.finfo("float").eps
 	_explored_states = 0
 
 	def __init__(self):
 		self.action_queue = deque()
 
+	@no_grad
 	def search(self, state: np.ndarray, time_limit: float = None, max_states: int = None) -> bool:
+		time_limit, max_states = self.reset(time_limit, max_states)
+		t0 = time.perf_counter()
+		if cube.is_solved(state):
+			return True
+		solved = False
+		while not solved and time.perf_counter() - t0 < time_limit and len(self) < max_states:
+			action, state, solved = self._step(state)
+			self.action_queue.append(action)
+			self._explored_states = len(self.action_queue)
+		return solved
+
+	def _step(self, state: np.ndarray):
+		"""-> (action index, new state, is solved)"""
 		raise NotImplementedError
 
 	def reset(self, time_limit: float, max_states: int):
@@ -50,6 +64,135 @@ class DeepAgent(Agent):
 	def __init__(self, net):
 		super().__init__()
 		self.net = net
+
+
+class RandomSearch(Agent):
+	"""Random walk (agents.py:82-89)."""
+	def _step(self, state):
+		action = np.random.randint(cube.action_dim)
+		state = cube.rotate(state, *cube.action_space[action])
+		return action, state, cube.is_solved(state)
+
+	def __str__(self):
+		return "Random depth-first search"
+
+
+class BFS(Agent):
+	"""Breadth-first search over the 12-move graph (agents.py:92-129); every layer is one fan-out launch."""
+	states = dict()
+
+	def search(self, state: np.ndarray, time_limit: float = None, max_states: int = None) -> bool:
+		time_limit, max_states = self.reset(time_limit, max_states)
+		t0 = time.perf_counter()
+		if cube.is_solved(state):
+			return True
+		self.states = {state.tobytes(): (None, None)}          # state -> (predecessor key, action)
+		frontier = deque([state])
+		while frontier and time.perf_counter() - t0 < time_limit and len(self) < max_states:
+			parent = frontier.popleft()
+			pkey = parent.tobytes()
+			children, solved = cube.expand(parent[None], return_solved=True)
+			for a in range(cube.action_dim):
+				ckey = children[a].tobytes()
+				if ckey in self.states:
+					continue
+				if solved[a]:
+					self.action_queue.appendleft(a)
+					while self.states[pkey][0] is not None:
+						pkey, act = self.states[pkey]
+						self.action_queue.appendleft(act)
+					return True
+				self.states[ckey] = (pkey, a)
+				frontier.append(children[a])
+		return False
+
+	def __str__(self):
+		return "Breadth-first search"
+
+	def __len__(self):
+		return len(self.states)
+
+
+class PolicySearch(DeepAgent):
+	"""Follow (or sample from) the policy head (agents.py:132-151)."""
+	def __init__(self, net, sample_policy=False):
+		super().__init__(net)
+		self.sample_policy = sample_policy
+
+	def _step(self, state):
+		logits = self.net(cube.as_oh(state), value=False)
+		policy = torch.nn.functional.softmax(logits.float().cpu(), dim=1).numpy().squeeze()
+		action = int(np.random.choice(cube.action_dim, p=policy)) if self.sample_policy else int(policy.argmax())
+		state = cube.rotate(state, *cube.action_space[action])
+		return action, state, cube.is_solved(state)
+
+	def __str__(self):
+		return f"{'Sampled' if self.sample_policy else 'Greedy'} policy"
+
+
+class ValueSearch(DeepAgent):
+	"""Greedy one-step look-ahead on the value head (agents.py:154-169); one fan-out launch per step."""
+	def _step(self, state):
+		children, solved = cube.expand(np.asarray(state)[None], return_solved=True)
+		if solved.any():
+			action = int(np.flatnonzero(solved)[0])
+			return action, children[action], True
+		v = self.net(cube.as_oh(children), policy=False).float().squeeze().cpu().numpy()
+		action = int(np.argmax(v))
+		return action, children[action], False
+
+	def __str__(self):
+		return "Greedy value"
+
+
+class EGVM(DeepAgent):
+	"""Epsilon-greedy value maximisation (agents.py:649-726): `workers` walkers of `depth` moves, restart from the best."""
+	def __init__(self, net, epsilon: float, workers: int, depth: int):
+		super().__init__(net)
+		self.epsilon, self.workers, self.depth = epsilon, workers, depth
+
+	@no_grad
+	def search(self, state: np.ndarray, time_limit: float = None, max_states: int = None) -> bool:
+		time_limit, max_states = self.reset(time_limit, max_states)
+		t0 = time.perf_counter()
+		if cube.is_solved(state):
+			return True
+		while time.perf_counter() - t0 < time_limit and len(self) + self.workers * self.depth <= max_states:
+			paths, states, states_oh, solved = self.expand(state)
+			if solved != (-1, -1):
+				self.action_queue += deque(int(a) for a in paths[solved[0], :solved[1]])
+				return True
+			best = int(self.net(states_oh, policy=False).float().cpu().squeeze().argmax())
+			state = states[best]
+			worker, d = divmod(best, self.depth)
+			self.action_queue += deque(int(a) for a in paths[worker, :d + 1])
+		return False
+
+	def expand(self, state: np.ndarray):
+		"""Walks all workers `depth` moves on the device; row w*depth + d = worker w after d+1 moves."""
+		cur = torch.from_numpy(cube.repeat_state(np.asarray(state), self.workers)).to(gpu)
+		paths = np.empty((self.workers, self.depth), dtype=int)
+		visited = torch.empty((self.workers, self.depth, 20), dtype=torch.int8, device=gpu)
+		for d in range(self.depth):
+			use_random = np.random.choice(2, self.workers, p=[1 - self.epsilon, self.epsilon]).astype(bool)
+			actions = np.empty(self.workers, dtype=int)
+			actions[use_random] = np.random.randint(0, cube.action_dim, use_random.sum())
+			if (~use_random).any():
+				p = self.net(cube.device.as_oh(cur[torch.from_numpy(~use_random).to(gpu)].contiguous()), value=False).float().cpu().numpy()
+				actions[~use_random] = p.argmax(axis=1)
+			paths[:, d] = actions
+			cur = cube.device.multi_rotate(cur, torch.from_numpy(actions.astype(np.uint8)).to(gpu))
+			flags = cube.device.multi_is_solved(cur).cpu().numpy().astype(bool)
+			if flags.any():
+				self._explored_states += (d + 1) * self.workers
+				return paths, None, None, (int(np.flatnonzero(flags)[0]), d + 1)
+			visited[:, d] = cur
+		self._explored_states += self.workers * self.depth
+		flat = visited.reshape(self.workers * self.depth, 20)
+		return paths, flat.cpu().numpy(), cube.device.as_oh(flat), (-1, -1)
+
+	def __str__(self):
+		return f"EGVM (e={self.epsilon}, w={self.workers}, d={self.depth})"
 
 
 def _value_f32(out) -> torch.Tensor:
