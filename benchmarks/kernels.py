@@ -66,6 +66,7 @@ def main():
 		print(json.dumps(rows[-1]), flush=True)
 
 	report("device copy 256 MiB (torch, reference point)", 2 * a.numel(), timed(lambda: b.copy_(a), 50), a.numel(), "bytes")
+	report("device fill 240 MB (torch fill_, pure store stream)", children.numel(), timed(lambda: children.fill_(1), 50), children.numel(), "bytes")
 	report("expand12 + goal test", 272 * n, timed(lambda: cube.device.expand12(states, children, solved), args.reps), n, "expansions")
 	report("expand12 without flags", 260 * n, timed(lambda: cube.device.expand12(states, children, want_flags=False), args.reps), n, "expansions")
 	report("multi_rotate (per-state action)", 41 * n, timed(lambda: cube.device.multi_rotate(states, acts, out), args.reps), n, "transitions")

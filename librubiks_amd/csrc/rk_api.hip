@@ -137,6 +137,8 @@ int rk_multi_rotate(int repr, const int8_t *d_states, const uint8_t *d_actions, 
 	if (n == 0) return RK_OK;
 	if (!d_states || !d_actions || !d_out) return fail(RK_EINVAL, "rk_multi_rotate: null pointer");
 	if (misaligned(d_states, 4) || misaligned(d_out, 4)) return fail(RK_EINVAL, "rk_multi_rotate: state arrays must be 4-byte aligned");
+	if (repr == RK_REPR_686 && (misaligned(d_out, 16) || misaligned(d_states, 16)))
+		return fail(RK_EINVAL, "rk_multi_rotate: 6x8x6 state arrays must be 16-byte aligned");
 	if (repr == RK_REPR_2024) launch_multi_rotate(d_states, d_actions, nullptr, d_out, n, (hipStream_t)stream);
 	else {
 		if (d_out == d_states) return fail(RK_EINVAL, "rk_multi_rotate: in-place not supported for the 6x8x6 representation");
@@ -173,8 +175,9 @@ int rk_expand12(int repr, const int8_t *d_parents, int8_t *d_children, uint8_t *
 	if (repr == RK_REPR_2024) {
 		launch_expand12(d_parents, d_children, d_solved, d_stats, n, (hipStream_t)stream);
 	} else {
+		if (misaligned(d_parents, 16)) return fail(RK_EINVAL, "rk_expand12: 6x8x6 parents must be 16-byte aligned");
 		launch_rotate686(d_parents, nullptr, d_children, 12 * n, true, (hipStream_t)stream);
-		if (d_solved || d_stats) launch_is_solved686(d_children, d_solved, d_stats, 12 * n, (hipStream_t)stream);
+		if (d_solved || d_stats) launch_fanout_flags686(d_parents, d_solved, d_stats, n, (hipStream_t)stream);
 	}
 	RK_HIP(hipGetLastError());
 	return RK_OK;
@@ -199,6 +202,7 @@ int rk_multi_is_solved(int repr, const int8_t *d_states, uint8_t *d_flags, long 
 	if (!d_states) return fail(RK_EINVAL, "rk_multi_is_solved: null states");
 	if (misaligned(d_states, 4)) return fail(RK_EINVAL, "rk_multi_is_solved: states must be 4-byte aligned");
 	if (d_stats && misaligned(d_stats, 8)) return fail(RK_EINVAL, "rk_multi_is_solved: stats must be 8-byte aligned");
+	if (repr == RK_REPR_686 && misaligned(d_states, 16)) return fail(RK_EINVAL, "rk_multi_is_solved: 6x8x6 states must be 16-byte aligned");
 	if (repr == RK_REPR_2024) launch_multi_is_solved(d_states, d_flags, d_stats, n, (hipStream_t)stream);
 	else launch_is_solved686(d_states, d_flags, d_stats, n, (hipStream_t)stream);
 	RK_HIP(hipGetLastError());

@@ -425,43 +425,123 @@ __device__ __forceinline__ void stage_perm686(uint8_t *lds, int tid, int nthread
 }
 
 // FANOUT = false: out[r] = move actions[r] of states[r].  FANOUT = true: out[12 r + a] = move a of states[r].
+// A state is 144 ushorts (48 slots x 3).  A workgroup stages GROUP source states in LDS with 16 B/lane loads; each
+// thread then produces 16-byte chunks (8 ushorts) of the output, gathering its 8 source ushorts from LDS through the
+// per-action source-offset table src[a][u] = perm686[a][u/3]*3 + u%3 (also LDS).  Stores are 16 B/lane, contiguous
+// across lanes and non-temporal: a store stream.
 template <bool FANOUT>
 __global__ __launch_bounds__(256)
-void k_rotate686(const uint16_t *__restrict__ states, const uint8_t *__restrict__ actions, uint16_t *__restrict__ out, size_t n_out)
+void k_rotate686(const uint16_t *__restrict__ states, const uint8_t *__restrict__ actions, u32x4 *__restrict__ out, size_t n_in)
 {
-	__shared__ uint8_t s_perm[N_ACTIONS * S686_SLOTS];
-	stage_perm686(s_perm, threadIdx.x, blockDim.x);
-	__syncthreads();
-	const size_t total = n_out * 144;
-	for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-		const size_t r = idx / 144;
-		const int u = (int)(idx - r * 144), slot = u / 3, part = u - slot * 3;
-		size_t src_row;
-		uint32_t a;
-		if (FANOUT) { src_row = r / 12; a = (uint32_t)(r - src_row * 12); }
-		else        { src_row = r; a = actions[r]; a = a < 12u ? a : 0u; }
-		out[idx] = states[src_row * 144 + (int)s_perm[a * S686_SLOTS + slot] * 3 + part];
+	constexpr int GROUP = FANOUT ? 16 : 64;               // source states per workgroup step
+	constexpr int OUT_PER_IN = FANOUT ? 12 : 1;
+	__shared__ __attribute__((aligned(16))) uint8_t s_src[N_ACTIONS * 144];
+	__shared__ __attribute__((aligned(16))) uint16_t s_in[GROUP * 144];
+	for (int i = threadIdx.x; i < N_ACTIONS * 144; i += 256) {
+		const int a = i / 144, u = i - a * 144, slot = u / 3;
+		s_src[i] = (uint8_t)(D_TAB.perm686[a][slot] * 3 + (u - slot * 3));
+	}
+	const size_t n_groups = (n_in + GROUP - 1) / GROUP;
+	for (size_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+		const size_t first = g * GROUP;
+		const int ng = (int)((n_in - first < (size_t)GROUP) ? (n_in - first) : (size_t)GROUP);
+		__syncthreads();                                  // previous step's gathers are done (and s_src is ready)
+		const u32x4 *src4 = reinterpret_cast<const u32x4 *>(states + first * 144);
+		for (int i = threadIdx.x; i < ng * 18; i += 256) reinterpret_cast<u32x4 *>(s_in)[i] = src4[i];
+		__syncthreads();
+		u32x4 *dst = out + first * OUT_PER_IN * 18;
+		const int n_chunks = ng * OUT_PER_IN * 18;
+		for (int q = threadIdx.x; q < n_chunks; q += 256) {
+			const int r = q / 18, k = q - r * 18;          // output row inside the group, chunk inside the row
+			int local;
+			uint32_t a;
+			if (FANOUT) { local = r / 12; a = (uint32_t)(r - local * 12); }
+			else        { local = r; a = actions[first + r]; a = a < 12u ? a : 0u; }
+			const uint16_t *row = s_in + local * 144;
+			const u32x2 offs = *reinterpret_cast<const u32x2 *>(&s_src[a * 144 + k * 8]);
+			uint32_t h[8];
+			#pragma unroll
+			for (int i = 0; i < 8; i++) h[i] = row[((i < 4 ? offs.x : offs.y) >> (8 * (i & 3))) & 0xFFu];
+			__builtin_nontemporal_store(u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)}, dst + q);
+		}
 	}
 }
 
-// one wave per state: 72 dwords against the solved pattern
+// solved flags of the 12 children WITHOUT reading them back: child a of p is solved  <=>  p == move rev(a) of solved.
+// One wave per parent compares its 72 dwords with the 12 "one move from solved" patterns (built on the fly from the
+// slot table: such a pattern's slot s shows colour face(perm686[a^1][s])).
 __global__ __launch_bounds__(256)
-void k_is_solved686(const uint32_t *__restrict__ states, uint8_t *__restrict__ flags, long long *__restrict__ stats, size_t n)
+void k_fanout_flags686(const uint32_t *__restrict__ parents, uint8_t *__restrict__ flags, long long *__restrict__ stats, size_t n)
 {
+	__shared__ uint32_t s_near[N_ACTIONS][72];
+	for (int i = threadIdx.x; i < N_ACTIONS * 72; i += blockDim.x) {
+		const int a = i / 72, d = i - a * 72;
+		uint32_t w = 0;
+		#pragma unroll
+		for (int b = 0; b < 4; b++) {
+			const int byte = d * 4 + b, slot = byte / 6, colour = byte - slot * 6;
+			// near[a] = move (a^1) applied to solved: new[slot] = solved[perm[a^1][slot]], whose colour is its face
+			if ((D_TAB.perm686[a ^ 1][slot] >> 3) == colour) w |= 1u << (8 * b);
+		}
+		s_near[a][d] = w;
+	}
+	__syncthreads();
 	const int lane = threadIdx.x & 63;
-	const uint32_t *sol = reinterpret_cast<const uint32_t *>(D_TAB.solved686);
 	const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
 	const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
-	for (size_t r = wave; r < n; r += nwaves) {
-		const uint32_t *s = states + r * 72;
-		bool diff = s[lane] != sol[lane];
-		if (lane < 8) diff |= s[64 + lane] != sol[64 + lane];
-		const bool ok = __ballot(diff) == 0ull;
-		if (lane == 0) {
-			if (flags != nullptr) flags[r] = ok ? 1 : 0;
-			if (ok && stats != nullptr) {
+	for (size_t p = wave; p < n; p += nwaves) {
+		const uint32_t *s = parents + p * 72;
+		const uint32_t v0 = s[lane];
+		const uint32_t v1 = lane < 8 ? s[64 + lane] : 0u;
+		uint32_t mine = 0;                               // lane a < 12 ends up with flag a
+		#pragma unroll
+		for (int a = 0; a < N_ACTIONS; a++) {
+			bool diff = v0 != s_near[a][lane];
+			if (lane < 8) diff |= v1 != s_near[a][64 + lane];
+			const bool ok = __ballot(diff) == 0ull;
+			if (lane == a) mine = ok ? 1u : 0u;
+		}
+		if (lane < 12) {
+			if (flags != nullptr) flags[p * 12 + lane] = (uint8_t)mine;
+			if (mine && stats != nullptr) {
 				atomicAdd(reinterpret_cast<unsigned long long *>(&stats[0]), 1ull);
-				atomicMin(&stats[1], (long long)r);
+				atomicMin(&stats[1], (long long)(p * 12 + lane));
+			}
+		}
+	}
+}
+
+// goal test of 288-byte states: a workgroup takes 128 states per step, every thread compares nine 16-byte chunks
+// (coalesced) with the solved pattern's chunk and leaves a mismatch byte in LDS; 128 threads then fold 18 bytes each.
+__global__ __launch_bounds__(256)
+void k_is_solved686(const u32x4 *__restrict__ states, uint8_t *__restrict__ flags, long long *__restrict__ stats, size_t n)
+{
+	constexpr int GROUP = 128;
+	__shared__ u32x4 s_sol[18];
+	__shared__ uint8_t s_bad[GROUP * 18];
+	if (threadIdx.x < 18) {
+		const uint32_t *src = reinterpret_cast<const uint32_t *>(D_TAB.solved686) + 4 * threadIdx.x;
+		s_sol[threadIdx.x] = u32x4{src[0], src[1], src[2], src[3]};
+	}
+	const size_t n_groups = (n + GROUP - 1) / GROUP;
+	for (size_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+		const size_t first = g * GROUP;
+		const int ng = (int)((n - first < (size_t)GROUP) ? (n - first) : (size_t)GROUP);
+		__syncthreads();
+		const u32x4 *src = states + first * 18;
+		for (int q = threadIdx.x; q < ng * 18; q += 256) {
+			const u32x4 v = src[q], w = s_sol[q % 18];
+			s_bad[q] = (uint8_t)(((v.x ^ w.x) | (v.y ^ w.y) | (v.z ^ w.z) | (v.w ^ w.w)) != 0u);
+		}
+		__syncthreads();
+		if ((int)threadIdx.x < ng) {
+			uint32_t bad = 0;
+			#pragma unroll
+			for (int k = 0; k < 18; k++) bad |= s_bad[threadIdx.x * 18 + k];
+			if (flags != nullptr) flags[first + threadIdx.x] = bad ? 0 : 1;
+			if (!bad && stats != nullptr) {
+				atomicAdd(reinterpret_cast<unsigned long long *>(&stats[0]), 1ull);
+				atomicMin(&stats[1], (long long)(first + threadIdx.x));
 			}
 		}
 	}
@@ -594,17 +674,26 @@ void launch_as_oh(const int8_t *states, void *out, int out_dtype, size_t n, hipS
 
 void launch_rotate686(const int8_t *states, const uint8_t *actions, int8_t *out, size_t n_out, bool fanout, hipStream_t st)
 {
-	const unsigned grid = grid_for(n_out * 144, 256, 256u * 16u);
-	if (fanout)
-		hipLaunchKernelGGL(k_rotate686<true>, dim3(grid), dim3(256), 0, st, (const uint16_t *)states, actions, (uint16_t *)out, n_out);
-	else
-		hipLaunchKernelGGL(k_rotate686<false>, dim3(grid), dim3(256), 0, st, (const uint16_t *)states, actions, (uint16_t *)out, n_out);
+	if (fanout) {
+		const size_t n_in = n_out / 12;
+		const unsigned grid = grid_for(n_in, 16, 1u << 20);
+		hipLaunchKernelGGL(k_rotate686<true>, dim3(grid), dim3(256), 0, st, (const uint16_t *)states, actions, (u32x4 *)out, n_in);
+	} else {
+		const unsigned grid = grid_for(n_out, 64, 1u << 20);
+		hipLaunchKernelGGL(k_rotate686<false>, dim3(grid), dim3(256), 0, st, (const uint16_t *)states, actions, (u32x4 *)out, n_out);
+	}
+}
+
+void launch_fanout_flags686(const int8_t *parents, uint8_t *flags, long long *stats, size_t n, hipStream_t st)
+{
+	const unsigned grid = grid_for(n, 4, 256u * 8u);
+	hipLaunchKernelGGL(k_fanout_flags686, dim3(grid), dim3(256), 0, st, (const uint32_t *)parents, flags, stats, n);
 }
 
 void launch_is_solved686(const int8_t *states, uint8_t *flags, long long *stats, size_t n, hipStream_t st)
 {
-	const unsigned grid = grid_for(n, 4, 256u * 8u);
-	hipLaunchKernelGGL(k_is_solved686, dim3(grid), dim3(256), 0, st, (const uint32_t *)states, flags, stats, n);
+	const unsigned grid = grid_for(n, 128, 1u << 20);
+	hipLaunchKernelGGL(k_is_solved686, dim3(grid), dim3(256), 0, st, (const u32x4 *)states, flags, stats, n);
 }
 
 void launch_as_oh686(const int8_t *states, void *out, int out_dtype, size_t n, hipStream_t st)
