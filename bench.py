@@ -109,14 +109,22 @@ def main():
 	if world != args.gpus:
 		if world == 1 and args.gpus > 1:
 			sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-	torch.cuda.set_device(local_rank)
+	# One rank per GPU.  RK_BENCH_BACKEND=gloo is a rehearsal mode for a one-GPU box (several ranks share cuda:0 and
+	# the only collectives -- barrier and the MAX of the elapsed times -- go through the host); the driver uses nccl (= RCCL).
+	backend = os.environ.get("RK_BENCH_BACKEND", "nccl")
+	device_index = local_rank % max(1, torch.cuda.device_count())
+	torch.cuda.set_device(device_index)
 	dist = None
 	if world > 1:
 		import torch.distributed as dist
-		dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+		if backend == "nccl":
+			dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+		else:
+			dist.init_process_group(backend)
+	reduce_device = torch.device("cuda") if backend == "nccl" else torch.device("cpu")
 
 	from librubiks_amd import _ffi, cube
-	_ffi.check(_ffi.lib().rk_init(local_rank))
+	_ffi.check(_ffi.lib().rk_init(device_index))
 
 	parents = make_parents(N_PARENTS, seed=1000 + rank)
 	children = torch.empty((12 * N_PARENTS, 20), dtype=torch.int8, device="cuda")
@@ -143,7 +151,7 @@ def main():
 	fence()
 	elapsed = time.perf_counter() - t0
 
-	elapsed_max = max_over_ranks(elapsed, dist, torch.device("cuda"))
+	elapsed_max = max_over_ranks(elapsed, dist, reduce_device)
 	kernel_ms = ev0.elapsed_time(ev1) / args.steps          # HIP events on the launch stream: back-to-back launches
 
 	# sanity of the timed work: the children of the last step are a real fan-out (spot check on the device)
@@ -161,7 +169,7 @@ def main():
 			"ms_per_step": elapsed_max / args.steps * 1e3,
 			"higher_is_better": True, "scaling": "weak", "vs_baseline": None,
 			"dtype": "u8", "data": "synthetic",
-			"config": {"workload": "configs[1]: 1xMI355X fan-out (12 moves) + is_solved on 1M depth-20 scrambles per GPU, "
+			"config": {"workload": f"configs[1]: {world}xMI355X fan-out (12 moves) + is_solved on 1M depth-20 scrambles per GPU, "
 			                       "device-resident, one rk_expand12 launch per step",
 			           "parents_per_gpu": N_PARENTS, "children_per_step": 12 * N_PARENTS * world,
 			           "parallelism": f"independent batches x{world}"},

@@ -1,7 +1,12 @@
 """
-A/B of the fan-out kernel's shapes on one MI355X (interleaved, same process): non-temporal vs plain stores, 256- vs
-64-parent wave tiles, static vs dynamically scheduled persistent grid.  Every variant's output is checked against the
-shipping kernel's.  Uses the tuning hook rkx_expand12_variant (not part of the public C ABI).
+A/B of the fan-out kernel's shapes on one MI355X (interleaved, same process).  Every variant's output is checked
+against the shipping kernel's; outputs rotate over 6 buffer sets (1.5 GB) so that nothing written stays in the
+256 MiB Infinity Cache between launches -- the fair test for cached (plain) vs streaming (non-temporal) stores.
+Uses the tuning hook rkx_expand12_variant (not part of the public C ABI).
+
+Findings of round 1 (profiles/r01_tune_expand*.json): plain stores win only when the same 252 MB output is rewritten
+in place (Infinity-Cache hits, 41.6 us) and lose when outputs rotate (49.9 us); non-temporal stores with 64-parent
+tiles run at 44.5 us either way; an atomic tile counter on a persistent grid is 2-5x slower.
 """
 import ctypes as C
 import json
@@ -18,71 +23,48 @@ lib = _ffi.lib()
 lib.rkx_expand12_variant.restype = C.c_int
 lib.rkx_expand12_variant.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]
 
+NAMES = {0: "nt, tile256", 1: "plain, tile256", 2: "nt, tile64", 3: "plain, tile64",
+         16: "nt, tile64, 4 waves/WG (shipping)", 17: "nt, tile64, 2 waves/WG", 18: "nt, tile64, 8 waves/WG", 19: "nt, tile64, 1 wave/WG",
+         20: "nt, tile64, 4 waves/WG, direct input loads", 21: "nt, tile64, 2 waves/WG, direct input loads",
+         22: "nt, tile64, 8 waves/WG, direct input loads", 23: "nt, tile64, 1 wave/WG, direct input loads"}
 
-def main():
+
+def main(variants):
 	_ffi.check(lib.rk_init(0))
 	g = torch.Generator(device="cuda")
 	g.manual_seed(1)
 	acts = torch.randint(0, 12, (20, N), device="cuda", dtype=torch.uint8, generator=g)
 	parents = cube.device.apply_sequences(acts, False, True)
 	ref_c, ref_f = cube.device.expand12(parents)
-	children = torch.empty_like(ref_c)
-	solved = torch.empty_like(ref_f)
 	counter = torch.zeros(4, dtype=torch.int32, device="cuda")
-	names = {0: "nt, tile256, static", 1: "plain, tile256, static", 2: "nt, tile64, static", 3: "plain, tile64, static",
-	         4: "nt, tile256, dynamic", 5: "plain, tile256, dynamic", 6: "nt, tile64, dynamic", 7: "plain, tile64, dynamic"}
-	configs = [(v, 0) for v in (0, 1, 2, 3)]
-
-	def run(v, gb):
-		_ffi.check(lib.rkx_expand12_variant(v, parents.data_ptr(), children.data_ptr(), solved.data_ptr(), None, N, counter.data_ptr(), gb,
-		                                    _ffi.stream_ptr()))
-
-	results = {}
-	for v, gb in configs:
-		children.zero_(); solved.fill_(9)
-		run(v, gb)
-		ok = torch.equal(children, ref_c) and torch.equal(solved, ref_f)
-		results[(v, gb)] = {"variant": names[v], "grid_blocks": gb or "auto", "correct": bool(ok), "ms": []}
-	for rep in range(5):                       # interleaved repetitions
-		for v, gb in configs:
-			for _ in range(5):
-				run(v, gb)
-			e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-			e0.record()
-			for _ in range(40):
-				run(v, gb)
-			e1.record()
-			torch.cuda.synchronize()
-			results[(v, gb)]["ms"].append(e0.elapsed_time(e1) / 40)
-	# the same with the output rotating over 6 buffer sets (1.5 GB of children: nothing written stays in the 256 MiB
-	# Infinity Cache between launches) -- the fair test for cached (plain) vs streaming (non-temporal) stores
 	bufs = [(torch.empty_like(ref_c), torch.empty_like(ref_f)) for _ in range(6)]
-	for v, gb in [(0, 0), (1, 0), (2, 0), (3, 0)]:
-		def run_rot(i):
-			c, f = bufs[i % 6]
-			_ffi.check(lib.rkx_expand12_variant(v, parents.data_ptr(), c.data_ptr(), f.data_ptr(), None, N, counter.data_ptr(), gb, _ffi.stream_ptr()))
-		times = []
-		for rep in range(5):
+
+	def run(v, i):
+		c, f = bufs[i % 6]
+		_ffi.check(lib.rkx_expand12_variant(v, parents.data_ptr(), c.data_ptr(), f.data_ptr(), None, N, counter.data_ptr(), 0, _ffi.stream_ptr()))
+
+	res = {}
+	for v in variants:
+		bufs[0][0].zero_(); bufs[0][1].fill_(9)
+		run(v, 0)
+		res[v] = {"variant": NAMES[v], "correct": bool(torch.equal(bufs[0][0], ref_c) and torch.equal(bufs[0][1], ref_f)), "ms": []}
+	for rep in range(7):
+		for v in variants:
 			for i in range(6):
-				run_rot(i)
+				run(v, i)
 			e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 			e0.record()
 			for i in range(42):
-				run_rot(i)
+				run(v, i)
 			e1.record()
 			torch.cuda.synchronize()
-			times.append(e0.elapsed_time(e1) / 42)
-		ms = sorted(times)[2]
-		print(json.dumps({"variant": names[v] + ", ROTATING 6 output buffers", "ms_median": ms, "GB/s": round(272e6 / (ms * 1e-3) / 1e9, 1),
-		                  "frac_of_8TBs": round(272e6 / (ms * 1e-3) / 1e9 / 8000, 4)}), flush=True)
-	for r in results.values():
+			res[v]["ms"].append(round(e0.elapsed_time(e1) / 42, 5))
+	for v in variants:
+		r = res[v]
 		ms = sorted(r["ms"])[len(r["ms"]) // 2]
-		r["ms_median"] = ms
-		r["GB/s"] = round(272e6 / (ms * 1e-3) / 1e9, 1)
-		r["frac_of_8TBs"] = round(r["GB/s"] / 8000, 4)
-		r["ms"] = [round(x, 5) for x in r["ms"]]
+		r.update(ms_median=ms, **{"GB/s": round(272e6 / (ms * 1e-3) / 1e9, 1), "frac_of_8TBs": round(272e6 / (ms * 1e-3) / 8e12, 4)})
 		print(json.dumps(r), flush=True)
 
 
 if __name__ == "__main__":
-	main()
+	main([int(x) for x in sys.argv[1:]] or [16, 17, 18, 19, 20, 21, 22, 23, 0, 1])

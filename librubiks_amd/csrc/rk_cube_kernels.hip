@@ -27,7 +27,7 @@ namespace rk {
 //      the wave then streams the 15 360 B out as fifteen 1 KiB global_store_dwordx4.
 // ================================================================================================================
 constexpr int EXP_ROUND = 64;                  // parents per round (one per lane)
-constexpr int EXP_WAVES = 4;                   // waves per workgroup
+constexpr int EXP_WAVES = 4;                   // waves per workgroup of the shipping shape
 
 struct ExpandWaveLds {
 	u32x4    stage[EXP_ROUND * 15];            // 15 360 B: children of one round; first 5 120 B double as input staging
@@ -35,13 +35,16 @@ struct ExpandWaveLds {
 };
 
 // ROUNDS = rounds of 64 parents per wave tile (4 -> 256-parent tiles with 16 B/lane input loads, 1 -> 64-parent tiles);
-// NT = non-temporal output stores; DYNAMIC = tiles handed out by an atomic counter to a persistent grid.
-template <bool WITH_FLAGS, int ROUNDS = 4, bool NT = true, bool DYNAMIC = false>
-__global__ __launch_bounds__(EXP_WAVES * WAVE)
+// NT = non-temporal output stores; DYNAMIC = tiles handed out by an atomic counter to a persistent grid;
+// NWAVES = waves per workgroup; DIRECT_IN = each lane loads its own parent's five dwords straight from global memory
+// (stride 20 B across lanes, the lines are shared through L1) instead of the coalesced-load + LDS transpose.
+template <bool WITH_FLAGS, int ROUNDS = 4, bool NT = true, bool DYNAMIC = false, int NWAVES = EXP_WAVES, bool DIRECT_IN = false>
+__global__ __launch_bounds__(NWAVES * WAVE)
 void k_expand12(const uint32_t *__restrict__ parents, u32x4 *__restrict__ children, uint32_t *__restrict__ solved,
                 long long *__restrict__ stats, size_t n, size_t n_tiles, unsigned int *__restrict__ tile_counter = nullptr)
 {
 	constexpr int EXP_TILE = EXP_ROUND * ROUNDS;
+	constexpr int EXP_WAVES = NWAVES;
 	__shared__ u32x4 s_rows[48];
 	__shared__ ExpandWaveLds s_wave[EXP_WAVES];
 
@@ -70,7 +73,14 @@ void k_expand12(const uint32_t *__restrict__ parents, u32x4 *__restrict__ childr
 		uint32_t par[ROUNDS][5];
 		{
 			const uint32_t *src = parents + p0 * STATE_DWORDS;
-			if (ROUNDS == 4 && np == EXP_TILE && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+			if (DIRECT_IN) {
+				#pragma unroll
+				for (int q = 0; q < ROUNDS; q++) {
+					const int local = q * 64 + lane;
+					#pragma unroll
+					for (int j = 0; j < 5; j++) par[q][j] = local < np ? src[local * 5 + j] : 0u;
+				}
+			} else if (ROUNDS == 4 && np == EXP_TILE && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
 				const u32x4 *src4 = reinterpret_cast<const u32x4 *>(src);
 				#pragma unroll
 				for (int k = 0; k < 5; k++) L.stage[k * 64 + lane] = src4[k * 64 + lane];
@@ -82,12 +92,14 @@ void k_expand12(const uint32_t *__restrict__ parents, u32x4 *__restrict__ childr
 					stage_dw[idx] = idx < ndw ? src[idx] : 0u;
 				}
 			}
-			wave_lds_fence();
-			#pragma unroll
-			for (int q = 0; q < ROUNDS; q++)
+			if (!DIRECT_IN) {
+				wave_lds_fence();
 				#pragma unroll
-				for (int j = 0; j < 5; j++) par[q][j] = stage_dw[(q * 64 + lane) * 5 + j];
-			wave_lds_fence();
+				for (int q = 0; q < ROUNDS; q++)
+					#pragma unroll
+					for (int j = 0; j < 5; j++) par[q][j] = stage_dw[(q * 64 + lane) * 5 + j];
+				wave_lds_fence();
+			}
 		}
 
 		#pragma unroll
@@ -596,26 +608,33 @@ static inline unsigned grid_for(size_t work_items, size_t per_block, unsigned ca
 	return (unsigned)b;
 }
 
-// tuning aid (benchmarks/tune_expand.py): the same kernel in its other shapes.  variant bits: 1 = plain stores,
-// 2 = 64-parent tiles, 4 = persistent grid with a dynamic tile counter (needs a zeroed uint32 at `counter`).
+// tuning aid (benchmarks/tune_expand.py): the same kernel in its other shapes.
+//   variant 0..7   : bit 0 = plain stores, bit 1 = 64-parent tiles, bit 2 = persistent grid + atomic tile counter
+//   variant 16..23 : 64-parent tiles, non-temporal; bits 0-1 = waves per workgroup {4, 2, 8, 1}, bit 2 = direct input loads
 void launch_expand12_variant(int variant, const int8_t *parents, int8_t *children, uint8_t *solved, long long *stats, size_t n,
                              unsigned int *counter, int grid_blocks, hipStream_t st)
 {
-	const bool small = variant & 2;
-	const size_t n_tiles = small ? (n + 63) / 64 : (n + 255) / 256;
-	unsigned grid = grid_for(n_tiles, EXP_WAVES, 1u << 20);
-	if (grid_blocks > 0) grid = (unsigned)grid_blocks;
-	#define RK_LAUNCH(R, NTS, DYN) hipLaunchKernelGGL((k_expand12<true, R, NTS, DYN>), dim3(grid), dim3(EXP_WAVES * WAVE), 0, st, \
-		(const uint32_t *)parents, (u32x4 *)children, (uint32_t *)solved, stats, n, n_tiles, counter)
-	switch (variant & 7) {
-		case 0: RK_LAUNCH(4, true, false); break;
-		case 1: RK_LAUNCH(4, false, false); break;
-		case 2: RK_LAUNCH(1, true, false); break;
-		case 3: RK_LAUNCH(1, false, false); break;
-		case 4: RK_LAUNCH(4, true, true); break;
-		case 5: RK_LAUNCH(4, false, true); break;
-		case 6: RK_LAUNCH(1, true, true); break;
-		default: RK_LAUNCH(1, false, true); break;
+	#define RK_LAUNCH(R, NTS, DYN, W, DIN) do { \
+		const size_t n_tiles = (n + 64 * (R) - 1) / (64 * (R)); \
+		unsigned grid = grid_for(n_tiles, (W), 1u << 20); \
+		if (grid_blocks > 0) grid = (unsigned)grid_blocks; \
+		hipLaunchKernelGGL((k_expand12<true, R, NTS, DYN, W, DIN>), dim3(grid), dim3((W) * WAVE), 0, st, \
+			(const uint32_t *)parents, (u32x4 *)children, (uint32_t *)solved, stats, n, n_tiles, counter); } while (0)
+	switch (variant) {
+		case 0: RK_LAUNCH(4, true, false, 4, false); break;
+		case 1: RK_LAUNCH(4, false, false, 4, false); break;
+		case 2: RK_LAUNCH(1, true, false, 4, false); break;
+		case 3: RK_LAUNCH(1, false, false, 4, false); break;
+		case 4: RK_LAUNCH(4, true, true, 4, false); break;
+		case 6: RK_LAUNCH(1, true, true, 4, false); break;
+		case 16: RK_LAUNCH(1, true, false, 4, false); break;
+		case 17: RK_LAUNCH(1, true, false, 2, false); break;
+		case 18: RK_LAUNCH(1, true, false, 8, false); break;
+		case 19: RK_LAUNCH(1, true, false, 1, false); break;
+		case 20: RK_LAUNCH(1, true, false, 4, true); break;
+		case 21: RK_LAUNCH(1, true, false, 2, true); break;
+		case 22: RK_LAUNCH(1, true, false, 8, true); break;
+		default: RK_LAUNCH(1, true, false, 1, true); break;
 	}
 	#undef RK_LAUNCH
 }
