@@ -26,7 +26,9 @@ lib.rkx_expand12_variant.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p
 NAMES = {0: "nt, tile256", 1: "plain, tile256", 2: "nt, tile64", 3: "plain, tile64",
          16: "nt, tile64, 4 waves/WG (shipping)", 17: "nt, tile64, 2 waves/WG", 18: "nt, tile64, 8 waves/WG", 19: "nt, tile64, 1 wave/WG",
          20: "nt, tile64, 4 waves/WG, direct input loads", 21: "nt, tile64, 2 waves/WG, direct input loads",
-         22: "nt, tile64, 8 waves/WG, direct input loads", 23: "nt, tile64, 1 wave/WG, direct input loads"}
+         22: "nt, tile64, 8 waves/WG, direct input loads", 23: "nt, tile64, 1 wave/WG, direct input loads",
+         24: "nt, tile64, 4 waves/WG, parents preloaded before the table barrier", 25: "nt, tile64, 2 waves/WG, preload",
+         26: "nt, tile256, 4 waves/WG, preload"}
 
 
 def main(variants):

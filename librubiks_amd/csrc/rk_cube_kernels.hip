@@ -38,7 +38,10 @@ struct ExpandWaveLds {
 // NT = non-temporal output stores; DYNAMIC = tiles handed out by an atomic counter to a persistent grid;
 // NWAVES = waves per workgroup; DIRECT_IN = each lane loads its own parent's five dwords straight from global memory
 // (stride 20 B across lanes, the lines are shared through L1) instead of the coalesced-load + LDS transpose.
-template <bool WITH_FLAGS, int ROUNDS = 4, bool NT = true, bool DYNAMIC = false, int NWAVES = EXP_WAVES, bool DIRECT_IN = false>
+// PRELOAD = issue the first tile's parent loads before the move table is staged and the workgroup barrier, so that the
+// two global-memory latencies at the start of a workgroup's life overlap instead of adding up.
+template <bool WITH_FLAGS, int ROUNDS = 4, bool NT = true, bool DYNAMIC = false, int NWAVES = EXP_WAVES, bool DIRECT_IN = false,
+          bool PRELOAD = false>
 __global__ __launch_bounds__(NWAVES * WAVE)
 void k_expand12(const uint32_t *__restrict__ parents, u32x4 *__restrict__ children, uint32_t *__restrict__ solved,
                 long long *__restrict__ stats, size_t n, size_t n_tiles, unsigned int *__restrict__ tile_counter = nullptr)
@@ -49,6 +52,21 @@ void k_expand12(const uint32_t *__restrict__ parents, u32x4 *__restrict__ childr
 	__shared__ ExpandWaveLds s_wave[EXP_WAVES];
 
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	size_t tile = (size_t)blockIdx.x * EXP_WAVES + wv;
+	static_assert(!PRELOAD || (!DYNAMIC && !DIRECT_IN), "PRELOAD is for the statically scheduled LDS-transpose input path");
+	uint32_t pre[5 * ROUNDS];
+	bool have_pre = false;
+	if (PRELOAD && tile < n_tiles) {
+		const size_t p0 = tile * EXP_TILE;
+		const int ndw = (int)((n - p0 < (size_t)EXP_TILE) ? (n - p0) : (size_t)EXP_TILE) * STATE_DWORDS;
+		const uint32_t *src = parents + p0 * STATE_DWORDS;
+		#pragma unroll
+		for (int k = 0; k < 5 * ROUNDS; k++) {
+			const int idx = k * 64 + lane;
+			pre[k] = idx < ndw ? src[idx] : 0u;
+		}
+		have_pre = true;
+	}
 	if (tid < 48) {
 		const uint32_t *src = reinterpret_cast<const uint32_t *>(D_TAB.rows) + 4 * tid;
 		s_rows[tid] = u32x4{src[0], src[1], src[2], src[3]};
@@ -58,7 +76,6 @@ void k_expand12(const uint32_t *__restrict__ parents, u32x4 *__restrict__ childr
 	ExpandWaveLds &L = s_wave[wv];
 	uint32_t *stage_dw = reinterpret_cast<uint32_t *>(L.stage);
 
-	size_t tile = (size_t)blockIdx.x * EXP_WAVES + wv;
 	for (;;) {
 		if (DYNAMIC) {
 			unsigned int t = 0;
@@ -80,6 +97,10 @@ void k_expand12(const uint32_t *__restrict__ parents, u32x4 *__restrict__ childr
 					#pragma unroll
 					for (int j = 0; j < 5; j++) par[q][j] = local < np ? src[local * 5 + j] : 0u;
 				}
+			} else if (PRELOAD && have_pre) {
+				#pragma unroll
+				for (int k = 0; k < 5 * ROUNDS; k++) stage_dw[k * 64 + lane] = pre[k];
+				have_pre = false;
 			} else if (ROUNDS == 4 && np == EXP_TILE && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
 				const u32x4 *src4 = reinterpret_cast<const u32x4 *>(src);
 				#pragma unroll
@@ -611,14 +632,16 @@ static inline unsigned grid_for(size_t work_items, size_t per_block, unsigned ca
 // tuning aid (benchmarks/tune_expand.py): the same kernel in its other shapes.
 //   variant 0..7   : bit 0 = plain stores, bit 1 = 64-parent tiles, bit 2 = persistent grid + atomic tile counter
 //   variant 16..23 : 64-parent tiles, non-temporal; bits 0-1 = waves per workgroup {4, 2, 8, 1}, bit 2 = direct input loads
+//   variant 24..26 : parent loads issued before the table barrier (PRELOAD): tile64 x 4 waves, tile64 x 2 waves, tile256 x 4 waves
 void launch_expand12_variant(int variant, const int8_t *parents, int8_t *children, uint8_t *solved, long long *stats, size_t n,
                              unsigned int *counter, int grid_blocks, hipStream_t st)
 {
-	#define RK_LAUNCH(R, NTS, DYN, W, DIN) do { \
+	#define RK_LAUNCH(R, NTS, DYN, W, DIN) RK_LAUNCH2(R, NTS, DYN, W, DIN, false)
+	#define RK_LAUNCH2(R, NTS, DYN, W, DIN, PRE) do { \
 		const size_t n_tiles = (n + 64 * (R) - 1) / (64 * (R)); \
 		unsigned grid = grid_for(n_tiles, (W), 1u << 20); \
 		if (grid_blocks > 0) grid = (unsigned)grid_blocks; \
-		hipLaunchKernelGGL((k_expand12<true, R, NTS, DYN, W, DIN>), dim3(grid), dim3((W) * WAVE), 0, st, \
+		hipLaunchKernelGGL((k_expand12<true, R, NTS, DYN, W, DIN, PRE>), dim3(grid), dim3((W) * WAVE), 0, st, \
 			(const uint32_t *)parents, (u32x4 *)children, (uint32_t *)solved, stats, n, n_tiles, counter); } while (0)
 	switch (variant) {
 		case 0: RK_LAUNCH(4, true, false, 4, false); break;
@@ -634,9 +657,13 @@ void launch_expand12_variant(int variant, const int8_t *parents, int8_t *childre
 		case 20: RK_LAUNCH(1, true, false, 4, true); break;
 		case 21: RK_LAUNCH(1, true, false, 2, true); break;
 		case 22: RK_LAUNCH(1, true, false, 8, true); break;
+		case 24: RK_LAUNCH2(1, true, false, 4, false, true); break;
+		case 25: RK_LAUNCH2(1, true, false, 2, false, true); break;
+		case 26: RK_LAUNCH2(4, true, false, 4, false, true); break;
 		default: RK_LAUNCH(1, true, false, 1, true); break;
 	}
 	#undef RK_LAUNCH
+	#undef RK_LAUNCH2
 }
 
 // Shipping shape (benchmarks/tune_expand.py, profiles/r01_tune_expand.json): 64-parent wave tiles + non-temporal

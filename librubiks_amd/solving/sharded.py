@@ -44,20 +44,23 @@ OFFER_BYTES = 16        # shortcut offer
 class Transport:
 	"""The collectives the search needs, over torch.distributed (or nothing when world == 1)."""
 
-	def __init__(self, group=None):
+	def __init__(self, group=None, force_collectives: bool = False):
 		self.group = group
 		self.active = dist.is_available() and dist.is_initialized()
 		self.world = dist.get_world_size(group) if self.active else 1
 		self.rank = dist.get_rank(group) if self.active else 0
 		self.backend = dist.get_backend(group) if self.active else "local"
 		self.on_device = self.backend == "nccl"
+		# world == 1 normally short-circuits every collective; `force_collectives` runs them anyway, which is how the
+		# nccl (RCCL) code path -- device tensors, variable-size all_to_all_single -- is exercised on a one-GPU box
+		self.shortcut = self.world == 1 and not (force_collectives and self.active)
 
 	def _dev(self):
 		return gpu if self.on_device else torch.device("cpu")
 
 	def all_gather_vec(self, vec: np.ndarray) -> np.ndarray:
 		"""(world, len(vec)) array of every rank's float64 vector."""
-		if self.world == 1:
+		if self.shortcut:
 			return vec[None].copy()
 		mine = torch.from_numpy(np.ascontiguousarray(vec, dtype=np.float64)).to(self._dev())
 		if self.on_device:
@@ -69,7 +72,7 @@ class Transport:
 		return torch.stack(parts).numpy()
 
 	def exchange_counts(self, send_counts: np.ndarray) -> np.ndarray:
-		if self.world == 1:
+		if self.shortcut:
 			return send_counts.copy()
 		s = torch.from_numpy(np.ascontiguousarray(send_counts, dtype=np.int64)).to(self._dev())
 		r = torch.empty_like(s)
@@ -78,7 +81,7 @@ class Transport:
 
 	def exchange_records(self, send: torch.Tensor, send_counts: np.ndarray, recv_counts: np.ndarray) -> torch.Tensor:
 		"""send: (n, width) uint8 on the GPU grouped by destination; returns (m, width) uint8 on the GPU grouped by source."""
-		if self.world == 1:
+		if self.shortcut:
 			return send[:int(send_counts[0])]
 		width = send.shape[1]
 		n_out, n_in = int(send_counts.sum()), int(recv_counts.sum())
@@ -90,7 +93,7 @@ class Transport:
 		return dst if self.on_device else dst.to(gpu)
 
 	def broadcast_vec(self, vec: np.ndarray, src: int) -> np.ndarray:
-		if self.world == 1:
+		if self.shortcut:
 			return vec
 		t = torch.from_numpy(np.ascontiguousarray(vec, dtype=np.int64)).to(self._dev())
 		dist.broadcast(t, src=dist.get_global_rank(self.group, src) if self.group is not None else src, group=self.group)
@@ -116,10 +119,10 @@ def select_pops(heads: np.ndarray, n: int) -> np.ndarray:
 class ShardedAStar(DeepAgent):
 	"""Collective agent: every rank constructs it and calls `search` with the same arguments."""
 
-	def __init__(self, net, lambda_: float, expansions: int, capacity: int = 2_000_000, group=None):
+	def __init__(self, net, lambda_: float, expansions: int, capacity: int = 2_000_000, group=None, force_collectives: bool = False):
 		super().__init__(net)
 		self.lambda_, self.expansions, self.capacity = lambda_, int(expansions), int(capacity)
-		self.tp = Transport(group)
+		self.tp = Transport(group, force_collectives)
 		self._h = None
 		self.iterations = 0
 		self.total_states = 0

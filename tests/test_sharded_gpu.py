@@ -123,3 +123,38 @@ def test_multi_rank_on_one_gpu(world, tmp_path):
 		assert total == int(first[0]["total"]) and start.tobytes() in seen
 		assert total <= budget
 	assert n_solved >= 3
+
+
+def _nccl_world1(rank, port, out_path, case):
+	"""One rank, nccl backend, collectives forced: the RCCL transport (device tensors, variable-size all_to_all_single,
+	all_gather_into_tensor, broadcast) carries a whole search."""
+	import torch.distributed as dist
+	os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+	torch.cuda.set_device(0)
+	dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+	try:
+		seed, depth, lam, n, budget = case
+		np.random.seed(seed)
+		start, _, _ = orc.scramble(depth, True)
+		agent = ShardedAStar(StubNet(), lam, n, capacity=budget + 16, force_collectives=True)
+		assert agent.tp.backend == "nccl" and agent.tp.on_device and not agent.tp.shortcut
+		solved = agent.search(start, None, budget)
+		states, G, parents, pact = agent.local_arrays()
+		np.savez(out_path, solved=solved, states=states[1:], G=G[1:], parents=parents[2:], pact=pact[2:], queue=np.array(agent.action_queue, dtype=np.int64))
+	finally:
+		dist.destroy_process_group()
+
+
+def test_rccl_transport_world1(tmp_path):
+	case = (19, 7, 0.1, 300, 60_000)
+	out = str(tmp_path / "nccl.npz")
+	mp.spawn(_nccl_world1, args=(_free_port(), out, case), nprocs=1, join=True)
+	z = np.load(out)
+	seed, depth, lam, n, budget = case
+	np.random.seed(seed)
+	start, _, _ = orc.scramble(depth, True)
+	ref = AStarOracle(StubNet(), lam, n)
+	assert ref.search(start, budget) == bool(z["solved"])
+	rs, rG, rp, ra = ref.arrays()
+	assert (z["states"] == rs).all() and (z["G"] == rG).all() and (z["parents"] == rp).all() and (z["pact"] == ra).all()
+	assert z["queue"].tolist() == list(ref.action_queue)
