@@ -147,42 +147,83 @@ __global__ void k_astar_lookup(const uint32_t *children, int stride, int K, cons
 	}
 }
 
-// first_unseen / first_seen flags and the exclusive scan of first_unseen (= rank among the new states).
-// One workgroup walks the batch in chunks of 1024; K is a few thousand in the reference's configurations.
-__global__ __launch_bounds__(1024)
-void k_astar_flags_scan(int K, const uint32_t *table, const uint32_t *mark, const int32_t *seen, const uint32_t *child_slot,
-                        uint8_t *flags, int32_t *rank, long long *counters)
+// ---- order-preserving compaction across many workgroups ---------------------------------------------------------
+// Three small launches: (1) per-1024-element workgroup: predicate, rank inside the workgroup, workgroup total;
+// (2) one workgroup scans the totals; (3) the consumer adds the workgroup's offset to the local rank.
+constexpr int SCAN_BLOCK = 1024;
+
+// exclusive prefix of a 0/1 predicate inside a 1024-thread workgroup; *total = number of set predicates
+__device__ __forceinline__ int block_rank(bool pred, int *s_wave /* [16] */, int *total)
+{
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const unsigned long long b = __ballot(pred);
+	const int in_wave = __popcll(b & ((1ull << lane) - 1ull));
+	__syncthreads();                                  // s_wave may still be read from a previous call
+	if (lane == 0) s_wave[wv] = __popcll(b);
+	__syncthreads();
+	int before = 0, tot = 0;
+	#pragma unroll
+	for (int w = 0; w < 16; w++) {
+		const int v = s_wave[w];
+		before += w < wv ? v : 0;
+		tot += v;
+	}
+	*total = tot;
+	return before + in_wave;
+}
+
+// first_unseen / first_seen flags (agents.py:291-295) and the rank of every first_unseen child inside its workgroup
+__global__ __launch_bounds__(SCAN_BLOCK)
+void k_astar_flags(int K, const uint32_t *table, const uint32_t *mark, const int32_t *seen, const uint32_t *child_slot,
+                   uint8_t *flags, int32_t *rank, int32_t *block_sums)
+{
+	__shared__ int s_wave[16];
+	const int c = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+	int fu = 0, fs = 0;
+	if (c < K) {
+		const int32_t sidx = seen[c];
+		if (sidx == 0) fu = table[child_slot[c]] == (TENT | (uint32_t)c);
+		else fs = mark[sidx] == (uint32_t)c;
+		flags[c] = (uint8_t)(fu | (fs << 1));
+	}
+	int total;
+	const int r = block_rank(fu != 0, s_wave, &total);
+	if (c < K) rank[c] = r;
+	if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// exclusive scan of `n` workgroup totals in place (one workgroup); the grand total goes to *out_total
+__global__ __launch_bounds__(SCAN_BLOCK)
+void k_scan_blocks(int32_t *sums, int n, long long *out_total)
 {
 	__shared__ int s_wave[16];
 	__shared__ int s_base;
-	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-	if (tid == 0) s_base = 0;
+	if (threadIdx.x == 0) s_base = 0;
 	__syncthreads();
-	for (int c0 = 0; c0 < K; c0 += 1024) {
-		const int c = c0 + tid;
-		int fu = 0, fs = 0;
-		if (c < K) {
-			const int32_t sidx = seen[c];
-			if (sidx == 0) fu = table[child_slot[c]] == (TENT | (uint32_t)c);
-			else fs = mark[sidx] == (uint32_t)c;
-			flags[c] = (uint8_t)(fu | (fs << 1));
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	for (int i0 = 0; i0 < n; i0 += SCAN_BLOCK) {
+		const int i = i0 + threadIdx.x;
+		const int v = i < n ? sums[i] : 0;
+		int incl = v;                                  // inclusive scan inside the wave
+		#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const int o = __shfl_up(incl, d, 64);
+			if (lane >= d) incl += o;
 		}
-		const unsigned long long b = __ballot(fu);
-		const int in_wave = __popcll(b & ((1ull << lane) - 1ull));
-		if (lane == 0) s_wave[wv] = __popcll(b);
+		if (lane == 63) s_wave[wv] = incl;
 		__syncthreads();
 		int before = s_base;
 		for (int w = 0; w < wv; w++) before += s_wave[w];
-		if (c < K) rank[c] = before + in_wave;
+		if (i < n) sums[i] = before + incl - v;
 		__syncthreads();
-		if (tid == 0) {
+		if (threadIdx.x == 0) {
 			int tot = 0;
 			for (int w = 0; w < 16; w++) tot += s_wave[w];
 			s_base += tot;
 		}
 		__syncthreads();
 	}
-	if (tid == 0) counters[CTR_NEW] = s_base;
+	if (threadIdx.x == 0 && out_total != nullptr) *out_total = s_base;
 }
 
 // append the new states (agents.py:299-313), finalise their hash slots, goal test of the new states
@@ -192,7 +233,7 @@ void k_astar_flags_scan(int K, const uint32_t *table, const uint32_t *mark, cons
 //                  received from the ranks that expanded them; the parent lives on rank parent_rank.
 template <bool SHARDED>
 __global__ void k_astar_append(const uint32_t *children, const uint8_t *solved, int K, const uint8_t *flags, const int32_t *rank,
-                               const int32_t *seen, const uint32_t *child_slot, const int32_t *exp_idx, uint32_t n_before,
+                               const int32_t *block_off, const int32_t *seen, const uint32_t *child_slot, const int32_t *exp_idx, uint32_t n_before,
                                uint32_t *states, int32_t *G, int32_t *parents, uint8_t *pact, uint8_t *prank, uint32_t *table,
                                uint8_t *newway, int32_t *val1, long long *counters)
 {
@@ -214,7 +255,7 @@ __global__ void k_astar_append(const uint32_t *children, const uint8_t *solved, 
 		act = (uint8_t)(c % 12);
 	}
 	if (f & 1) {
-		const uint32_t idx = n_before + 1u + (uint32_t)rank[c];
+		const uint32_t idx = n_before + 1u + (uint32_t)(rank[c] + block_off[c / SCAN_BLOCK]);
 		uint32_t s[5];
 		load5(cs, s);
 		#pragma unroll
@@ -385,89 +426,92 @@ __global__ void k_shard_records(const uint32_t *children, int K, const int32_t *
 	owner[c] = (uint8_t)owner_of(s, world);
 }
 
-// stable partition of the K records by owner into `send`; counts[w] = records for rank w.  One workgroup.
-__global__ __launch_bounds__(1024)
-void k_shard_bucket(int K, uint32_t world, const uint32_t *recs, const uint8_t *owner, u32x4 *send, long long *counts)
+// Stable partition of the K records by owner into `send` (batch order inside every bucket), many workgroups:
+// (1) per-workgroup histogram over owners, laid out owner-major [w][block] so that ONE exclusive scan of the whole
+//     array yields, for every (owner, workgroup), the first output slot of that workgroup's records for that owner;
+// (2) k_scan_blocks; (3) scatter: rank among the same-owner records of the workgroup + that offset.
+__global__ __launch_bounds__(SCAN_BLOCK)
+void k_shard_hist(int K, uint32_t world, const uint8_t *owner, int32_t *hist /* [world][n_blocks] */, int n_blocks)
+{
+	__shared__ int s_cnt[256];
+	if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
+	__syncthreads();
+	const int c = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+	if (c < K) atomicAdd(&s_cnt[owner[c]], 1);
+	__syncthreads();
+	if (threadIdx.x < world) hist[(size_t)threadIdx.x * n_blocks + blockIdx.x] = s_cnt[threadIdx.x];
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK)
+void k_shard_scatter(int K, uint32_t world, const uint32_t *recs, const uint8_t *owner, const int32_t *offs /* scanned hist */,
+                     int n_blocks, u32x4 *send, long long *counts)
 {
 	__shared__ int s_wave[16];
-	__shared__ int s_base;
-	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-	if (tid == 0) s_base = 0;
-	__syncthreads();
-	const u32x4 *src = reinterpret_cast<const u32x4 *>(recs);
-	for (uint32_t w = 0; w < world; w++) {
-		const int start = s_base;
-		for (int c0 = 0; c0 < K; c0 += 1024) {
-			const int c = c0 + tid;
-			const bool mine = c < K && owner[c] == w;
-			const unsigned long long b = __ballot(mine);
-			const int in_wave = __popcll(b & ((1ull << lane) - 1ull));
-			if (lane == 0) s_wave[wv] = __popcll(b);
-			__syncthreads();
-			int before = s_base;
-			for (int k = 0; k < wv; k++) before += s_wave[k];
-			if (mine) {
-				send[2 * (size_t)(before + in_wave)] = src[2 * (size_t)c];
-				send[2 * (size_t)(before + in_wave) + 1] = src[2 * (size_t)c + 1];
-			}
-			__syncthreads();
-			if (tid == 0) {
-				int tot = 0;
-				for (int k = 0; k < 16; k++) tot += s_wave[k];
-				s_base += tot;
-			}
-			__syncthreads();
-		}
-		if (tid == 0) counts[w] = s_base - start;
-		__syncthreads();
+	const int c = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+	const uint32_t mine = c < K ? owner[c] : 0xFFFFFFFFu;
+	int dest = -1;
+	for (uint32_t w = 0; w < world; w++) {             // world <= 8 on a node; every round is one ballot per wave
+		int total;
+		const int r = block_rank(mine == w, s_wave, &total);
+		if (mine == w) dest = offs[(size_t)w * n_blocks + blockIdx.x] + r;
+	}
+	if (dest >= 0) {
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(recs);
+		send[2 * (size_t)dest] = src[2 * (size_t)c];
+		send[2 * (size_t)dest + 1] = src[2 * (size_t)c + 1];
+	}
+	// per-owner totals: first slot of the next owner minus first slot of this one
+	if (blockIdx.x == 0 && threadIdx.x < world) {
+		const uint32_t w = threadIdx.x;
+		const long long start = offs[(size_t)w * n_blocks];
+		const long long end = w + 1 < world ? offs[(size_t)(w + 1) * n_blocks] : (long long)K;
+		counts[w] = end - start;
 	}
 }
 
 // receiver side of relaxation case 2: a first-seen child whose own G is at least two below its would-be parent's
-// offers the parent a shortcut.  Candidates keep receive order (= grouped by the rank that sent the child).
+// offers the parent a shortcut.  Offers keep receive order (= grouped by the rank that sent the child).
 // Shortcut record (16 B): {parent_idx, new G for the parent, index of the child on this rank, this rank | rev(action) << 8}
-__global__ __launch_bounds__(1024)
-void k_shard_shortcuts(int K, const uint8_t *flags, const int32_t *seen, const uint32_t *recs, const int32_t *G, uint32_t my_rank,
-                       uint32_t *mark, u32x4 *out, long long *counts)
+__device__ __forceinline__ bool shortcut_offer(int c, int K, const uint8_t *flags, const int32_t *seen, const uint32_t *recs,
+                                               const int32_t *G, uint32_t my_rank, u32x4 *rec, uint32_t *dst)
+{
+	if (c >= K || !(flags[c] & 2)) return false;
+	const uint32_t *r = recs + (size_t)c * 8;
+	const int32_t s = seen[c];
+	const int32_t g_parent = (int32_t)(r[6] & 0xFFFFu) - 1;
+	const int32_t g_new = G[s] + 1;
+	*dst = r[6] >> 24;
+	*rec = u32x4{r[5], (uint32_t)g_new, (uint32_t)s, my_rank | ((((r[6] >> 16) & 0xFFu) ^ 1u) << 8)};
+	return g_new < g_parent;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK)
+void k_shard_offers_count(int K, const uint8_t *flags, const int32_t *seen, const uint32_t *recs, const int32_t *G, uint32_t my_rank,
+                          uint32_t *mark, int32_t *rank, int32_t *block_sums, long long *counts)
 {
 	__shared__ int s_wave[16];
-	__shared__ int s_base;
-	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-	if (tid == 0) s_base = 0;
-	__syncthreads();
-	for (int c0 = 0; c0 < K; c0 += 1024) {
-		const int c = c0 + tid;
-		bool cand = false;
-		u32x4 rec = {0u, 0u, 0u, 0u};
-		uint32_t dst = 0;
-		if (c < K && (flags[c] & 2)) {
-			const uint32_t *r = recs + (size_t)c * 8;
-			const int32_t s = seen[c];
-			const int32_t g_parent = (int32_t)(r[6] & 0xFFFFu) - 1;
-			const int32_t g_new = G[s] + 1;
-			cand = g_new < g_parent;
-			dst = r[6] >> 24;
-			rec = u32x4{r[5], (uint32_t)g_new, (uint32_t)s, my_rank | ((((r[6] >> 16) & 0xFFu) ^ 1u) << 8)};
-			mark[s] = NO_MARK;
-		}
-		const unsigned long long b = __ballot(cand);
-		const int in_wave = __popcll(b & ((1ull << lane) - 1ull));
-		if (lane == 0) s_wave[wv] = __popcll(b);
-		__syncthreads();
-		int before = s_base;
-		for (int k = 0; k < wv; k++) before += s_wave[k];
-		if (cand) {
-			out[before + in_wave] = rec;
-			atomicAdd(reinterpret_cast<unsigned long long *>(&counts[dst]), 1ull);
-		}
-		__syncthreads();
-		if (tid == 0) {
-			int tot = 0;
-			for (int k = 0; k < 16; k++) tot += s_wave[k];
-			s_base += tot;
-		}
-		__syncthreads();
-	}
+	const int c = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+	u32x4 rec;
+	uint32_t dst = 0;
+	const bool cand = shortcut_offer(c, K, flags, seen, recs, G, my_rank, &rec, &dst);
+	if (c < K && (flags[c] & 2)) mark[seen[c]] = NO_MARK;       // the marks this batch set are no longer needed
+	int total;
+	const int r = block_rank(cand, s_wave, &total);
+	if (c < K) rank[c] = cand ? r : -1;
+	if (cand) atomicAdd(reinterpret_cast<unsigned long long *>(&counts[dst]), 1ull);
+	if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK)
+void k_shard_offers_write(int K, const uint8_t *flags, const int32_t *seen, const uint32_t *recs, const int32_t *G, uint32_t my_rank,
+                          const int32_t *rank, const int32_t *block_off, u32x4 *out)
+{
+	const int c = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+	if (c >= K || rank[c] < 0) return;
+	u32x4 rec;
+	uint32_t dst;
+	shortcut_offer(c, K, flags, seen, recs, G, my_rank, &rec, &dst);
+	out[block_off[blockIdx.x] + rank[c]] = rec;
 }
 
 // parent side of case 2 (agents.py:362-367): evaluate every offer against G as it stands, then let the LAST hit per
@@ -541,6 +585,7 @@ struct rk_astar {
 	size_t k_in = 0;              // capacity (records) of the per-iteration scratch: 12 * max_exp * world
 	uint32_t *recs = nullptr; uint8_t *owner = nullptr, *hit = nullptr;
 	long long *dev_counts = nullptr;
+	int32_t *blk = nullptr;       // workgroup totals / offsets of the multi-workgroup compactions: (k_in/1024 + 2) * world
 	const uint32_t *pending_recs = nullptr;   // received records of the pending insert (caller memory)
 	int n_in = 0;
 	// host mirrors
@@ -594,7 +639,8 @@ static int astar_create_impl(rk_astar_t **out, size_t capacity, int max_expansio
 	A(seen, KI); A(child_slot, KI); A(flags, KI); A(rank_, KI); A(newway, KI); A(shortcut, KI); A(val1, KI); A(val2, KI);
 	A(newrec[0], KI + 1024); A(newrec[1], KI + 1024);
 	A(counters, CTR_COUNT); A(root_dev, 8);
-	if (world > 1 || true) { A(recs, K * 8 + 64); A(owner, K + 64); A(hit, KI + 64); A(dev_counts, 256); }
+	A(recs, K * 8 + 64); A(owner, K + 64); A(hit, KI + 64); A(dev_counts, 256);
+	A(blk, (KI / SCAN_BLOCK + 2) * (size_t)world + 64);
 	#undef A
 	if (e) { rk_astar_destroy(h); return e; }
 	*out = h;
@@ -658,8 +704,10 @@ int rk_astar_expand(rk_astar_t *h, int n_expand, long long *h_info, void *stream
 		hipLaunchKernelGGL(k_astar_pop, dim3(blocks((size_t)n_pop * 5)), dim3(256), 0, st, h->open[h->cur], n_pop, h->states, h->exp_idx, h->par_states);
 		launch_expand12((const int8_t *)h->par_states, (int8_t *)h->children, h->solved, nullptr, (size_t)n_pop, st);
 		hipLaunchKernelGGL(k_astar_lookup, dim3(blocks(K)), dim3(256), 0, st, h->children, 5, K, h->states, h->table, h->mask, h->mark, h->seen, h->child_slot);
-		hipLaunchKernelGGL(k_astar_flags_scan, dim3(1), dim3(1024), 0, st, K, h->table, h->mark, h->seen, h->child_slot, h->flags, h->rank_, h->counters);
-		hipLaunchKernelGGL(k_astar_append<false>, dim3(blocks(K)), dim3(256), 0, st, h->children, h->solved, K, h->flags, h->rank_, h->seen, h->child_slot,
+		const int nb = (int)blocks(K, SCAN_BLOCK);
+		hipLaunchKernelGGL(k_astar_flags, dim3(nb), dim3(SCAN_BLOCK), 0, st, K, h->table, h->mark, h->seen, h->child_slot, h->flags, h->rank_, h->blk);
+		hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(SCAN_BLOCK), 0, st, h->blk, nb, h->counters + CTR_NEW);
+		hipLaunchKernelGGL(k_astar_append<false>, dim3(blocks(K)), dim3(256), 0, st, h->children, h->solved, K, h->flags, h->rank_, h->blk, h->seen, h->child_slot,
 		                   h->exp_idx, (uint32_t)h->n_before, h->states, h->G, h->parents, h->pact, h->prank, h->table, h->newway, h->val1, h->counters);
 		RK_HIP(hipGetLastError());
 		RK_HIP(hipMemcpyAsync(ctr, h->counters, sizeof ctr, hipMemcpyDeviceToHost, st));
@@ -763,7 +811,10 @@ int rk_astar_shard_pop(rk_astar_t *h, int n_pop, void *d_send, long long *h_send
 		hipLaunchKernelGGL(k_astar_pop, dim3(blocks((size_t)n_pop * 5)), dim3(256), 0, st, h->open[h->cur], n_pop, h->states, h->exp_idx, h->par_states);
 		launch_expand12((const int8_t *)h->par_states, (int8_t *)h->children, nullptr, nullptr, (size_t)n_pop, st);
 		hipLaunchKernelGGL(k_shard_records, dim3(blocks(K)), dim3(256), 0, st, h->children, K, h->exp_idx, h->G, (uint32_t)h->rank, (uint32_t)h->world, h->recs, h->owner);
-		hipLaunchKernelGGL(k_shard_bucket, dim3(1), dim3(1024), 0, st, K, (uint32_t)h->world, h->recs, h->owner, (u32x4 *)d_send, h->dev_counts);
+		const int nb = (int)blocks(K, SCAN_BLOCK);
+		hipLaunchKernelGGL(k_shard_hist, dim3(nb), dim3(SCAN_BLOCK), 0, st, K, (uint32_t)h->world, h->owner, h->blk, nb);
+		hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(SCAN_BLOCK), 0, st, h->blk, nb * h->world, (long long *)nullptr);
+		hipLaunchKernelGGL(k_shard_scatter, dim3(nb), dim3(SCAN_BLOCK), 0, st, K, (uint32_t)h->world, h->recs, h->owner, h->blk, nb, (u32x4 *)d_send, h->dev_counts);
 		RK_HIP(hipGetLastError());
 		RK_HIP(hipMemcpyAsync(h_send_counts, h->dev_counts, (size_t)h->world * sizeof(long long), hipMemcpyDeviceToHost, st));
 		RK_HIP(hipStreamSynchronize(st));
@@ -791,13 +842,18 @@ int rk_astar_shard_insert(rk_astar_t *h, const void *d_recv, long long n_recv, v
 		RK_HIP(hipMemsetAsync(h->counters, 0, CTR_COUNT * sizeof(long long), st));
 		RK_HIP(hipMemsetAsync(h->dev_counts, 0, 256 * sizeof(long long), st));
 		hipLaunchKernelGGL(k_astar_lookup, dim3(blocks(K)), dim3(256), 0, st, recs, 8, K, h->states, h->table, h->mask, h->mark, h->seen, h->child_slot);
-		hipLaunchKernelGGL(k_astar_flags_scan, dim3(1), dim3(1024), 0, st, K, h->table, h->mark, h->seen, h->child_slot, h->flags, h->rank_, h->counters);
-		hipLaunchKernelGGL(k_astar_append<true>, dim3(blocks(K)), dim3(256), 0, st, recs, (const uint8_t *)nullptr, K, h->flags, h->rank_, h->seen, h->child_slot,
+		const int nb = (int)blocks(K, SCAN_BLOCK);
+		hipLaunchKernelGGL(k_astar_flags, dim3(nb), dim3(SCAN_BLOCK), 0, st, K, h->table, h->mark, h->seen, h->child_slot, h->flags, h->rank_, h->blk);
+		hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(SCAN_BLOCK), 0, st, h->blk, nb, h->counters + CTR_NEW);
+		hipLaunchKernelGGL(k_astar_append<true>, dim3(blocks(K)), dim3(256), 0, st, recs, (const uint8_t *)nullptr, K, h->flags, h->rank_, h->blk, h->seen, h->child_slot,
 		                   (const int32_t *)nullptr, (uint32_t)h->n_before, h->states, h->G, h->parents, h->pact, h->prank, h->table, h->newway, h->val1, h->counters);
 		hipLaunchKernelGGL(k_relax_1b<true>, dim3(blocks(K)), dim3(256), 0, st, K, h->newway, h->val1, h->seen, (const int32_t *)nullptr, recs,
 		                   h->G, h->parents, h->pact, h->prank, h->counters);
-		hipLaunchKernelGGL(k_shard_shortcuts, dim3(1), dim3(1024), 0, st, K, h->flags, h->seen, recs, h->G, (uint32_t)h->rank, h->mark,
-		                   (u32x4 *)d_shortcuts_out, h->dev_counts);
+		hipLaunchKernelGGL(k_shard_offers_count, dim3(nb), dim3(SCAN_BLOCK), 0, st, K, h->flags, h->seen, recs, h->G, (uint32_t)h->rank, h->mark,
+		                   h->rank_, h->blk, h->dev_counts);
+		hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(SCAN_BLOCK), 0, st, h->blk, nb, (long long *)nullptr);
+		hipLaunchKernelGGL(k_shard_offers_write, dim3(nb), dim3(SCAN_BLOCK), 0, st, K, h->flags, h->seen, recs, h->G, (uint32_t)h->rank, h->rank_, h->blk,
+		                   (u32x4 *)d_shortcuts_out);
 		RK_HIP(hipGetLastError());
 		RK_HIP(hipMemcpyAsync(ctr, h->counters, sizeof ctr, hipMemcpyDeviceToHost, st));
 		RK_HIP(hipMemcpyAsync(h_shortcut_counts, h->dev_counts, (size_t)h->world * sizeof(long long), hipMemcpyDeviceToHost, st));
