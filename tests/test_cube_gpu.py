@@ -291,3 +291,30 @@ def test_headline_1m_bit_exact(golden):
 	assert torch.equal(oh.sum(dim=1), torch.full((200_000,), 20.0, device="cuda"))
 	cols = oh.view(200_000, 20, 24).argmax(dim=2).to(torch.int8)
 	assert torch.equal(cols, dp[:200_000])
+
+
+def test_fuzz_shapes_offsets_against_oracle():
+	"""Random sizes and pool offsets (4-byte-aligned views) through every 20-byte kernel, device path."""
+	rng = np.random.RandomState(2024)
+	pool_rows = 9000
+	base = random_walk(pool_rows, 11, seed=77)
+	base[rng.randint(0, pool_rows, 40)] = orc.SOLVED
+	near = orc.multi_rotate(orc.repeat_state(orc.SOLVED, 12), *orc.iter_actions())
+	base[rng.randint(0, pool_rows, 60)] = near[rng.randint(0, 12, 60)]
+	pool = dev(base)
+	for _ in range(40):
+		n = int(rng.choice([1, 3, 64, 65, 127, 128, 300, 511, 1024, 2049, 5000]))
+		off = int(rng.randint(0, pool_rows - n))
+		view, host = pool[off:off + n], base[off:off + n]
+		ch, fl = cube.device.expand12(view)
+		ref_ch, ref_fl = c_oracle.expand12(host)
+		assert (ch.cpu().numpy() == ref_ch).all() and (fl.cpu().numpy() == ref_fl).all(), (n, off)
+		acts = rng.randint(0, 12, n).astype(np.uint8)
+		assert (cube.device.multi_rotate(view, dev(acts)).cpu().numpy() == c_oracle.multi_rotate(host, acts)).all(), (n, off)
+		assert (cube.device.multi_is_solved(view).cpu().numpy().astype(bool) == orc.multi_is_solved(host)).all(), (n, off)
+		assert (cube.device.as_oh(view).cpu().numpy() == c_oracle.as_oh(host)).all(), (n, off)
+		depth, games = int(rng.randint(1, 9)), int(rng.randint(1, 70))
+		seq = rng.randint(0, 12, (depth, games)).astype(np.uint8)
+		for ws in (False, True):
+			got = cube.device.apply_sequences(dev(seq), ws, False).cpu().numpy()
+			assert (got == orc.sequence_states(seq // 2, 1 - seq % 2, ws)).all(), (depth, games, ws)
