@@ -69,6 +69,11 @@ def main():
 	report("device fill 240 MB (torch fill_, pure store stream)", children.numel(), timed(lambda: children.fill_(1), 50), children.numel(), "bytes")
 	report("expand12 + goal test", 272 * n, timed(lambda: cube.device.expand12(states, children, solved), args.reps), n, "expansions")
 	report("expand12 without flags", 260 * n, timed(lambda: cube.device.expand12(states, children, want_flags=False), args.reps), n, "expansions")
+	planes = cube.device.to_soa(states)
+	ch_soa = torch.empty((12, 5, n), dtype=torch.int32, device="cuda")
+	fl_soa = torch.empty((12, n), dtype=torch.uint8, device="cuda")
+	report("expand12 + goal test, structure-of-arrays planes", 272 * n, timed(lambda: cube.device.expand12_soa(planes, ch_soa, fl_soa), args.reps), n, "expansions")
+	del ch_soa, fl_soa
 	report("multi_rotate (per-state action)", 41 * n, timed(lambda: cube.device.multi_rotate(states, acts, out), args.reps), n, "transitions")
 	report("multi_rotate on 12 M rows", 41 * 12 * n, timed(lambda: cube.device.multi_rotate(children, acts.repeat(12), children), 20), 12 * n, "transitions")
 	report("multi_is_solved", 21 * n, timed(lambda: cube.device.multi_is_solved(states, flags), args.reps), n, "states")

@@ -86,6 +86,16 @@ int rk_multi_rotate_fd(int repr, const int8_t *d_states, const uint8_t *d_faces,
 int rk_expand12(int repr, const int8_t *d_parents, int8_t *d_children, uint8_t *d_solved,
                 long long *d_stats, size_t n, void *stream);
 
+/* Structure-of-arrays form of the fan-out for device-resident pipelines (same arithmetic, different layout):
+ * d_parents uint32 [5][n] (plane j = bytes 4j..4j+3 of every state), d_children uint32 [12][5][n] (child a of
+ * parent p has its dword j at [(a*5 + j)*n + p]), d_solved uint8 [12][n] (nullable).  Every access of a wavefront
+ * is one contiguous run, so the kernel needs no LDS transpose.  d_stats as rk_expand12 (the index it reports is
+ * 12 p + a).  rk_states_to_soa / rk_states_from_soa convert between (n,20) int8 rows and the five planes. */
+int rk_expand12_soa(const uint32_t *d_parents, uint32_t *d_children, uint8_t *d_solved, long long *d_stats, size_t n,
+                    void *stream);
+int rk_states_to_soa(const int8_t *d_states, uint32_t *d_planes, size_t n, void *stream);
+int rk_states_from_soa(const uint32_t *d_planes, int8_t *d_states, size_t n, void *stream);
+
 /* multi_is_solved (cube.py:88-89).  d_flags (nullable) one byte per state; d_stats as above. */
 int rk_multi_is_solved(int repr, const int8_t *d_states, uint8_t *d_flags, long long *d_stats,
                        size_t n, void *stream);

@@ -37,6 +37,9 @@ SIGNATURES = {
 	"rk_multi_rotate": (_i, [_i, _vp, _vp, _vp, _sz, _vp]),
 	"rk_multi_rotate_fd": (_i, [_i, _vp, _vp, _vp, _vp, _sz, _vp]),
 	"rk_expand12": (_i, [_i, _vp, _vp, _vp, _vp, _sz, _vp]),
+	"rk_expand12_soa": (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),
+	"rk_states_to_soa": (_i, [_vp, _vp, _sz, _vp]),
+	"rk_states_from_soa": (_i, [_vp, _vp, _sz, _vp]),
 	"rk_multi_is_solved": (_i, [_i, _vp, _vp, _vp, _sz, _vp]),
 	"rk_apply_sequences": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _vp]),
 	"rk_as_oh": (_i, [_i, _vp, _vp, _i, _sz, _vp]),

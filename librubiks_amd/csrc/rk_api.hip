@@ -183,6 +183,35 @@ int rk_expand12(int repr, const int8_t *d_parents, int8_t *d_children, uint8_t *
 	return RK_OK;
 }
 
+int rk_expand12_soa(const uint32_t *d_parents, uint32_t *d_children, uint8_t *d_solved, long long *d_stats, size_t n, void *stream)
+{
+	if (n == 0) return RK_OK;
+	if (!d_parents || !d_children) return fail(RK_EINVAL, "rk_expand12_soa: null pointer");
+	if (misaligned(d_parents, 4) || misaligned(d_children, 4)) return fail(RK_EINVAL, "rk_expand12_soa: planes must be 4-byte aligned");
+	if (d_stats && (!d_solved || misaligned(d_stats, 8))) return fail(RK_EINVAL, "rk_expand12_soa: stats need flags and 8-byte alignment");
+	launch_expand12_soa(d_parents, d_children, d_solved, d_stats, n, (hipStream_t)stream);
+	RK_HIP(hipGetLastError());
+	return RK_OK;
+}
+
+int rk_states_to_soa(const int8_t *d_states, uint32_t *d_planes, size_t n, void *stream)
+{
+	if (n == 0) return RK_OK;
+	if (!d_states || !d_planes || misaligned(d_states, 4) || misaligned(d_planes, 4)) return fail(RK_EINVAL, "rk_states_to_soa: bad pointer");
+	launch_states_soa(d_states, d_planes, n, true, (hipStream_t)stream);
+	RK_HIP(hipGetLastError());
+	return RK_OK;
+}
+
+int rk_states_from_soa(const uint32_t *d_planes, int8_t *d_states, size_t n, void *stream)
+{
+	if (n == 0) return RK_OK;
+	if (!d_states || !d_planes || misaligned(d_states, 4) || misaligned(d_planes, 4)) return fail(RK_EINVAL, "rk_states_from_soa: bad pointer");
+	launch_states_soa(d_states, const_cast<uint32_t *>(d_planes), n, false, (hipStream_t)stream);
+	RK_HIP(hipGetLastError());
+	return RK_OK;
+}
+
 /* Tuning hook, deliberately outside the public header: other shapes of the fan-out kernel (benchmarks/tune_expand.py). */
 int rkx_expand12_variant(int variant, const int8_t *d_parents, int8_t *d_children, uint8_t *d_solved, long long *d_stats, size_t n,
                          unsigned int *d_counter, int grid_blocks, void *stream)

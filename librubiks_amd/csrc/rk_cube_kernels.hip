@@ -207,6 +207,72 @@ void k_expand12(const uint32_t *__restrict__ parents, u32x4 *__restrict__ childr
 }
 
 // ================================================================================================================
+// expand12, structure-of-arrays form.  Parents are five dword planes P[j][n] (plane j = bytes 4j..4j+3 of every state),
+// children sixty planes C[a][j][n] (action-major) and twelve flag planes F[a][n].  Lane i of a wave handles parent
+// p0+i, so every load and every one of the 60 stores of a wave is one contiguous 256-byte access: no LDS transpose
+// at all (LDS only holds the 768-byte row table).  Same arithmetic as k_expand12; the layout differs from the
+// reference's (12 n, 20) array, so this form is for device-resident pipelines, not for the drop-in surface.
+// ================================================================================================================
+template <bool WITH_FLAGS>
+__global__ __launch_bounds__(256)
+void k_expand12_soa(const uint32_t *__restrict__ parents, uint32_t *__restrict__ children, uint8_t *__restrict__ solved,
+                    long long *__restrict__ stats, size_t n)
+{
+	__shared__ u32x4 s_rows[48];
+	const int tid = threadIdx.x;
+	if (tid < 48) {
+		const uint32_t *src = reinterpret_cast<const uint32_t *>(D_TAB.rows) + 4 * tid;
+		s_rows[tid] = u32x4{src[0], src[1], src[2], src[3]};
+	}
+	__syncthreads();
+	for (size_t p = (size_t)blockIdx.x * blockDim.x + tid; p < n; p += (size_t)gridDim.x * blockDim.x) {
+		uint32_t out[60];
+		#pragma unroll
+		for (int j = 0; j < 5; j++) {
+			const uint32_t x = parents[(size_t)j * n + p];
+			const int kind_base = (j < 2) ? 0 : 24;
+			const u32x4 r0 = s_rows[kind_base + (x & 0xFF)];
+			const u32x4 r1 = s_rows[kind_base + ((x >> 8) & 0xFF)];
+			const u32x4 r2 = s_rows[kind_base + ((x >> 16) & 0xFF)];
+			const u32x4 r3 = s_rows[kind_base + (x >> 24)];
+			transpose4x4(r0.x, r1.x, r2.x, r3.x, out[0 * 5 + j], out[1 * 5 + j], out[2 * 5 + j], out[3 * 5 + j]);
+			transpose4x4(r0.y, r1.y, r2.y, r3.y, out[4 * 5 + j], out[5 * 5 + j], out[6 * 5 + j], out[7 * 5 + j]);
+			transpose4x4(r0.z, r1.z, r2.z, r3.z, out[8 * 5 + j], out[9 * 5 + j], out[10 * 5 + j], out[11 * 5 + j]);
+		}
+		#pragma unroll
+		for (int d = 0; d < 60; d++) __builtin_nontemporal_store(out[d], children + (size_t)d * n + p);
+		if (WITH_FLAGS) {
+			int first = -1, cnt = 0;
+			#pragma unroll
+			for (int a = 11; a >= 0; a--) {
+				const bool ok = is_solved5(&out[a * 5]);
+				solved[(size_t)a * n + p] = ok ? 1 : 0;
+				if (ok) { first = a; cnt++; }
+			}
+			if (stats != nullptr && __ballot(cnt != 0) != 0ull && cnt != 0) {
+				atomicAdd(reinterpret_cast<unsigned long long *>(&stats[0]), (unsigned long long)cnt);
+				atomicMin(&stats[1], (long long)(p * 12 + first));
+			}
+		}
+	}
+}
+
+// AoS (n, 20) <-> five dword planes
+__global__ __launch_bounds__(256)
+void k_states_to_soa(const uint32_t *__restrict__ states, uint32_t *__restrict__ planes, size_t n, int to_soa)
+{
+	// one thread per dword; consecutive threads walk the AoS array, so the AoS side is coalesced and the plane side is
+	// a stride-5 gather/scatter inside a 1 280-byte window (served by L1/L2)
+	const size_t total = n * 5;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+		const size_t p = i / 5;
+		const int j = (int)(i - p * 5);
+		if (to_soa) planes[(size_t)j * n + p] = states[i];
+		else const_cast<uint32_t *>(states)[i] = planes[(size_t)j * n + p];
+	}
+}
+
+// ================================================================================================================
 // multi_rotate: out[i] = move actions[i] on states[i]                                       cube.py:256-263
 // Algorithmic bytes per state: 20 + 1 read, 20 written.
 // A wave owns 256 states (5 KiB in, 5 KiB out, all as 1 KiB dwordx4 accesses); lane l handles states 4l..4l+3 of
@@ -679,6 +745,21 @@ void launch_expand12(const int8_t *parents, int8_t *children, uint8_t *solved, l
 	else
 		hipLaunchKernelGGL((k_expand12<false, 1, true, false>), dim3(grid), dim3(EXP_WAVES * WAVE), 0, st, (const uint32_t *)parents,
 		                   (u32x4 *)children, (uint32_t *)nullptr, (long long *)nullptr, n, n_tiles, (unsigned int *)nullptr);
+}
+
+void launch_expand12_soa(const uint32_t *parents, uint32_t *children, uint8_t *solved, long long *stats, size_t n, hipStream_t st)
+{
+	const unsigned grid = grid_for(n, 256, 1u << 20);
+	if (solved != nullptr)
+		hipLaunchKernelGGL(k_expand12_soa<true>, dim3(grid), dim3(256), 0, st, parents, children, solved, stats, n);
+	else
+		hipLaunchKernelGGL(k_expand12_soa<false>, dim3(grid), dim3(256), 0, st, parents, children, (uint8_t *)nullptr, (long long *)nullptr, n);
+}
+
+void launch_states_soa(const int8_t *states, uint32_t *planes, size_t n, bool to_soa, hipStream_t st)
+{
+	const unsigned grid = grid_for(n * 5, 256, 256u * 16u);
+	hipLaunchKernelGGL(k_states_to_soa, dim3(grid), dim3(256), 0, st, (const uint32_t *)states, planes, n, to_soa ? 1 : 0);
 }
 
 void launch_multi_rotate(const int8_t *states, const uint8_t *actions, const uint8_t *dirs, int8_t *out, size_t n, hipStream_t st)

@@ -188,6 +188,45 @@ class device:
 		return children, solved
 
 	@staticmethod
+	def to_soa(states: torch.Tensor) -> torch.Tensor:
+		"""(n, 20) int8 rows -> int32 (5, n) planes (plane j = bytes 4j..4j+3 of every state)."""
+		_ffi.require_gpu()
+		n = len(states)
+		planes = torch.empty((5, n), dtype=torch.int32, device=states.device)
+		_ffi.check(_ffi.lib().rk_states_to_soa(states.data_ptr(), planes.data_ptr(), n, _ffi.stream_ptr()))
+		return planes
+
+	@staticmethod
+	def from_soa(planes: torch.Tensor) -> torch.Tensor:
+		"""int32 (..., 5, n) planes -> (n, 20) int8 rows (leading dimensions, e.g. the 12 actions, become rows blocks)."""
+		_ffi.require_gpu()
+		lead = planes.shape[:-2]
+		n = planes.shape[-1]
+		flat = planes.reshape(-1, 5, n)
+		out = torch.empty((flat.shape[0], n, 20), dtype=torch.int8, device=planes.device)
+		for i in range(flat.shape[0]):
+			_ffi.check(_ffi.lib().rk_states_from_soa(flat[i].data_ptr(), out[i].data_ptr(), n, _ffi.stream_ptr()))
+		return out.reshape(*lead, n, 20)
+
+	@staticmethod
+	def expand12_soa(parents: torch.Tensor, children: torch.Tensor = None, solved: torch.Tensor = None,
+	                 stats: torch.Tensor = None, want_flags: bool = True):
+		"""
+		Structure-of-arrays fan-out: parents int32 (5, n) -> children int32 (12, 5, n) [action-major] and solved
+		uint8 (12, n).  Same arithmetic as expand12; every access of a wavefront is one contiguous run.
+		"""
+		_ffi.require_gpu()
+		n = parents.shape[1]
+		if children is None:
+			children = torch.empty((12, 5, n), dtype=torch.int32, device=parents.device)
+		if solved is None and want_flags:
+			solved = torch.empty((12, n), dtype=torch.uint8, device=parents.device)
+		_ffi.check(_ffi.lib().rk_expand12_soa(
+			parents.data_ptr(), children.data_ptr(), solved.data_ptr() if solved is not None else None,
+			stats.data_ptr() if stats is not None else None, n, _ffi.stream_ptr()))
+		return children, solved
+
+	@staticmethod
 	def multi_is_solved(states: torch.Tensor, flags: torch.Tensor = None, stats: torch.Tensor = None) -> torch.Tensor:
 		"""uint8 (n,) flags, 1 where the state is solved (cube.py:88-89)."""
 		_ffi.require_gpu()

@@ -318,3 +318,25 @@ def test_fuzz_shapes_offsets_against_oracle():
 		for ws in (False, True):
 			got = cube.device.apply_sequences(dev(seq), ws, False).cpu().numpy()
 			assert (got == orc.sequence_states(seq // 2, 1 - seq % 2, ws)).all(), (depth, games, ws)
+
+
+@pytest.mark.parametrize("n", [1, 63, 256, 1000, 70_001])
+def test_soa_fanout_matches_aos(n):
+	"""The structure-of-arrays form: same children and flags as the AoS kernel / the oracle, in plane layout."""
+	p = random_walk(n, 10, seed=300 + n % 13)
+	if n > 5:
+		p[n // 2] = orc.rotate(orc.SOLVED, 5, 1)
+		p[1] = orc.SOLVED
+	dp = dev(p)
+	planes = cube.device.to_soa(dp)
+	assert planes.shape == (5, n)
+	assert (planes.cpu().numpy().T.copy().view(np.int8).reshape(n, 20) == p).all()
+	assert torch.equal(cube.device.from_soa(planes), dp)
+	stats = torch.tensor([0, _ffi.INT64_MAX], dtype=torch.int64, device="cuda")
+	ch, fl = cube.device.expand12_soa(planes, stats=stats)
+	ref_ch, ref_fl = c_oracle.expand12(p)
+	got = cube.device.from_soa(ch).cpu().numpy()                       # (12, n, 20): action-major
+	assert (got.transpose(1, 0, 2).reshape(12 * n, 20) == ref_ch).all()
+	assert (fl.cpu().numpy().T.reshape(-1) == ref_fl).all()
+	st = stats.cpu().numpy()
+	assert st[0] == ref_fl.sum() and st[1] == (np.flatnonzero(ref_fl)[0] if ref_fl.any() else _ffi.INT64_MAX)
