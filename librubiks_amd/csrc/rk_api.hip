@@ -40,16 +40,34 @@ int check_repr(int repr)
 	return RK_OK;
 }
 
-// scratch device buffer with RAII for the *_host entries
+// Scratch for the *_host entries: grow-only device buffers cached per host thread and device, so that a small call
+// (one state through cube.rotate) costs two tiny copies and a launch instead of three hipMalloc/hipFree pairs.
+struct ScratchSlot { void *p = nullptr; size_t cap = 0; int device = -1; };
+thread_local ScratchSlot g_scratch[8];
+thread_local int g_scratch_next = 0;
+
 struct DevBuf {
 	void *p = nullptr;
 	int alloc(size_t bytes)
 	{
-		RK_HIP(hipMalloc(&p, bytes ? bytes : 16));
+		if (g_scratch_next >= 8) return fail(RK_ESTATE, "scratch slots exhausted");
+		ScratchSlot &s = g_scratch[g_scratch_next++];
+		int dev = 0;
+		RK_HIP(hipGetDevice(&dev));
+		if (bytes < 256) bytes = 256;
+		if (s.device != dev || s.cap < bytes) {
+			if (s.p && s.device == dev) (void)hipFree(s.p);
+			s.p = nullptr; s.cap = 0; s.device = dev;
+			RK_HIP(hipMalloc(&s.p, bytes));
+			s.cap = bytes;
+		}
+		p = s.p;
 		return RK_OK;
 	}
-	~DevBuf() { if (p) (void)hipFree(p); }
 };
+
+// resets the slot cursor when a *_host entry starts (slots are handed out in call order, so sizes stay matched)
+struct ScratchScope { ScratchScope() { g_scratch_next = 0; } };
 
 }  // namespace
 
@@ -291,6 +309,7 @@ int rk_multi_rotate_host(int repr, const int8_t *h_states, const uint8_t *h_acti
 		if (h_actions[i] >= N_ACTIONS) return fail(RK_EINVAL, "rk_multi_rotate_host: action %u at row %zu out of range", h_actions[i], i);
 	const size_t sb = (size_t)state_bytes(repr);
 	hipStream_t st = (hipStream_t)stream;
+	ScratchScope scope;
 	DevBuf in, act, out;
 	if (int e = in.alloc(n * sb)) return e;
 	if (int e = act.alloc(n)) return e;
@@ -312,6 +331,7 @@ int rk_expand12_host(int repr, const int8_t *h_parents, int8_t *h_children, uint
 	if (!h_parents || !h_children) return fail(RK_EINVAL, "rk_expand12_host: null pointer");
 	const size_t sb = (size_t)state_bytes(repr);
 	hipStream_t st = (hipStream_t)stream;
+	ScratchScope scope;
 	DevBuf in, ch, fl, stt;
 	if (int e = in.alloc(n * sb)) return e;
 	if (int e = ch.alloc(12 * n * sb)) return e;
@@ -337,16 +357,19 @@ int rk_multi_is_solved_host(int repr, const int8_t *h_states, uint8_t *h_flags, 
 	if (!h_states) return fail(RK_EINVAL, "rk_multi_is_solved_host: null pointer");
 	const size_t sb = (size_t)state_bytes(repr);
 	hipStream_t st = (hipStream_t)stream;
+	ScratchScope scope;
 	DevBuf in, fl, stt;
 	if (int e = in.alloc(n * sb)) return e;
 	if (int e = fl.alloc(n)) return e;
-	if (int e = stt.alloc(sizeof STATS_INIT)) return e;
 	RK_HIP(hipMemcpyAsync(in.p, h_states, n * sb, hipMemcpyHostToDevice, st));
-	RK_HIP(hipMemcpyAsync(stt.p, STATS_INIT, sizeof STATS_INIT, hipMemcpyHostToDevice, st));
+	if (h_stats) {                                   // the counters cost two extra copies: only when asked for
+		if (int e = stt.alloc(sizeof STATS_INIT)) return e;
+		RK_HIP(hipMemcpyAsync(stt.p, STATS_INIT, sizeof STATS_INIT, hipMemcpyHostToDevice, st));
+	}
 	if (int e = rk_multi_is_solved(repr, (const int8_t *)in.p, (uint8_t *)fl.p, (long long *)stt.p, n, stream)) return e;
 	if (h_flags) RK_HIP(hipMemcpyAsync(h_flags, fl.p, n, hipMemcpyDeviceToHost, st));
-	long long stats[2];
-	RK_HIP(hipMemcpyAsync(stats, stt.p, sizeof stats, hipMemcpyDeviceToHost, st));
+	long long stats[2] = {0, 0};
+	if (h_stats) RK_HIP(hipMemcpyAsync(stats, stt.p, sizeof stats, hipMemcpyDeviceToHost, st));
 	RK_HIP(hipStreamSynchronize(st));
 	if (h_stats) { h_stats[0] = stats[0]; h_stats[1] = stats[0] ? stats[1] : -1; }
 	return RK_OK;
@@ -368,6 +391,7 @@ int rk_apply_sequences_host(int repr, const uint8_t *h_actions, int depth, int g
 	for (size_t i = 0; i < nact; i++)
 		if (h_actions[i] >= N_ACTIONS) return fail(RK_EINVAL, "rk_apply_sequences_host: action %u out of range", h_actions[i]);
 	hipStream_t st = (hipStream_t)stream;
+	ScratchScope scope;
 	DevBuf act, out;
 	if (int e = act.alloc(nact)) return e;
 	if (int e = out.alloc((size_t)games * rows * STATE_BYTES)) return e;

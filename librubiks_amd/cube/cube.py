@@ -274,12 +274,31 @@ def rotate(state: np.ndarray, face: int, direction: int) -> np.ndarray:
 	return multi_rotate(np.asarray(state)[None], [face], [direction])[0]
 
 
+_SMALL = 4096     # host arrays up to this many states go straight through the library's *_host entries (no torch hop)
+
+
+def _host_actions(faces, dirs, n: int) -> np.ndarray:
+	f = np.asarray(faces).astype(np.int64).ravel()
+	d = np.asarray(dirs).astype(np.int64).ravel()
+	if len(f) != n or len(d) != n:
+		raise IndexError(f"need {n} faces and directions, got {len(f)} and {len(d)}")
+	if n and (f.min() < 0 or f.max() > 5 or d.min() < 0 or d.max() > 1):
+		raise IndexError("face must be in 0..5 and direction in 0..1")
+	return (2 * f + (1 - d)).astype(np.uint8)
+
+
 def multi_rotate(states: np.ndarray, faces: np.ndarray, directions: np.ndarray) -> np.ndarray:
 	"""Performs action (faces[i], directions[i]) on states[i]; returns a new array."""
 	_ffi.require_gpu()
 	n = len(states)
 	if n == 0:
 		return states.clone() if isinstance(states, torch.Tensor) else np.array(states, dtype=np.int8, copy=True)
+	if n <= _SMALL and not isinstance(states, torch.Tensor) and not _is_dev(faces) and not _is_dev(directions):
+		src = np.ascontiguousarray(states, dtype=np.int8)
+		acts = _host_actions(faces, directions, n)
+		out = np.empty_like(src)
+		_ffi.check(_ffi.lib().rk_multi_rotate_host(_repr_id(), src.ctypes.data, acts.ctypes.data, out.ctypes.data, n, _ffi.stream_ptr()))
+		return out
 	acts = _actions_from(faces, directions, n)
 	out = device.multi_rotate(_to_dev_states(states), acts)
 	return out if _is_dev(states) else out.cpu().numpy()
@@ -313,6 +332,11 @@ def multi_is_solved(states: np.ndarray) -> np.ndarray:
 	_ffi.require_gpu()
 	if len(states) == 0:
 		return np.zeros(0, dtype=bool)
+	if len(states) <= _SMALL and not isinstance(states, torch.Tensor):
+		src = np.ascontiguousarray(states, dtype=np.int8)
+		flags = np.empty(len(src), dtype=np.uint8)
+		_ffi.check(_ffi.lib().rk_multi_is_solved_host(_repr_id(), src.ctypes.data, flags.ctypes.data, None, len(src), _ffi.stream_ptr()))
+		return flags.astype(bool)
 	flags = device.multi_is_solved(_to_dev_states(states))
 	return flags.bool() if _is_dev(states) else flags.cpu().numpy().astype(bool)
 
