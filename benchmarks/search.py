@@ -40,13 +40,7 @@ class TimedNet(torch.nn.Module):
 def bench_astar(args):
 	net = FcSmall().cuda().eval()
 	if args.bf16:
-		net = net.to(torch.bfloat16)
-		base = net
-		class Cast(torch.nn.Module):
-			def forward(self, x, policy=True, value=True):
-				out = base(x.to(torch.bfloat16), policy=policy, value=value)
-				return [o.float() for o in out] if isinstance(out, list) else out.float()
-		net = Cast()
+		net = net.to(torch.bfloat16)          # the agent then asks the engine for a bf16 one-hot (exact 0/1) directly
 	rows = []
 	for timed in (False, True):
 		use = TimedNet(net) if timed else net

@@ -195,6 +195,23 @@ class EGVM(DeepAgent):
 		return f"EGVM (e={self.epsilon}, w={self.workers}, d={self.depth})"
 
 
+_OH_CODES = {torch.float32: _ffi.OH_F32, torch.float16: _ffi.OH_F16, torch.bfloat16: _ffi.OH_BF16}
+
+
+def _oh_dtype(net) -> torch.dtype:
+	"""
+	The dtype the net wants its one-hot input in: that of its first floating-point parameter (a bf16/fp16 net gets a
+	bf16/fp16 one-hot straight from the kernel -- 0/1 are exact, and no cast kernel or float32 copy is needed);
+	float32 for anything that is not a torch module.
+	"""
+	params = getattr(net, "parameters", None)
+	if callable(params):
+		for prm in params():
+			if prm.dtype in _OH_CODES:
+				return prm.dtype
+	return torch.float32
+
+
 def _value_f32(out) -> torch.Tensor:
 	"""The net's value head as a contiguous float32 vector on the GPU."""
 	if isinstance(out, (list, tuple)):
@@ -272,7 +289,8 @@ class AStar(DeepAgent):
 		lib, st = _ffi.lib(), _ffi.stream_ptr()
 		_ffi.check(lib.rk_astar_reset(h, state.ctypes.data, float(self.lambda_), st))
 		self._root, self._n = state.copy(), 1
-		oh = torch.empty((12 * self.expansions, 480), dtype=torch.float32, device=gpu)
+		oh_dtype = _oh_dtype(self.net)
+		oh = torch.empty((12 * self.expansions, 480), dtype=oh_dtype, device=gpu)
 		info = (C.c_longlong * 5)()
 		budget = min(max_states, cap)
 		while time.perf_counter() - t0 < time_limit and self._n + self.expansions * cube.action_dim <= budget:
@@ -294,7 +312,7 @@ class AStar(DeepAgent):
 				return True
 			values = None
 			if n_new:
-				_ffi.check(lib.rk_astar_new_states_oh(h, oh.data_ptr(), _ffi.OH_F32, st))
+				_ffi.check(lib.rk_astar_new_states_oh(h, oh.data_ptr(), _OH_CODES[oh_dtype], st))
 				values = _value_f32(self.net(oh[:n_new], policy=False, value=True))
 				assert values.numel() == n_new
 			_ffi.check(lib.rk_astar_commit(h, values.data_ptr() if values is not None else None, _ffi.stream_ptr()))
@@ -429,7 +447,7 @@ class MCTSBatch(DeepAgent):
 	def _step(self, oh, h):
 		lib = _ffi.lib()
 		_ffi.check(lib.rk_mcts_expand(h, _ffi.stream_ptr()))
-		_ffi.check(lib.rk_mcts_children_oh(h, oh.data_ptr(), _ffi.OH_F32, _ffi.stream_ptr()))
+		_ffi.check(lib.rk_mcts_children_oh(h, oh.data_ptr(), _OH_CODES[oh.dtype], _ffi.stream_ptr()))
 		p, v = _policy_value_f32(self.net(oh))
 		self._keep = (p, v)            # the kernels read these after this call returns
 		_ffi.check(lib.rk_mcts_backup_select(h, p.data_ptr(), v.data_ptr(), _ffi.stream_ptr()))
@@ -449,11 +467,12 @@ class MCTSBatch(DeepAgent):
 		ms = np.minimum(np.broadcast_to(np.asarray(max_states, dtype=np.int64), (self.n_trees,)), self.capacity).copy()
 		h, lib = self._engine(), _ffi.lib()
 		_ffi.check(lib.rk_mcts_reset(h, states.ctypes.data, ms.ctypes.data, self.c, self.nu, _ffi.stream_ptr()))
-		root_oh = torch.empty((self.n_trees, 480), dtype=torch.float32, device=gpu)
-		_ffi.check(lib.rk_mcts_roots_oh(h, root_oh.data_ptr(), _ffi.OH_F32, _ffi.stream_ptr()))
+		oh_dtype = _oh_dtype(self.net)
+		root_oh = torch.empty((self.n_trees, 480), dtype=oh_dtype, device=gpu)
+		_ffi.check(lib.rk_mcts_roots_oh(h, root_oh.data_ptr(), _OH_CODES[oh_dtype], _ffi.stream_ptr()))
 		p, v = _policy_value_f32(self.net(root_oh))                      # agents.py:470-473
 		_ffi.check(lib.rk_mcts_set_root_pv(h, p.data_ptr(), v.data_ptr(), _ffi.stream_ptr()))
-		oh = torch.empty((12 * self.n_trees, 480), dtype=torch.float32, device=gpu)
+		oh = torch.empty((12 * self.n_trees, 480), dtype=oh_dtype, device=gpu)
 		self.simulations = 0
 		graph = None
 		if use_graph:

@@ -35,7 +35,7 @@ import torch
 import torch.distributed as dist
 
 from librubiks_amd import gpu, no_grad, _ffi, cube
-from librubiks_amd.solving.agents import DeepAgent, _value_f32
+from librubiks_amd.solving.agents import DeepAgent, _value_f32, _oh_dtype, _OH_CODES
 
 REC_BYTES = 32          # child record
 OFFER_BYTES = 16        # shortcut offer
@@ -160,7 +160,8 @@ class ShardedAStar(DeepAgent):
 		k_out, k_in = 12 * N, 12 * N * tp.world
 		send = torch.empty((k_out, REC_BYTES), dtype=torch.uint8, device=gpu)
 		offers_out = torch.empty((k_in, OFFER_BYTES), dtype=torch.uint8, device=gpu)
-		oh = torch.empty((min(k_in, self.capacity), 480), dtype=torch.float32, device=gpu)
+		oh_dtype = _oh_dtype(self.net)
+		oh = torch.empty((min(k_in, self.capacity), 480), dtype=oh_dtype, device=gpu)
 		send_counts = np.zeros(tp.world, np.int64)
 		offer_counts = np.zeros(tp.world, np.int64)
 		info = np.zeros(5, np.int64)
@@ -205,7 +206,7 @@ class ShardedAStar(DeepAgent):
 			# 5. value net on this rank's new states, push
 			values = None
 			if n_new:
-				_ffi.check(lib.rk_astar_new_states_oh(h, oh.data_ptr(), _ffi.OH_F32, st()))
+				_ffi.check(lib.rk_astar_new_states_oh(h, oh.data_ptr(), _OH_CODES[oh_dtype], st()))
 				values = _value_f32(self.net(oh[:n_new], policy=False, value=True))
 			_ffi.check(lib.rk_astar_shard_push(h, values.data_ptr() if values is not None else None, st()))
 			# 6. shortcut offers back to the parents' owners

@@ -126,3 +126,25 @@ def test_real_net_invariants():
 	assert (moved == st[pick]).all() and (G[pick] == G[par[pick]] + 1).all()
 	q = agent.open_queue
 	assert q == sorted(q)
+
+
+def test_low_precision_net_gets_low_precision_onehot():
+	"""A bf16 net is fed a bf16 one-hot straight from the kernel (no float32 copy, no cast); results stay valid."""
+	seen = []
+	net = TinyNet().cuda().eval().to(torch.bfloat16)
+	hook = net.body[0].register_forward_pre_hook(lambda m, inp: seen.append(inp[0].dtype))
+	np.random.seed(2)
+	state, _, _ = cube.scramble(3, True)
+	agent = AStar(net, 0.5, 16)
+	solved = agent.search(state, None, 20_000)
+	hook.remove()
+	assert seen and all(d == torch.bfloat16 for d in seen)
+	if solved:
+		s = state
+		for a in agent.action_queue:
+			s = cube.rotate(s, *cube.action_space[a])
+		assert cube.is_solved(s)
+	st, G, par, act = agent.states, agent.G, agent.parents, agent.parent_actions
+	n = len(agent)
+	pick = np.arange(2, n + 1)
+	assert (orc.multi_rotate(st[par[pick]], act[pick] // 2, 1 - act[pick] % 2) == st[pick]).all()
