@@ -18,7 +18,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from librubiks_amd import _ffi, cube  # noqa: E402
 
-N = 1_000_000
+N = int(os.environ.get("RK_TUNE_N", "1000000"))
 lib = _ffi.lib()
 lib.rkx_expand12_variant.restype = C.c_int
 lib.rkx_expand12_variant.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]
@@ -28,7 +28,9 @@ NAMES = {0: "nt, tile256", 1: "plain, tile256", 2: "nt, tile64", 3: "plain, tile
          20: "nt, tile64, 4 waves/WG, direct input loads", 21: "nt, tile64, 2 waves/WG, direct input loads",
          22: "nt, tile64, 8 waves/WG, direct input loads", 23: "nt, tile64, 1 wave/WG, direct input loads",
          24: "nt, tile64, 4 waves/WG, parents preloaded before the table barrier", 25: "nt, tile64, 2 waves/WG, preload",
-         26: "nt, tile256, 4 waves/WG, preload"}
+         26: "nt, tile256, 4 waves/WG, preload", 27: "plain, tile64, 4 waves/WG, preload",
+         28: "nt, tile64, 4 waves/WG, half-round staging (16 waves/CU)", 29: "nt, tile64, 4 waves/WG, half-round staging, preload",
+         30: "nt, tile64, 2 waves/WG, half-round staging", 31: "nt, tile64, 8 waves/WG, half-round staging"}
 
 
 def main(variants):
@@ -39,17 +41,18 @@ def main(variants):
 	parents = cube.device.apply_sequences(acts, False, True)
 	ref_c, ref_f = cube.device.expand12(parents)
 	counter = torch.zeros(4, dtype=torch.int32, device="cuda")
-	bufs = [(torch.empty_like(ref_c), torch.empty_like(ref_f)) for _ in range(6)]
+	bufs = [(torch.empty_like(ref_c), torch.empty_like(ref_f)) for _ in range(6 if N <= 2_000_000 else 2)]
 
-	def run(v, i):
-		c, f = bufs[i % 6]
-		_ffi.check(lib.rkx_expand12_variant(v, parents.data_ptr(), c.data_ptr(), f.data_ptr(), None, N, counter.data_ptr(), 0, _ffi.stream_ptr()))
+	def run(vg, i):
+		v, gb = vg
+		c, f = bufs[i % len(bufs)]
+		_ffi.check(lib.rkx_expand12_variant(v, parents.data_ptr(), c.data_ptr(), f.data_ptr(), None, N, counter.data_ptr(), gb, _ffi.stream_ptr()))
 
 	res = {}
 	for v in variants:
 		bufs[0][0].zero_(); bufs[0][1].fill_(9)
 		run(v, 0)
-		res[v] = {"variant": NAMES[v], "correct": bool(torch.equal(bufs[0][0], ref_c) and torch.equal(bufs[0][1], ref_f)), "ms": []}
+		res[v] = {"variant": NAMES[v[0]], "grid_blocks": v[1] or "one tile per wave", "correct": bool(torch.equal(bufs[0][0], ref_c) and torch.equal(bufs[0][1], ref_f)), "ms": []}
 	for rep in range(7):
 		for v in variants:
 			for i in range(6):
@@ -64,9 +67,11 @@ def main(variants):
 	for v in variants:
 		r = res[v]
 		ms = sorted(r["ms"])[len(r["ms"]) // 2]
-		r.update(ms_median=ms, **{"GB/s": round(272e6 / (ms * 1e-3) / 1e9, 1), "frac_of_8TBs": round(272e6 / (ms * 1e-3) / 8e12, 4)})
+		r.update(ms_median=ms, **{"GB/s": round(272.0 * N / (ms * 1e-3) / 1e9, 1), "frac_of_8TBs": round(272.0 * N / (ms * 1e-3) / 8e12, 4)})
 		print(json.dumps(r), flush=True)
 
 
 if __name__ == "__main__":
-	main([int(x) for x in sys.argv[1:]] or [16, 17, 18, 19, 20, 21, 22, 23, 0, 1])
+	# arguments: variant or variant:grid_blocks
+	args = [a.split(":") for a in sys.argv[1:]] or [["16"], ["17"], ["18"], ["19"], ["20"], ["24"], ["24", "512"], ["24", "1024"], ["0"], ["1"]]
+	main([(int(a[0]), int(a[1]) if len(a) > 1 else 0) for a in args])

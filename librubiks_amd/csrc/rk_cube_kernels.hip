@@ -29,8 +29,9 @@ namespace rk {
 constexpr int EXP_ROUND = 64;                  // parents per round (one per lane)
 constexpr int EXP_WAVES = 4;                   // waves per workgroup of the shipping shape
 
-struct ExpandWaveLds {
-	u32x4    stage[EXP_ROUND * 15];            // 15 360 B: children of one round; first 5 120 B double as input staging
+template <int HALVES>
+struct ExpandWaveLdsT {
+	u32x4    stage[EXP_ROUND * 15 / HALVES];   // 15 360 B (or half): children of one round; the head doubles as input staging
 	uint32_t flags[EXP_ROUND * 3];             // 768 B: 12 solved bytes per parent
 };
 
@@ -38,17 +39,20 @@ struct ExpandWaveLds {
 // NT = non-temporal output stores; DYNAMIC = tiles handed out by an atomic counter to a persistent grid;
 // NWAVES = waves per workgroup; DIRECT_IN = each lane loads its own parent's five dwords straight from global memory
 // (stride 20 B across lanes, the lines are shared through L1) instead of the coalesced-load + LDS transpose.
-// PRELOAD = issue the first tile's parent loads before the move table is staged and the workgroup barrier, so that the
-// two global-memory latencies at the start of a workgroup's life overlap instead of adding up.
+// PRELOAD = software pipeline of the input: a tile's parent loads are issued one tile ahead (the first before the move
+// table is staged), so a wave that walks several tiles (persistent grid) never waits a full HBM latency per tile.
+// HALVES = 2 stages and streams a round's children in two halves of 32 parents: half the LDS per wave (8.4 KB), which lets
+// twice as many waves live on a CU (LDS, not registers, caps the occupancy of this kernel) at the price of 128 VGPRs.
 template <bool WITH_FLAGS, int ROUNDS = 4, bool NT = true, bool DYNAMIC = false, int NWAVES = EXP_WAVES, bool DIRECT_IN = false,
-          bool PRELOAD = false>
-__global__ __launch_bounds__(NWAVES * WAVE)
+          bool PRELOAD = false, int HALVES = 1>
+__global__ __launch_bounds__(NWAVES * WAVE, (HALVES == 2 ? 4 : 1))
 void k_expand12(const uint32_t *__restrict__ parents, u32x4 *__restrict__ children, uint32_t *__restrict__ solved,
                 long long *__restrict__ stats, size_t n, size_t n_tiles, unsigned int *__restrict__ tile_counter = nullptr)
 {
 	constexpr int EXP_TILE = EXP_ROUND * ROUNDS;
 	constexpr int EXP_WAVES = NWAVES;
 	__shared__ u32x4 s_rows[48];
+	typedef ExpandWaveLdsT<HALVES> ExpandWaveLds;
 	__shared__ ExpandWaveLds s_wave[EXP_WAVES];
 
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -100,7 +104,19 @@ void k_expand12(const uint32_t *__restrict__ parents, u32x4 *__restrict__ childr
 			} else if (PRELOAD && have_pre) {
 				#pragma unroll
 				for (int k = 0; k < 5 * ROUNDS; k++) stage_dw[k * 64 + lane] = pre[k];
-				have_pre = false;
+				// issue the NEXT tile's loads now; they land while this tile is being expanded
+				const size_t nxt = tile + (size_t)gridDim.x * EXP_WAVES;
+				have_pre = nxt < n_tiles;
+				if (have_pre) {
+					const size_t q0 = nxt * EXP_TILE;
+					const int ndw2 = (int)((n - q0 < (size_t)EXP_TILE) ? (n - q0) : (size_t)EXP_TILE) * STATE_DWORDS;
+					const uint32_t *src2 = parents + q0 * STATE_DWORDS;
+					#pragma unroll
+					for (int k = 0; k < 5 * ROUNDS; k++) {
+						const int idx = k * 64 + lane;
+						pre[k] = idx < ndw2 ? src2[idx] : 0u;
+					}
+				}
 			} else if (ROUNDS == 4 && np == EXP_TILE && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
 				const u32x4 *src4 = reinterpret_cast<const u32x4 *>(src);
 				#pragma unroll
@@ -151,27 +167,39 @@ void k_expand12(const uint32_t *__restrict__ parents, u32x4 *__restrict__ childr
 					if (is_solved5(&out[a * 5])) fl[a >> 2] |= 1u << (8 * (a & 3));
 			}
 
-			// ---- children out: lane-major 240 B blocks -> wave-contiguous 15 x 1 KiB ----
-			#pragma unroll
-			for (int v = 0; v < 15; v++)
-				L.stage[lane * 15 + v] = u32x4{out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]};
+			// ---- children out: lane-major 240 B blocks -> wave-contiguous 1 KiB stores (in HALVES passes) ----
 			if (WITH_FLAGS) {
 				L.flags[lane * 3 + 0] = fl[0];
 				L.flags[lane * 3 + 1] = fl[1];
 				L.flags[lane * 3 + 2] = fl[2];
 			}
-			wave_lds_fence();
-
-			u32x4 *dst = children + (p0 + round_first) * 15;
-			const int nvec = nr * 15;
 			#pragma unroll
-			for (int v = 0; v < 15; v++) {
-				const int idx = v * 64 + lane;
-				const u32x4 val = L.stage[idx];
-				if (idx < nvec) {
-					if (NT) __builtin_nontemporal_store(val, dst + idx);
-					else dst[idx] = val;
+			for (int h = 0; h < HALVES; h++) {
+				constexpr int LANES = EXP_ROUND / HALVES;               // parents per pass
+				constexpr int NVEC = LANES * 15;                        // 16-byte chunks per pass
+				if (HALVES == 1 || lane / LANES == h) {
+					const int l = lane % LANES;
+					#pragma unroll
+					for (int v = 0; v < 15; v++)
+						L.stage[l * 15 + v] = u32x4{out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]};
 				}
+				wave_lds_fence();
+				u32x4 *dst = children + (p0 + round_first + h * LANES) * 15;
+				int valid = nr - h * LANES;
+				valid = valid < 0 ? 0 : (valid > LANES ? LANES : valid);
+				const int nvec = valid * 15;
+				#pragma unroll
+				for (int v = 0; v < (NVEC + 63) / 64; v++) {
+					const int idx = v * 64 + lane;
+					if (idx < NVEC) {
+						const u32x4 val = L.stage[idx];
+						if (idx < nvec) {
+							if (NT) __builtin_nontemporal_store(val, dst + idx);
+							else dst[idx] = val;
+						}
+					}
+				}
+				if (HALVES > 1) wave_lds_fence();
 			}
 			if (WITH_FLAGS) {
 				uint32_t *fdst = solved + (p0 + round_first) * 3;
@@ -698,16 +726,18 @@ static inline unsigned grid_for(size_t work_items, size_t per_block, unsigned ca
 // tuning aid (benchmarks/tune_expand.py): the same kernel in its other shapes.
 //   variant 0..7   : bit 0 = plain stores, bit 1 = 64-parent tiles, bit 2 = persistent grid + atomic tile counter
 //   variant 16..23 : 64-parent tiles, non-temporal; bits 0-1 = waves per workgroup {4, 2, 8, 1}, bit 2 = direct input loads
-//   variant 24..26 : parent loads issued before the table barrier (PRELOAD): tile64 x 4 waves, tile64 x 2 waves, tile256 x 4 waves
+//   variant 24..27 : software-pipelined input (PRELOAD): tile64 x 4 waves, tile64 x 2 waves, tile256 x 4 waves, tile64 x 4 waves
+//                    with plain stores; combine with grid_blocks for a persistent grid
 void launch_expand12_variant(int variant, const int8_t *parents, int8_t *children, uint8_t *solved, long long *stats, size_t n,
                              unsigned int *counter, int grid_blocks, hipStream_t st)
 {
 	#define RK_LAUNCH(R, NTS, DYN, W, DIN) RK_LAUNCH2(R, NTS, DYN, W, DIN, false)
-	#define RK_LAUNCH2(R, NTS, DYN, W, DIN, PRE) do { \
+	#define RK_LAUNCH2(R, NTS, DYN, W, DIN, PRE) RK_LAUNCH3(R, NTS, DYN, W, DIN, PRE, 1)
+	#define RK_LAUNCH3(R, NTS, DYN, W, DIN, PRE, HLV) do { \
 		const size_t n_tiles = (n + 64 * (R) - 1) / (64 * (R)); \
 		unsigned grid = grid_for(n_tiles, (W), 1u << 20); \
 		if (grid_blocks > 0) grid = (unsigned)grid_blocks; \
-		hipLaunchKernelGGL((k_expand12<true, R, NTS, DYN, W, DIN, PRE>), dim3(grid), dim3((W) * WAVE), 0, st, \
+		hipLaunchKernelGGL((k_expand12<true, R, NTS, DYN, W, DIN, PRE, HLV>), dim3(grid), dim3((W) * WAVE), 0, st, \
 			(const uint32_t *)parents, (u32x4 *)children, (uint32_t *)solved, stats, n, n_tiles, counter); } while (0)
 	switch (variant) {
 		case 0: RK_LAUNCH(4, true, false, 4, false); break;
@@ -724,12 +754,18 @@ void launch_expand12_variant(int variant, const int8_t *parents, int8_t *childre
 		case 21: RK_LAUNCH(1, true, false, 2, true); break;
 		case 22: RK_LAUNCH(1, true, false, 8, true); break;
 		case 24: RK_LAUNCH2(1, true, false, 4, false, true); break;
+		case 27: RK_LAUNCH2(1, false, false, 4, false, true); break;
+		case 28: RK_LAUNCH3(1, true, false, 4, false, false, 2); break;
+		case 29: RK_LAUNCH3(1, true, false, 4, false, true, 2); break;
+		case 30: RK_LAUNCH3(1, true, false, 2, false, false, 2); break;
+		case 31: RK_LAUNCH3(1, true, false, 8, false, false, 2); break;
 		case 25: RK_LAUNCH2(1, true, false, 2, false, true); break;
 		case 26: RK_LAUNCH2(4, true, false, 4, false, true); break;
 		default: RK_LAUNCH(1, true, false, 1, true); break;
 	}
 	#undef RK_LAUNCH
 	#undef RK_LAUNCH2
+	#undef RK_LAUNCH3
 }
 
 // Shipping shape (benchmarks/tune_expand.py, profiles/r01_tune_expand.json): 64-parent wave tiles + non-temporal
@@ -738,13 +774,17 @@ void launch_expand12_variant(int variant, const int8_t *parents, int8_t *childre
 void launch_expand12(const int8_t *parents, int8_t *children, uint8_t *solved, long long *stats, size_t n, hipStream_t st)
 {
 	const size_t n_tiles = (n + EXP_ROUND - 1) / EXP_ROUND;
-	const unsigned grid = grid_for(n_tiles, EXP_WAVES, 1u << 20);
-	if (solved != nullptr)
-		hipLaunchKernelGGL((k_expand12<true, 1, true, false>), dim3(grid), dim3(EXP_WAVES * WAVE), 0, st, (const uint32_t *)parents,
-		                   (u32x4 *)children, (uint32_t *)solved, stats, n, n_tiles, (unsigned int *)nullptr);
-	else
-		hipLaunchKernelGGL((k_expand12<false, 1, true, false>), dim3(grid), dim3(EXP_WAVES * WAVE), 0, st, (const uint32_t *)parents,
-		                   (u32x4 *)children, (uint32_t *)nullptr, (long long *)nullptr, n, n_tiles, (unsigned int *)nullptr);
+	// Up to ~8 M parents one tile per wave is fastest (the 20 B/parent input stays in the 256 MiB Infinity Cache between
+	// launches and the dispatcher keeps up).  Beyond that the input comes from HBM and a wave that only ever sees one tile
+	// waits a full memory latency for it: a persistent grid whose waves prefetch their next tile's parents while expanding
+	// the current one is 1.3x faster there (profiles/r01_tune_expand_shapes.json, 16 M parents: 1.12 ms -> 0.84 ms).
+	const bool persistent = n_tiles > (size_t)131072;
+	const unsigned grid = persistent ? 2048u : grid_for(n_tiles, EXP_WAVES, 1u << 20);
+	#define RK_GO(FLAGS, PRE) hipLaunchKernelGGL((k_expand12<FLAGS, 1, true, false, EXP_WAVES, false, PRE>), dim3(grid), dim3(EXP_WAVES * WAVE), 0, st, \
+		(const uint32_t *)parents, (u32x4 *)children, (uint32_t *)(FLAGS ? solved : nullptr), FLAGS ? stats : (long long *)nullptr, n, n_tiles, (unsigned int *)nullptr)
+	if (solved != nullptr) { if (persistent) RK_GO(true, true); else RK_GO(true, false); }
+	else                   { if (persistent) RK_GO(false, true); else RK_GO(false, false); }
+	#undef RK_GO
 }
 
 void launch_expand12_soa(const uint32_t *parents, uint32_t *children, uint8_t *solved, long long *stats, size_t n, hipStream_t st)

@@ -340,3 +340,30 @@ def test_soa_fanout_matches_aos(n):
 	assert (fl.cpu().numpy().T.reshape(-1) == ref_fl).all()
 	st = stats.cpu().numpy()
 	assert st[0] == ref_fl.sum() and st[1] == (np.flatnonzero(ref_fl)[0] if ref_fl.any() else _ffi.INT64_MAX)
+
+
+def test_large_batch_persistent_path():
+	"""Above 8.4 M parents the launcher switches to the persistent, input-prefetching grid: same results."""
+	n = 8_500_000 + 37
+	g = torch.Generator(device="cuda")
+	g.manual_seed(5)
+	acts = torch.randint(0, 12, (18, n), device="cuda", dtype=torch.uint8, generator=g)
+	parents = cube.device.apply_sequences(acts, False, True)
+	del acts
+	parents[12345] = dev(orc.rotate(orc.SOLVED, 0, 1))
+	parents[n - 1] = dev(orc.rotate(orc.SOLVED, 3, 0))
+	stats = torch.tensor([0, _ffi.INT64_MAX], dtype=torch.int64, device="cuda")
+	ch, fl = cube.device.expand12(parents, stats=stats)
+	# a sample against the oracle, everything against the inverse-move property
+	pick = torch.cat([torch.arange(0, 4096), torch.randint(0, n, (4096,)), torch.arange(n - 4096, n)]).cuda()
+	ref_ch, ref_fl = c_oracle.expand12(parents[pick].cpu().numpy())
+	got = ch.view(n, 12, 20)[pick].reshape(-1, 20).cpu().numpy()
+	assert (got == ref_ch).all()
+	assert (fl.view(n, 12)[pick].reshape(-1).cpu().numpy() == ref_fl).all()
+	rev = torch.arange(12, dtype=torch.uint8, device="cuda").bitwise_xor(1).repeat(n)
+	back = cube.device.multi_rotate(ch, rev)
+	del rev
+	assert bool((back.view(n, 12, 20) == parents.view(n, 1, 20)).all())
+	assert int(fl.sum()) == stats[0].item() >= 2 and stats[1].item() == int(torch.nonzero(fl)[0])
+	ch2, _ = cube.device.expand12(parents, want_flags=False)
+	assert torch.equal(ch2, ch)
