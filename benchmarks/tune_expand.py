@@ -23,14 +23,13 @@ lib = _ffi.lib()
 lib.rkx_expand12_variant.restype = C.c_int
 lib.rkx_expand12_variant.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]
 
-NAMES = {0: "nt, tile256", 1: "plain, tile256", 2: "nt, tile64", 3: "plain, tile64",
+NAMES = {0: "nt, tile256", 1: "plain, tile256", 3: "plain, tile64",
          16: "nt, tile64, 4 waves/WG (shipping)", 17: "nt, tile64, 2 waves/WG", 18: "nt, tile64, 8 waves/WG", 19: "nt, tile64, 1 wave/WG",
-         20: "nt, tile64, 4 waves/WG, direct input loads", 21: "nt, tile64, 2 waves/WG, direct input loads",
-         22: "nt, tile64, 8 waves/WG, direct input loads", 23: "nt, tile64, 1 wave/WG, direct input loads",
-         24: "nt, tile64, 4 waves/WG, parents preloaded before the table barrier", 25: "nt, tile64, 2 waves/WG, preload",
-         26: "nt, tile256, 4 waves/WG, preload", 27: "plain, tile64, 4 waves/WG, preload",
-         28: "nt, tile64, 4 waves/WG, half-round staging (16 waves/CU)", 29: "nt, tile64, 4 waves/WG, half-round staging, preload",
-         30: "nt, tile64, 2 waves/WG, half-round staging", 31: "nt, tile64, 8 waves/WG, half-round staging"}
+         24: "nt, tile64, 4 waves/WG, software-pipelined input", 26: "nt, tile256, 4 waves/WG, pipelined input",
+         27: "plain, tile64, 4 waves/WG, pipelined input",
+         28: "nt, tile64, 4 waves/WG, half-round staging (16 waves/CU)", 29: "nt, tile64, 4 waves/WG, half-round staging, pipelined input"}
+# (dropped from the code after losing clearly, results kept in profiles/r01_tune_expand*.json: atomic tile counter on a
+#  persistent grid, per-lane strided input loads)
 
 
 def main(variants):
@@ -73,5 +72,5 @@ def main(variants):
 
 if __name__ == "__main__":
 	# arguments: variant or variant:grid_blocks
-	args = [a.split(":") for a in sys.argv[1:]] or [["16"], ["17"], ["18"], ["19"], ["20"], ["24"], ["24", "512"], ["24", "1024"], ["0"], ["1"]]
+	args = [a.split(":") for a in sys.argv[1:]] or [["16"], ["17"], ["18"], ["19"], ["24"], ["24", "2048"], ["28"], ["0"], ["1"], ["3"]]
 	main([(int(a[0]), int(a[1]) if len(a) > 1 else 0) for a in args])

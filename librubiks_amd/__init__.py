@@ -6,27 +6,28 @@ librubiks_amd -- MI355X-native drop-in for the cube hot path of peleiden/librubi
 
 All cube arithmetic runs in hand-written HIP kernels (librubiks_hip.so, C ABI in include/rubiks_hip.h).
 There is no CPU fallback: without the library or without a gfx950 device the compute entry points raise.
-Mirrors librubiks/__init__.py:5-22 for the `cpu` / `gpu` / `no_grad` / `reset_cuda` names.
+
+The names `cpu`, `gpu`, `no_grad` and `reset_cuda` exist because callers of the reference import them from its
+package root (librubiks/__init__.py:5-22).
 """
-import functools
-
 import torch
-
-cpu = torch.device("cpu")
-gpu = torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
 __version__ = "0.1.0"
 
+_HAS_DEVICE = torch.cuda.is_available()
 
-def reset_cuda():
-	torch.cuda.empty_cache()
-	if torch.cuda.is_available():
-		torch.cuda.synchronize()
+#: where one-hot batches and the nets live; the host device when no GPU is visible (then only host helpers work)
+gpu = torch.device("cuda") if _HAS_DEVICE else torch.device("cpu")
+cpu = torch.device("cpu")
 
 
 def no_grad(fun):
-	@functools.wraps(fun)
-	def wrapper(*args, **kwargs):
-		with torch.no_grad():
-			return fun(*args, **kwargs)
-	return wrapper
+	"""Decorator: run `fun` without autograd bookkeeping."""
+	return torch.no_grad()(fun)
+
+
+def reset_cuda():
+	"""Release cached device memory and wait for the device to go idle."""
+	if _HAS_DEVICE:
+		torch.cuda.empty_cache()
+		torch.cuda.synchronize()

@@ -235,9 +235,8 @@ int rkx_expand12_variant(int variant, const int8_t *d_parents, int8_t *d_childre
                          unsigned int *d_counter, int grid_blocks, void *stream)
 {
 	if (!d_parents || !d_children || !d_solved || misaligned(d_children, 16)) return fail(RK_EINVAL, "rkx_expand12_variant: bad argument");
-	if ((variant & 4) && !d_counter) return fail(RK_EINVAL, "rkx_expand12_variant: dynamic variants need a counter");
-	if (variant & 4) RK_HIP(hipMemsetAsync(d_counter, 0, sizeof(unsigned int), (hipStream_t)stream));
-	launch_expand12_variant(variant, d_parents, d_children, d_solved, d_stats, n, d_counter, grid_blocks, (hipStream_t)stream);
+	(void)d_counter;
+	launch_expand12_variant(variant, d_parents, d_children, d_solved, d_stats, n, grid_blocks, (hipStream_t)stream);
 	RK_HIP(hipGetLastError());
 	return RK_OK;
 }

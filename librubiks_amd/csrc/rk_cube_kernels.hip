@@ -35,19 +35,21 @@ struct ExpandWaveLdsT {
 	uint32_t flags[EXP_ROUND * 3];             // 768 B: 12 solved bytes per parent
 };
 
+// The kernel's shape is a set of compile-time knobs; benchmarks/tune_expand.py A/Bs them (profiles/r01_tune_expand*.json).
+// Two shapes ship (launch_expand12): <ROUNDS 1, NT, 4 waves> with one tile per wave, and the same with PRELOAD on a
+// persistent grid for batches whose input no longer fits the Infinity Cache.  Shapes that were tried and dropped from the
+// code because they lost clearly: an atomic tile counter (2-5x slower), per-lane strided input loads instead of the LDS
+// transpose (3 % slower).
 // ROUNDS = rounds of 64 parents per wave tile (4 -> 256-parent tiles with 16 B/lane input loads, 1 -> 64-parent tiles);
-// NT = non-temporal output stores; DYNAMIC = tiles handed out by an atomic counter to a persistent grid;
-// NWAVES = waves per workgroup; DIRECT_IN = each lane loads its own parent's five dwords straight from global memory
-// (stride 20 B across lanes, the lines are shared through L1) instead of the coalesced-load + LDS transpose.
+// NT = non-temporal output stores; NWAVES = waves per workgroup;
 // PRELOAD = software pipeline of the input: a tile's parent loads are issued one tile ahead (the first before the move
 // table is staged), so a wave that walks several tiles (persistent grid) never waits a full HBM latency per tile.
 // HALVES = 2 stages and streams a round's children in two halves of 32 parents: half the LDS per wave (8.4 KB), which lets
 // twice as many waves live on a CU (LDS, not registers, caps the occupancy of this kernel) at the price of 128 VGPRs.
-template <bool WITH_FLAGS, int ROUNDS = 4, bool NT = true, bool DYNAMIC = false, int NWAVES = EXP_WAVES, bool DIRECT_IN = false,
-          bool PRELOAD = false, int HALVES = 1>
+template <bool WITH_FLAGS, int ROUNDS = 1, bool NT = true, int NWAVES = EXP_WAVES, bool PRELOAD = false, int HALVES = 1>
 __global__ __launch_bounds__(NWAVES * WAVE, (HALVES == 2 ? 4 : 1))
 void k_expand12(const uint32_t *__restrict__ parents, u32x4 *__restrict__ children, uint32_t *__restrict__ solved,
-                long long *__restrict__ stats, size_t n, size_t n_tiles, unsigned int *__restrict__ tile_counter = nullptr)
+                long long *__restrict__ stats, size_t n, size_t n_tiles)
 {
 	constexpr int EXP_TILE = EXP_ROUND * ROUNDS;
 	constexpr int EXP_WAVES = NWAVES;
@@ -57,7 +59,6 @@ void k_expand12(const uint32_t *__restrict__ parents, u32x4 *__restrict__ childr
 
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	size_t tile = (size_t)blockIdx.x * EXP_WAVES + wv;
-	static_assert(!PRELOAD || (!DYNAMIC && !DIRECT_IN), "PRELOAD is for the statically scheduled LDS-transpose input path");
 	uint32_t pre[5 * ROUNDS];
 	bool have_pre = false;
 	if (PRELOAD && tile < n_tiles) {
@@ -80,13 +81,7 @@ void k_expand12(const uint32_t *__restrict__ parents, u32x4 *__restrict__ childr
 	ExpandWaveLds &L = s_wave[wv];
 	uint32_t *stage_dw = reinterpret_cast<uint32_t *>(L.stage);
 
-	for (;;) {
-		if (DYNAMIC) {
-			unsigned int t = 0;
-			if (lane == 0) t = atomicAdd(tile_counter, 1u);
-			tile = __shfl(t, 0, 64);
-		}
-		if (tile >= n_tiles) break;
+	for (; tile < n_tiles; tile += (size_t)gridDim.x * EXP_WAVES) {
 		const size_t p0 = tile * EXP_TILE;
 		const int np = (int)((n - p0 < (size_t)EXP_TILE) ? (n - p0) : (size_t)EXP_TILE);   // parents in this tile
 
@@ -94,14 +89,7 @@ void k_expand12(const uint32_t *__restrict__ parents, u32x4 *__restrict__ childr
 		uint32_t par[ROUNDS][5];
 		{
 			const uint32_t *src = parents + p0 * STATE_DWORDS;
-			if (DIRECT_IN) {
-				#pragma unroll
-				for (int q = 0; q < ROUNDS; q++) {
-					const int local = q * 64 + lane;
-					#pragma unroll
-					for (int j = 0; j < 5; j++) par[q][j] = local < np ? src[local * 5 + j] : 0u;
-				}
-			} else if (PRELOAD && have_pre) {
+			if (PRELOAD && have_pre) {
 				#pragma unroll
 				for (int k = 0; k < 5 * ROUNDS; k++) stage_dw[k * 64 + lane] = pre[k];
 				// issue the NEXT tile's loads now; they land while this tile is being expanded
@@ -129,14 +117,12 @@ void k_expand12(const uint32_t *__restrict__ parents, u32x4 *__restrict__ childr
 					stage_dw[idx] = idx < ndw ? src[idx] : 0u;
 				}
 			}
-			if (!DIRECT_IN) {
-				wave_lds_fence();
+			wave_lds_fence();
+			#pragma unroll
+			for (int q = 0; q < ROUNDS; q++)
 				#pragma unroll
-				for (int q = 0; q < ROUNDS; q++)
-					#pragma unroll
-					for (int j = 0; j < 5; j++) par[q][j] = stage_dw[(q * 64 + lane) * 5 + j];
-				wave_lds_fence();
-			}
+				for (int j = 0; j < 5; j++) par[q][j] = stage_dw[(q * 64 + lane) * 5 + j];
+			wave_lds_fence();
 		}
 
 		#pragma unroll
@@ -230,7 +216,6 @@ void k_expand12(const uint32_t *__restrict__ parents, u32x4 *__restrict__ childr
 			}
 			wave_lds_fence();
 		}
-		if (!DYNAMIC) tile += (size_t)gridDim.x * EXP_WAVES;
 	}
 }
 
@@ -723,49 +708,31 @@ static inline unsigned grid_for(size_t work_items, size_t per_block, unsigned ca
 	return (unsigned)b;
 }
 
-// tuning aid (benchmarks/tune_expand.py): the same kernel in its other shapes.
-//   variant 0..7   : bit 0 = plain stores, bit 1 = 64-parent tiles, bit 2 = persistent grid + atomic tile counter
-//   variant 16..23 : 64-parent tiles, non-temporal; bits 0-1 = waves per workgroup {4, 2, 8, 1}, bit 2 = direct input loads
-//   variant 24..27 : software-pipelined input (PRELOAD): tile64 x 4 waves, tile64 x 2 waves, tile256 x 4 waves, tile64 x 4 waves
-//                    with plain stores; combine with grid_blocks for a persistent grid
+// tuning aid (benchmarks/tune_expand.py): the same kernel in its other shapes; grid_blocks > 0 makes the grid persistent.
 void launch_expand12_variant(int variant, const int8_t *parents, int8_t *children, uint8_t *solved, long long *stats, size_t n,
-                             unsigned int *counter, int grid_blocks, hipStream_t st)
+                             int grid_blocks, hipStream_t st)
 {
-	#define RK_LAUNCH(R, NTS, DYN, W, DIN) RK_LAUNCH2(R, NTS, DYN, W, DIN, false)
-	#define RK_LAUNCH2(R, NTS, DYN, W, DIN, PRE) RK_LAUNCH3(R, NTS, DYN, W, DIN, PRE, 1)
-	#define RK_LAUNCH3(R, NTS, DYN, W, DIN, PRE, HLV) do { \
+	#define RK_LAUNCH(R, NTS, W, PRE, HLV) do { \
 		const size_t n_tiles = (n + 64 * (R) - 1) / (64 * (R)); \
 		unsigned grid = grid_for(n_tiles, (W), 1u << 20); \
 		if (grid_blocks > 0) grid = (unsigned)grid_blocks; \
-		hipLaunchKernelGGL((k_expand12<true, R, NTS, DYN, W, DIN, PRE, HLV>), dim3(grid), dim3((W) * WAVE), 0, st, \
-			(const uint32_t *)parents, (u32x4 *)children, (uint32_t *)solved, stats, n, n_tiles, counter); } while (0)
+		hipLaunchKernelGGL((k_expand12<true, R, NTS, W, PRE, HLV>), dim3(grid), dim3((W) * WAVE), 0, st, \
+			(const uint32_t *)parents, (u32x4 *)children, (uint32_t *)solved, stats, n, n_tiles); } while (0)
 	switch (variant) {
-		case 0: RK_LAUNCH(4, true, false, 4, false); break;
-		case 1: RK_LAUNCH(4, false, false, 4, false); break;
-		case 2: RK_LAUNCH(1, true, false, 4, false); break;
-		case 3: RK_LAUNCH(1, false, false, 4, false); break;
-		case 4: RK_LAUNCH(4, true, true, 4, false); break;
-		case 6: RK_LAUNCH(1, true, true, 4, false); break;
-		case 16: RK_LAUNCH(1, true, false, 4, false); break;
-		case 17: RK_LAUNCH(1, true, false, 2, false); break;
-		case 18: RK_LAUNCH(1, true, false, 8, false); break;
-		case 19: RK_LAUNCH(1, true, false, 1, false); break;
-		case 20: RK_LAUNCH(1, true, false, 4, true); break;
-		case 21: RK_LAUNCH(1, true, false, 2, true); break;
-		case 22: RK_LAUNCH(1, true, false, 8, true); break;
-		case 24: RK_LAUNCH2(1, true, false, 4, false, true); break;
-		case 27: RK_LAUNCH2(1, false, false, 4, false, true); break;
-		case 28: RK_LAUNCH3(1, true, false, 4, false, false, 2); break;
-		case 29: RK_LAUNCH3(1, true, false, 4, false, true, 2); break;
-		case 30: RK_LAUNCH3(1, true, false, 2, false, false, 2); break;
-		case 31: RK_LAUNCH3(1, true, false, 8, false, false, 2); break;
-		case 25: RK_LAUNCH2(1, true, false, 2, false, true); break;
-		case 26: RK_LAUNCH2(4, true, false, 4, false, true); break;
-		default: RK_LAUNCH(1, true, false, 1, true); break;
+		case 0: RK_LAUNCH(4, true, 4, false, 1); break;        // 256-parent tiles, non-temporal
+		case 1: RK_LAUNCH(4, false, 4, false, 1); break;       // 256-parent tiles, plain stores
+		case 3: RK_LAUNCH(1, false, 4, false, 1); break;       // 64-parent tiles, plain stores
+		case 17: RK_LAUNCH(1, true, 2, false, 1); break;       // 2 waves per workgroup
+		case 18: RK_LAUNCH(1, true, 8, false, 1); break;       // 8 waves per workgroup
+		case 19: RK_LAUNCH(1, true, 1, false, 1); break;       // 1 wave per workgroup
+		case 24: RK_LAUNCH(1, true, 4, true, 1); break;        // software-pipelined input
+		case 26: RK_LAUNCH(4, true, 4, true, 1); break;        // ... with 256-parent tiles
+		case 27: RK_LAUNCH(1, false, 4, true, 1); break;       // ... with plain stores
+		case 28: RK_LAUNCH(1, true, 4, false, 2); break;       // half-round staging (16 waves/CU)
+		case 29: RK_LAUNCH(1, true, 4, true, 2); break;        // ... pipelined
+		default: RK_LAUNCH(1, true, 4, false, 1); break;       // 16: the shipping shape
 	}
 	#undef RK_LAUNCH
-	#undef RK_LAUNCH2
-	#undef RK_LAUNCH3
 }
 
 // Shipping shape (benchmarks/tune_expand.py, profiles/r01_tune_expand.json): 64-parent wave tiles + non-temporal
@@ -780,8 +747,8 @@ void launch_expand12(const int8_t *parents, int8_t *children, uint8_t *solved, l
 	// the current one is 1.3x faster there (profiles/r01_tune_expand_shapes.json, 16 M parents: 1.12 ms -> 0.84 ms).
 	const bool persistent = n_tiles > (size_t)131072;
 	const unsigned grid = persistent ? 2048u : grid_for(n_tiles, EXP_WAVES, 1u << 20);
-	#define RK_GO(FLAGS, PRE) hipLaunchKernelGGL((k_expand12<FLAGS, 1, true, false, EXP_WAVES, false, PRE>), dim3(grid), dim3(EXP_WAVES * WAVE), 0, st, \
-		(const uint32_t *)parents, (u32x4 *)children, (uint32_t *)(FLAGS ? solved : nullptr), FLAGS ? stats : (long long *)nullptr, n, n_tiles, (unsigned int *)nullptr)
+	#define RK_GO(FLAGS, PRE) hipLaunchKernelGGL((k_expand12<FLAGS, 1, true, EXP_WAVES, PRE>), dim3(grid), dim3(EXP_WAVES * WAVE), 0, st, \
+		(const uint32_t *)parents, (u32x4 *)children, (uint32_t *)(FLAGS ? solved : nullptr), FLAGS ? stats : (long long *)nullptr, n, n_tiles)
 	if (solved != nullptr) { if (persistent) RK_GO(true, true); else RK_GO(true, false); }
 	else                   { if (persistent) RK_GO(false, true); else RK_GO(false, false); }
 	#undef RK_GO

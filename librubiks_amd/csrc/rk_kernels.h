@@ -12,7 +12,7 @@ const Tables &host_tables();
 
 void launch_expand12(const int8_t *parents, int8_t *children, uint8_t *solved, long long *stats, size_t n, hipStream_t st);
 void launch_expand12_variant(int variant, const int8_t *parents, int8_t *children, uint8_t *solved, long long *stats, size_t n,
-                             unsigned int *counter, int grid_blocks, hipStream_t st);
+                             int grid_blocks, hipStream_t st);
 void launch_expand12_soa(const uint32_t *parents, uint32_t *children, uint8_t *solved, long long *stats, size_t n, hipStream_t st);
 void launch_states_soa(const int8_t *states, uint32_t *planes, size_t n, bool to_soa, hipStream_t st);
 void launch_multi_rotate(const int8_t *states, const uint8_t *actions_or_faces, const uint8_t *dirs_or_null, int8_t *out,
