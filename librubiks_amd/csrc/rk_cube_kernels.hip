@@ -38,8 +38,11 @@ struct ExpandWaveLdsT {
 // The kernel's shape is a set of compile-time knobs; benchmarks/tune_expand.py A/Bs them (profiles/r01_tune_expand*.json).
 // Two shapes ship (launch_expand12): <ROUNDS 1, NT, 4 waves> with one tile per wave, and the same with PRELOAD on a
 // persistent grid for batches whose input no longer fits the Infinity Cache.  Shapes that were tried and dropped from the
-// code because they lost clearly: an atomic tile counter (2-5x slower), per-lane strided input loads instead of the LDS
-// transpose (3 % slower).
+// code because they lost or tied: an atomic tile counter (2-5x slower), per-lane strided input loads instead of the LDS
+// transpose (3 % slower), and a "split" shape where a lane owns (parent, four children) and a wave writes only 3 840 B
+// at 32 waves/CU (45.5 us vs 44.6 us).  The geometry-only diagnostics below show why shapes stop mattering: the same
+// loads and stores WITHOUT any table look-up, transpose or LDS traffic take 44.2 us -- the kernel is bound by its
+// memory access pattern (7 % reads, three streams), which runs at ~6.1 TB/s on this chip.
 // ROUNDS = rounds of 64 parents per wave tile (4 -> 256-parent tiles with 16 B/lane input loads, 1 -> 64-parent tiles);
 // NT = non-temporal output stores; NWAVES = waves per workgroup;
 // PRELOAD = software pipeline of the input: a tile's parent loads are issued one tile ahead (the first before the move
@@ -708,6 +711,68 @@ static inline unsigned grid_for(size_t work_items, size_t per_block, unsigned ca
 	return (unsigned)b;
 }
 
+// Diagnostic only (never used by the product): the fan-out kernel's memory geometry without its work.  Every wave
+// reads its tile's 1 280 B, then writes 15 KiB + 768 B of junk derived from it with the same store instructions.
+//   mode 0: straight from registers (no LDS staging)     mode 1: through the LDS staging round trip
+//   mode 2: no parent loads (stores only)                mode 3: no parent loads and no flag stream (one pure store stream)
+// Timing it against the real kernel separates "the store pattern" from "the table look-ups and transposes".
+template <int MODE, bool NT>
+__global__ __launch_bounds__(EXP_WAVES * WAVE)
+void k_expand12_geometry(const uint32_t *__restrict__ parents, u32x4 *__restrict__ children, uint32_t *__restrict__ solved, size_t n_tiles)
+{
+	__shared__ ExpandWaveLdsT<1> s_wave[EXP_WAVES];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	ExpandWaveLdsT<1> &L = s_wave[wv];
+	for (size_t tile = (size_t)blockIdx.x * EXP_WAVES + wv; tile < n_tiles; tile += (size_t)gridDim.x * EXP_WAVES) {
+		const uint32_t *src = parents + tile * 64 * STATE_DWORDS;
+		uint32_t x = (uint32_t)tile;
+		if (MODE < 2) {
+			#pragma unroll
+			for (int k = 0; k < 5; k++) x ^= src[k * 64 + lane];
+		}
+		u32x4 *dst = children + tile * 64 * 15;
+		if (MODE == 1) {
+			#pragma unroll
+			for (int v = 0; v < 15; v++) L.stage[lane * 15 + v] = u32x4{x, x + v, x ^ v, x};
+			wave_lds_fence();
+		}
+		#pragma unroll
+		for (int v = 0; v < 15; v++) {
+			const u32x4 val = MODE == 1 ? L.stage[v * 64 + lane] : u32x4{x, x + v, x ^ v, x};
+			if (NT) __builtin_nontemporal_store(val, dst + v * 64 + lane);
+			else dst[v * 64 + lane] = val;
+		}
+		if (MODE != 3 && lane < 48) {
+			const u32x4 val = u32x4{x, x, x, x};
+			if (NT) __builtin_nontemporal_store(val, reinterpret_cast<u32x4 *>(solved + tile * 192) + lane);
+			else reinterpret_cast<u32x4 *>(solved + tile * 192)[lane] = val;
+		}
+		if (MODE == 1) wave_lds_fence();
+	}
+}
+
+// Diagnostic only: a pure store stream of `total_kib` KiB in configurable geometry, no LDS, no loads.  Each wave writes
+// CH chunks of 1 KiB, either as one contiguous run or interleaved with the other waves of its workgroup.
+template <int CH, bool INTERLEAVE, bool NT>
+__global__ __launch_bounds__(256)
+void k_store_geometry(u32x4 *__restrict__ dst, size_t total_kib)
+{
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const size_t wave_global = (size_t)blockIdx.x * 4 + wv;
+	const size_t n_waves = (total_kib + CH - 1) / CH;
+	for (size_t w = wave_global; w < n_waves; w += (size_t)gridDim.x * 4) {
+		const u32x4 val = u32x4{(uint32_t)w, (uint32_t)lane, 0u, 1u};
+		#pragma unroll
+		for (int v = 0; v < CH; v++) {
+			const size_t kib = INTERLEAVE ? ((w / 4) * 4 * CH + (size_t)v * 4 + (w & 3)) : (w * CH + v);
+			if (kib < total_kib) {
+				if (NT) __builtin_nontemporal_store(val, dst + kib * 64 + lane);
+				else dst[kib * 64 + lane] = val;
+			}
+		}
+	}
+}
+
 // tuning aid (benchmarks/tune_expand.py): the same kernel in its other shapes; grid_blocks > 0 makes the grid persistent.
 void launch_expand12_variant(int variant, const int8_t *parents, int8_t *children, uint8_t *solved, long long *stats, size_t n,
                              int grid_blocks, hipStream_t st)
@@ -730,6 +795,41 @@ void launch_expand12_variant(int variant, const int8_t *parents, int8_t *childre
 		case 27: RK_LAUNCH(1, false, 4, true, 1); break;       // ... with plain stores
 		case 28: RK_LAUNCH(1, true, 4, false, 2); break;       // half-round staging (16 waves/CU)
 		case 29: RK_LAUNCH(1, true, 4, true, 2); break;        // ... pipelined
+		case 40: case 41: case 42: case 43: {                  // geometry-only diagnostics (outputs are junk; n must be a multiple of 64)
+			const size_t n_tiles = n / 64;
+			unsigned grid = grid_blocks > 0 ? (unsigned)grid_blocks : grid_for(n_tiles, EXP_WAVES, 1u << 20);
+			if (variant == 40) hipLaunchKernelGGL((k_expand12_geometry<0, true>), dim3(grid), dim3(EXP_WAVES * WAVE), 0, st, (const uint32_t *)parents, (u32x4 *)children, (uint32_t *)solved, n_tiles);
+			if (variant == 41) hipLaunchKernelGGL((k_expand12_geometry<1, true>), dim3(grid), dim3(EXP_WAVES * WAVE), 0, st, (const uint32_t *)parents, (u32x4 *)children, (uint32_t *)solved, n_tiles);
+			if (variant == 42) hipLaunchKernelGGL((k_expand12_geometry<0, false>), dim3(grid), dim3(EXP_WAVES * WAVE), 0, st, (const uint32_t *)parents, (u32x4 *)children, (uint32_t *)solved, n_tiles);
+			if (variant == 43) hipLaunchKernelGGL((k_expand12_geometry<1, false>), dim3(grid), dim3(EXP_WAVES * WAVE), 0, st, (const uint32_t *)parents, (u32x4 *)children, (uint32_t *)solved, n_tiles);
+			break;
+		}
+		case 44: case 45: case 46: case 47: {
+			const size_t n_tiles = n / 64;
+			unsigned grid = grid_blocks > 0 ? (unsigned)grid_blocks : grid_for(n_tiles, EXP_WAVES, 1u << 20);
+			if (variant == 44) hipLaunchKernelGGL((k_expand12_geometry<2, true>), dim3(grid), dim3(EXP_WAVES * WAVE), 0, st, (const uint32_t *)parents, (u32x4 *)children, (uint32_t *)solved, n_tiles);
+			if (variant == 45) hipLaunchKernelGGL((k_expand12_geometry<3, true>), dim3(grid), dim3(EXP_WAVES * WAVE), 0, st, (const uint32_t *)parents, (u32x4 *)children, (uint32_t *)solved, n_tiles);
+			if (variant == 46) hipLaunchKernelGGL((k_expand12_geometry<2, false>), dim3(grid), dim3(EXP_WAVES * WAVE), 0, st, (const uint32_t *)parents, (u32x4 *)children, (uint32_t *)solved, n_tiles);
+			if (variant == 47) hipLaunchKernelGGL((k_expand12_geometry<3, false>), dim3(grid), dim3(EXP_WAVES * WAVE), 0, st, (const uint32_t *)parents, (u32x4 *)children, (uint32_t *)solved, n_tiles);
+			break;
+		}
+		case 50: case 51: case 52: case 53: case 54: case 55: case 56: case 57: case 58: case 59: {   // pure store streams over the children buffer
+			const size_t kib = n * 240 / 1024;
+			#define RK_ST(CH, IL, NTS) do { const size_t nw = (kib + CH - 1) / CH; unsigned grid = grid_blocks > 0 ? (unsigned)grid_blocks : grid_for(nw, 4, 1u << 22); \
+				hipLaunchKernelGGL((k_store_geometry<CH, IL, NTS>), dim3(grid), dim3(256), 0, st, (u32x4 *)children, kib); } while (0)
+			if (variant == 50) RK_ST(15, false, true);
+			if (variant == 51) RK_ST(15, false, false);
+			if (variant == 52) RK_ST(4, false, true);
+			if (variant == 53) RK_ST(4, false, false);
+			if (variant == 54) RK_ST(4, true, false);
+			if (variant == 55) RK_ST(15, true, true);
+			if (variant == 56) RK_ST(1, false, false);
+			if (variant == 57) RK_ST(1, false, true);
+			if (variant == 58) RK_ST(60, false, true);
+			if (variant == 59) RK_ST(16, true, false);
+			#undef RK_ST
+			break;
+		}
 		default: RK_LAUNCH(1, true, 4, false, 1); break;       // 16: the shipping shape
 	}
 	#undef RK_LAUNCH
