@@ -132,7 +132,8 @@ int rk_as_correct686(const int8_t *d_states, float *d_out, size_t n, void *strea
  *                     (agents.py:316-317), then relax the already-seen children (agents.py:326-329, 333-367).
  *                     Skip it when `won` (the reference returns before relaxing).
  * Results are identical to the reference's arrays (same index numbering, G, parents, parent_actions) whenever the
- * value net returns the same numbers. */
+ * value net returns the same numbers.  An engine handle is not thread-safe: one host thread drives it, on one stream
+ * at a time (different handles are independent). */
 typedef struct rk_astar rk_astar_t;
 int rk_astar_create(rk_astar_t **out, size_t capacity, int max_expansions);
 int rk_astar_destroy(rk_astar_t *h);
