@@ -151,6 +151,13 @@ def _new_stats() -> torch.Tensor:
 	return torch.tensor([0, INT64_MAX], dtype=torch.int64, device=gpu)
 
 
+def _check_dev(t: torch.Tensor, dtype: torch.dtype, what: str):
+	"""The C ABI takes raw pointers: refuse anything that is not a dense device tensor of the expected element type."""
+	if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+		raise ValueError(f"{what} must be a contiguous CUDA tensor of dtype {dtype}, got "
+		                 f"{type(t).__name__}" + (f" {t.dtype} on {t.device}, contiguous={t.is_contiguous()}" if isinstance(t, torch.Tensor) else ""))
+
+
 class device:
 	"""
 	Device-resident forms of the hot path: torch CUDA tensors in and out, no host copies, no synchronisation.
@@ -161,9 +168,15 @@ class device:
 	def multi_rotate(states: torch.Tensor, actions: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
 		"""out[i] = move actions[i] (uint8 action index) applied to states[i]   (cube.py:256-263)."""
 		_ffi.require_gpu()
+		_check_dev(states, torch.int8, "states")
+		_check_dev(actions, torch.uint8, "actions")
 		n = len(states)
+		if len(actions) != n:
+			raise ValueError(f"{n} states but {len(actions)} actions")
 		if out is None:
 			out = torch.empty_like(states)
+		else:
+			_check_dev(out, torch.int8, "out")
 		_ffi.check(_ffi.lib().rk_multi_rotate(_repr_id(), states.data_ptr(), actions.data_ptr(), out.data_ptr(), n, _ffi.stream_ptr()))
 		return out
 
@@ -176,11 +189,22 @@ class device:
 		`stats` (int64[2] = [count, first index], initialise to [0, INT64_MAX]) is updated if given.
 		"""
 		_ffi.require_gpu()
+		_check_dev(parents, torch.int8, "parents")
 		n = len(parents)
 		if children is None:
 			children = torch.empty((12 * n, *parents.shape[1:]), dtype=torch.int8, device=parents.device)
+		else:
+			_check_dev(children, torch.int8, "children")
+			if children.numel() != 12 * parents.numel():
+				raise ValueError("children must hold 12 states per parent")
 		if solved is None and want_flags:
 			solved = torch.empty(12 * n, dtype=torch.uint8, device=parents.device)
+		elif solved is not None:
+			_check_dev(solved, torch.uint8, "solved")
+			if solved.numel() != 12 * n:
+				raise ValueError("solved must hold 12 flags per parent")
+		if stats is not None:
+			_check_dev(stats, torch.int64, "stats")
 		_ffi.check(_ffi.lib().rk_expand12(
 			_repr_id(), parents.data_ptr(), children.data_ptr(),
 			solved.data_ptr() if solved is not None else None,
@@ -230,9 +254,14 @@ class device:
 	def multi_is_solved(states: torch.Tensor, flags: torch.Tensor = None, stats: torch.Tensor = None) -> torch.Tensor:
 		"""uint8 (n,) flags, 1 where the state is solved (cube.py:88-89)."""
 		_ffi.require_gpu()
+		_check_dev(states, torch.int8, "states")
 		n = len(states)
 		if flags is None:
 			flags = torch.empty(n, dtype=torch.uint8, device=states.device)
+		else:
+			_check_dev(flags, torch.uint8, "flags")
+		if stats is not None:
+			_check_dev(stats, torch.int64, "stats")
 		_ffi.check(_ffi.lib().rk_multi_is_solved(
 			_repr_id(), states.data_ptr(), flags.data_ptr(), stats.data_ptr() if stats is not None else None,
 			n, _ffi.stream_ptr()))
@@ -242,6 +271,7 @@ class device:
 	def apply_sequences(actions: torch.Tensor, with_solved: bool, only_last: bool) -> torch.Tensor:
 		"""actions uint8 (depth, games) -> states of every game along its move sequence (cube.py:218-232)."""
 		_ffi.require_gpu()
+		_check_dev(actions, torch.uint8, "actions")
 		depth, games = actions.shape
 		moves = depth - int(with_solved)
 		rows = 1 if only_last else moves + int(with_solved)
@@ -254,10 +284,15 @@ class device:
 	def as_oh(states: torch.Tensor, out: torch.Tensor = None, dtype: torch.dtype = torch.float32) -> torch.Tensor:
 		"""One-hot (n, 480 | 288) of `dtype` (float32, float16 or bfloat16)   (cube.py:265-277, 363-369)."""
 		_ffi.require_gpu()
+		_check_dev(states, torch.int8, "states")
 		n = len(states)
 		code = {torch.float32: _ffi.OH_F32, torch.float16: _ffi.OH_F16, torch.bfloat16: _ffi.OH_BF16}[dtype]
 		if out is None:
 			out = torch.empty((n, get_oh_shape()), dtype=dtype, device=states.device)
+		else:
+			_check_dev(out, dtype, "out")
+			if out.numel() < n * get_oh_shape():
+				raise ValueError("one-hot output too small")
 		_ffi.check(_ffi.lib().rk_as_oh(_repr_id(), states.data_ptr(), out.data_ptr(), code, n, _ffi.stream_ptr()))
 		return out
 

@@ -367,3 +367,25 @@ def test_large_batch_persistent_path():
 	assert int(fl.sum()) == stats[0].item() >= 2 and stats[1].item() == int(torch.nonzero(fl)[0])
 	ch2, _ = cube.device.expand12(parents, want_flags=False)
 	assert torch.equal(ch2, ch)
+
+
+def test_device_api_rejects_bad_tensors():
+	"""Raw pointers go to the C ABI: strided, wrongly typed or host tensors must be refused, not reinterpreted."""
+	p = dev(random_walk(64, 5, seed=1))
+	with pytest.raises(ValueError):
+		cube.device.expand12(p[::2])                                   # strided view
+	with pytest.raises(ValueError):
+		cube.device.expand12(p.to(torch.int32))
+	with pytest.raises(ValueError):
+		cube.device.expand12(p.cpu())
+	with pytest.raises(ValueError):
+		cube.device.multi_rotate(p, torch.zeros(64, dtype=torch.int64, device="cuda"))
+	with pytest.raises(ValueError):
+		cube.device.multi_rotate(p, torch.zeros(63, dtype=torch.uint8, device="cuda"))
+	with pytest.raises(ValueError):
+		cube.device.expand12(p, children=torch.empty((100, 20), dtype=torch.int8, device="cuda"))
+	with pytest.raises(ValueError):
+		cube.device.as_oh(p, out=torch.empty((64, 480), dtype=torch.float16, device="cuda"))
+	# the drop-in surface accepts strided / wider-typed input by making a dense int8 copy
+	assert (cube.multi_rotate(p[::2].cpu().numpy().astype(np.int64), np.zeros(32, int), np.ones(32, int))
+	        == orc.multi_rotate(p[::2].cpu().numpy(), np.zeros(32, int), np.ones(32, int))).all()
