@@ -84,6 +84,7 @@ class BFS(Agent):
 	def search(self, state: np.ndarray, time_limit: float = None, max_states: int = None) -> bool:
 		time_limit, max_states = self.reset(time_limit, max_states)
 		t0 = time.perf_counter()
+		self.states = {}
 		if cube.is_solved(state):
 			return True
 		self.states = {state.tobytes(): (None, None)}          # state -> (predecessor key, action)
