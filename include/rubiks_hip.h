@@ -156,6 +156,31 @@ long long rk_astar_lookup(rk_astar_t *h, const int8_t *h_state, void *stream);
 /* The open queue in pop order: up to max_len (cost, index) pairs to HOST arrays; returns the count written. */
 long long rk_astar_export_open(rk_astar_t *h, double *h_costs, long long *h_indices, size_t max_len, void *stream);
 
+/* ---- batched A*: S independent searches in lock-step, no host synchronisation inside an iteration -------------
+ * Every search follows agents.py:171-413 exactly as rk_astar_* does; all sizes that vary (nodes popped, new states,
+ * queue length, won, out of budget) live in device memory, so one iteration of ALL searches is a fixed sequence of
+ * launches around one net forward on the padded (S * 12 N, 480) one-hot batch -- capturable in a hipGraph:
+ *   rk_astarb_step_expand : loop guard + pop + fan-out + membership / first-occurrence / append + goal test for every
+ *                           search, then the one-hot of the new states into d_onehot (S, 12 N, 480) (rows past a
+ *                           search's new states are zero)
+ *   rk_astarb_step_commit : d_values (S * 12 N) from the net; cost, push, relaxation, bookkeeping
+ *   rk_astarb_status      : synchronises; h_status (S, 6) int64 = done, won (2 = start already solved), n_states,
+ *                           iterations, queue length, index of the solved state
+ * rk_astarb_set_merge_bound tells the engine an upper bound of any search's queue length (the launch width of the
+ * queue merge); the host raises it from the status it polls (it starts at 12 N + 1 and the queue grows by at most
+ * 12 N per iteration). */
+typedef struct rk_astarb rk_astarb_t;
+int rk_astarb_create(rk_astarb_t **out, int n_searches, size_t capacity_per_search, int max_expansions);
+int rk_astarb_destroy(rk_astarb_t *h);
+int rk_astarb_reset(rk_astarb_t *h, const int8_t *h_start_states, const long long *h_max_states, double lambda, void *stream);
+int rk_astarb_set_merge_bound(rk_astarb_t *h, long long bound);
+int rk_astarb_step_expand(rk_astarb_t *h, void *d_onehot, int out_dtype, void *stream);
+int rk_astarb_step_commit(rk_astarb_t *h, const float *d_values, void *stream);
+int rk_astarb_status(rk_astarb_t *h, long long *h_status, void *stream);
+int rk_astarb_export(rk_astarb_t *h, int search, size_t first, size_t count, int8_t *h_states, double *h_G,
+                     long long *h_parents, long long *h_parent_actions, void *stream);
+long long rk_astarb_path(rk_astarb_t *h, int search, long long index, long long *h_actions, size_t max_len, void *stream);
+
 /* ---- hash-sharded A* across the GPUs of a node (BASELINE config 5; no counterpart in the reference) ------------
  * One engine per GPU/rank holds the states it owns, owner(state) = rk_shard_owner(state, world).  The host drives
  * one iteration as: pick the globally best N open nodes (all-gather of the queue heads) -> rk_astar_shard_pop

@@ -56,6 +56,15 @@ SIGNATURES = {
 	"rk_astar_path": (C.c_longlong, [_vp, C.c_longlong, _vp, _sz, _vp]),
 	"rk_astar_lookup": (C.c_longlong, [_vp, _vp, _vp]),
 	"rk_astar_export_open": (C.c_longlong, [_vp, _vp, _vp, _sz, _vp]),
+	"rk_astarb_create": (_i, [C.POINTER(_vp), _i, _sz, _i]),
+	"rk_astarb_destroy": (_i, [_vp]),
+	"rk_astarb_reset": (_i, [_vp, _vp, _vp, C.c_double, _vp]),
+	"rk_astarb_set_merge_bound": (_i, [_vp, C.c_longlong]),
+	"rk_astarb_step_expand": (_i, [_vp, _vp, _i, _vp]),
+	"rk_astarb_step_commit": (_i, [_vp, _vp, _vp]),
+	"rk_astarb_status": (_i, [_vp, _vp, _vp]),
+	"rk_astarb_export": (_i, [_vp, _i, _sz, _sz, _vp, _vp, _vp, _vp, _vp]),
+	"rk_astarb_path": (C.c_longlong, [_vp, _i, C.c_longlong, _vp, _sz, _vp]),
 	"rk_astar_create_sharded": (_i, [C.POINTER(_vp), _sz, _i, _i, _i]),
 	"rk_shard_owner": (_i, [_vp, _i]),
 	"rk_astar_shard_reset": (_i, [_vp, _vp, C.c_double, _vp]),

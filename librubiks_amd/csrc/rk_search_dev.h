@@ -1,0 +1,103 @@
+// Device-side pieces shared by the search engines (single A*, sharded A*, batched A*): queue records and their order,
+// the state hash, order-preserving compaction inside a workgroup, binary search in a sorted run.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include "rk_device.h"
+
+namespace rk {
+
+struct Rec { uint64_t key; uint64_t idx; };
+
+constexpr uint32_t TENT = 0x80000000u;          // hash slot holds a batch position, not yet an index
+constexpr uint32_t NO_MARK = 0xFFFFFFFFu;
+
+enum { CTR_NEW = 0, CTR_WON = 1, CTR_SOLVED_IDX = 2, CTR_COUNT = 4 };
+
+__device__ __forceinline__ bool rec_less(const Rec &a, const Rec &b)
+{
+	return a.key < b.key || (a.key == b.key && a.idx < b.idx);
+}
+
+// float64 -> uint64 whose unsigned order is the float order (no NaNs expected)
+__device__ __forceinline__ uint64_t sortable_key(double c)
+{
+	c = c + 0.0;                                  // -0.0 -> +0.0: Python compares them equal
+	const uint64_t u = (uint64_t)__double_as_longlong(c);
+	return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+__host__ __device__ inline double key_to_double(uint64_t k)
+{
+	const uint64_t u = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+	double d;
+	memcpy(&d, &u, sizeof d);
+	return d;
+}
+
+__host__ __device__ inline uint32_t hash_state(const uint32_t s[5])
+{
+	uint64_t h = 0x9E3779B97F4A7C15ull;
+	#pragma unroll
+	for (int j = 0; j < 5; j++) {
+		h ^= s[j];
+		h *= 0xFF51AFD7ED558CCDull;
+		h ^= h >> 29;
+	}
+	return (uint32_t)(h ^ (h >> 32));
+}
+
+// owner rank of a state in a hash-sharded search: a remix of the hash, so that it is independent of the table slot
+__host__ __device__ inline uint32_t owner_of(const uint32_t s[5], uint32_t world)
+{
+	const uint32_t h = hash_state(s) * 0x9E3779B1u;
+	return (uint32_t)(((uint64_t)h * world) >> 32);
+}
+
+__device__ __forceinline__ void load5(const uint32_t *p, uint32_t s[5])
+{
+	#pragma unroll
+	for (int j = 0; j < 5; j++) s[j] = p[j];
+}
+
+__device__ __forceinline__ bool equal5(const uint32_t a[5], const uint32_t *p)
+{
+	return ((a[0] ^ p[0]) | (a[1] ^ p[1]) | (a[2] ^ p[2]) | (a[3] ^ p[3]) | (a[4] ^ p[4])) == 0;
+}
+
+// ---- order-preserving compaction across many workgroups ---------------------------------------------------------
+constexpr int SCAN_BLOCK = 1024;
+
+// exclusive prefix of a 0/1 predicate inside a 1024-thread workgroup; *total = number of set predicates
+__device__ __forceinline__ int block_rank(bool pred, int *s_wave /* [16] */, int *total)
+{
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const unsigned long long b = __ballot(pred);
+	const int in_wave = __popcll(b & ((1ull << lane) - 1ull));
+	__syncthreads();                                  // s_wave may still be read from a previous call
+	if (lane == 0) s_wave[wv] = __popcll(b);
+	__syncthreads();
+	int before = 0, tot = 0;
+	#pragma unroll
+	for (int w = 0; w < 16; w++) {
+		const int v = s_wave[w];
+		before += w < wv ? v : 0;
+		tot += v;
+	}
+	*total = tot;
+	return before + in_wave;
+}
+
+__device__ __forceinline__ int lower_bound_rec(const Rec *a, int n, const Rec &x)
+{
+	int lo = 0, hi = n;
+	while (lo < hi) {
+		const int mid = (lo + hi) >> 1;
+		if (rec_less(a[mid], x)) lo = mid + 1; else hi = mid;
+	}
+	return lo;
+}
+
+
+}  // namespace rk

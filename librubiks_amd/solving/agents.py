@@ -643,3 +643,125 @@ class MCTS(DeepAgent):
 
 	def __len__(self):
 		return self._n
+
+
+class AStarBatch(DeepAgent):
+	"""
+	S independent batch weighted A* searches advanced in lock-step on the GPU (engine rk_astarb_*).  Every search
+	follows the reference's AStar exactly (agents.py:171-413): same node numbering, G, parents and action queue as
+	running the reference on that start state alone, whenever the net returns the same numbers.
+
+	One iteration of all searches = one fixed sequence of launches around one net forward on the padded
+	(S * 12 N, 480) batch; nothing synchronises, so `use_graph=True` captures the iteration in a hipGraph and replays
+	it.  The host polls the per-search status every `poll` iterations (searches that are solved or out of budget are
+	skipped on the device in between).  This is the throughput form for evaluating many scrambles -- the reference's
+	Evaluator runs its games one after the other.
+	"""
+
+	def __init__(self, net, lambda_: float, expansions: int, n_searches: int, capacity: int = 200_000):
+		super().__init__(net)
+		self.lambda_, self.expansions, self.n_searches = float(lambda_), int(expansions), int(n_searches)
+		self.capacity = max(int(capacity), 12 * self.expansions + 2)
+		self._h = None
+		self.status = None
+		self.iterations = 0
+
+	def _engine(self):
+		if self._h is None:
+			h = C.c_void_p()
+			_ffi.check(_ffi.lib().rk_astarb_create(C.byref(h), self.n_searches, self.capacity, self.expansions))
+			self._h = h
+		return self._h
+
+	def __del__(self):
+		try:
+			if getattr(self, "_h", None) is not None:
+				_ffi.lib().rk_astarb_destroy(self._h)
+				self._h = None
+		except Exception:
+			pass
+
+	def _poll(self) -> np.ndarray:
+		st = np.zeros((self.n_searches, 6), np.int64)
+		_ffi.check(_ffi.lib().rk_astarb_status(self._h, st.ctypes.data, _ffi.stream_ptr()))
+		self.status = st
+		return st
+
+	def _step(self, oh, code):
+		lib, h = _ffi.lib(), self._h
+		_ffi.check(lib.rk_astarb_step_expand(h, oh.data_ptr(), code, _ffi.stream_ptr()))
+		values = _value_f32(self.net(oh, policy=False, value=True))
+		self._keep = values
+		_ffi.check(lib.rk_astarb_step_commit(h, values.data_ptr(), _ffi.stream_ptr()))
+
+	@no_grad
+	def search(self, states: np.ndarray, time_limit: float = None, max_states=None, use_graph: bool = False, poll: int = 8) -> np.ndarray:
+		"""Runs all searches until each is solved or out of budget / time; returns the bool vector `solved` (S,)."""
+		_ffi.require_gpu()
+		t0 = time.perf_counter()
+		assert time_limit or max_states is not None
+		self.net.eval()
+		time_limit = time_limit or 1e10
+		S, K = self.n_searches, 12 * self.expansions
+		states = np.ascontiguousarray(states, dtype=np.int8).reshape(S, 20)
+		budget = np.minimum(np.broadcast_to(np.asarray(self.capacity if max_states is None else max_states, dtype=np.int64), (S,)),
+		                    self.capacity).copy()
+		h, lib = self._engine(), _ffi.lib()
+		_ffi.check(lib.rk_astarb_reset(h, states.ctypes.data, budget.ctypes.data, self.lambda_, _ffi.stream_ptr()))
+		oh_dtype = _oh_dtype(self.net)
+		oh = torch.empty((S * K, 480), dtype=oh_dtype, device=gpu)
+		code = _OH_CODES[oh_dtype]
+		self.iterations = 0
+		graph, graph_bound = None, 0
+		longest = 1                                                     # longest queue seen at the last poll
+		while time.perf_counter() - t0 < time_limit:
+			bound = longest + poll * K                                  # a queue grows by at most 12 N per iteration
+			_ffi.check(lib.rk_astarb_set_merge_bound(h, bound))
+			if use_graph and (graph is None or bound > graph_bound):
+				graph_bound = min(2 * bound, self.capacity)
+				_ffi.check(lib.rk_astarb_set_merge_bound(h, graph_bound))
+				side = torch.cuda.Stream()
+				side.wait_stream(torch.cuda.current_stream())
+				with torch.cuda.stream(side):
+					self._step(oh, code)                                # a real iteration; also warms the allocator
+				torch.cuda.current_stream().wait_stream(side)
+				self.iterations += 1
+				graph = torch.cuda.CUDAGraph()
+				with torch.cuda.graph(graph):
+					self._step(oh, code)
+			for _ in range(poll):
+				if graph is not None:
+					graph.replay()
+				else:
+					self._step(oh, code)
+			self.iterations += poll
+			st = self._poll()
+			longest = int(st[:, 4].max())
+			if st[:, 0].all():
+				break
+		return self._poll()[:, 1] != 0
+
+	def action_queue_of(self, search: int) -> deque:
+		st = self.status[search]
+		if st[1] != 1:                                                   # unsolved, or the start was already solved
+			return deque()
+		buf = (C.c_longlong * 4096)()
+		n = _ffi.lib().rk_astarb_path(self._h, search, int(st[5]), buf, 4096, _ffi.stream_ptr())
+		if n < 0:
+			_ffi.check(int(n))
+		return deque(int(a) for a in buf[:n])
+
+	def arrays_of(self, search: int):
+		"""(states, G, parents, parent_actions) of one search, rows 0..n (row 0 unused), in the reference's dtypes."""
+		n = int(self._poll()[search, 2])
+		states, G = np.zeros((n + 1, 20), np.int8), np.zeros(n + 1)
+		parents, pact = np.zeros(n + 1, np.int64), np.zeros(n + 1, np.int64)
+		_ffi.check(_ffi.lib().rk_astarb_export(self._h, search, 1, n, states[1:].ctypes.data, G[1:].ctypes.data, parents[1:].ctypes.data,
+		                                       pact[1:].ctypes.data, _ffi.stream_ptr()))
+		return states, G, parents, pact
+
+	def __len__(self):
+		return int(self.status[:, 2].sum()) if self.status is not None else 0
+
+	def __str__(self):
+		return f"Batched AStar x{self.n_searches} (lambda={self.lambda_}, N={self.expansions})"
