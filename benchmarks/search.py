@@ -70,6 +70,47 @@ def bench_astar(args):
 	return rows
 
 
+def bench_astar_batch(args):
+	"""Many scrambles at once (the evaluation workload): AStarBatch against the same searches run one after the other."""
+	from librubiks_amd.solving.agents import AStarBatch
+	net = FcSmall().cuda().eval()
+	if args.bf16:
+		net = net.to(torch.bfloat16)
+	S = args.searches
+	starts = []
+	for g in range(S):
+		np.random.seed(g)
+		starts.append(cube.scramble(args.depth, True)[0])
+	starts = np.array(starts)
+	out = {}
+	for mode in ("sequential", "batch", "batch+graph"):
+		torch.cuda.synchronize()
+		t0 = time.perf_counter()
+		if mode == "sequential":
+			agent = AStar(net, args.lam, args.expansions)
+			states = iters = solved = 0
+			for g in range(min(S, args.sequential_games)):
+				solved += agent.search(starts[g], None, args.max_states)
+				states += len(agent)
+				iters += agent.iterations
+			scale = S / min(S, args.sequential_games)
+			states, iters, solved = states * scale, iters * scale, solved * scale
+			torch.cuda.synchronize()
+			dt = (time.perf_counter() - t0) * scale
+		else:
+			agent = AStarBatch(net, args.lam, args.expansions, S, capacity=args.max_states)
+			res = agent.search(starts, max_states=args.max_states, use_graph=mode.endswith("graph"), poll=args.poll)
+			torch.cuda.synchronize()
+			dt = time.perf_counter() - t0
+			states, iters, solved = int(agent.status[:, 2].sum()), int(agent.status[:, 3].sum()), int(res.sum())
+		out[mode] = {"seconds": dt, "states": int(states), "states_per_s": states / dt, "search_iterations": int(iters), "solved": int(solved)}
+	row = {"bench": "astar_batch", "config": f"{S} depth-{args.depth} scrambles, lambda={args.lam}, N={args.expansions}, max_states={args.max_states} each, "
+	       f"fc_small random init {'bf16' if args.bf16 else 'fp32'}", **out,
+	       "speedup_batch_graph_vs_sequential": out["sequential"]["seconds"] / out["batch+graph"]["seconds"]}
+	print(json.dumps(row), flush=True)
+	return row
+
+
 def bench_mcts(args):
 	net = FcSmall().cuda().eval()
 	T = args.trees
@@ -97,7 +138,9 @@ def bench_mcts(args):
 
 if __name__ == "__main__":
 	ap = argparse.ArgumentParser()
-	ap.add_argument("what", choices=["astar", "mcts"])
+	ap.add_argument("what", choices=["astar", "mcts", "astar_batch"])
+	ap.add_argument("--searches", type=int, default=64)
+	ap.add_argument("--sequential-games", type=int, default=16)
 	ap.add_argument("--games", type=int, default=5)
 	ap.add_argument("--depth", type=int, default=14)
 	ap.add_argument("--expansions", type=int, default=1000)
@@ -112,4 +155,4 @@ if __name__ == "__main__":
 	ap.add_argument("--max-path", type=int, default=16384)
 	a = ap.parse_args()
 	_ffi.check(_ffi.lib().rk_init(0))
-	bench_astar(a) if a.what == "astar" else bench_mcts(a)
+	{"astar": bench_astar, "mcts": bench_mcts, "astar_batch": bench_astar_batch}[a.what](a)
