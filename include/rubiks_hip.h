@@ -164,8 +164,8 @@ long long rk_astar_export_open(rk_astar_t *h, double *h_costs, long long *h_indi
  *                           search, then the one-hot of the new states into d_onehot (S, 12 N, 480) (rows past a
  *                           search's new states are zero)
  *   rk_astarb_step_commit : d_values (S * 12 N) from the net; cost, push, relaxation, bookkeeping
- *   rk_astarb_status      : synchronises; h_status (S, 6) int64 = done, won (2 = start already solved), n_states,
- *                           iterations, queue length, index of the solved state
+ *   rk_astarb_status      : synchronises; h_status (S, 7) int64 = done, won (2 = start already solved), n_states,
+ *                           iterations, queue length, index of the solved state, error (1 = merge bound too small)
  * rk_astarb_set_merge_bound tells the engine an upper bound of any search's queue length (the launch width of the
  * queue merge); the host raises it from the status it polls (it starts at 12 N + 1 and the queue grows by at most
  * 12 N per iteration). */

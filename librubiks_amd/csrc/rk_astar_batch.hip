@@ -336,13 +336,14 @@ __global__ void kb_relax_2b(BatchDev d)
 	}
 }
 
-__global__ void kb_end(BatchDev d)
+__global__ void kb_end(BatchDev d, int merge_width)
 {
 	const int s = blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= d.S) return;
 	int32_t *c = ctr_of(d, s);
 	if (c[B_NPOP] == 0) return;
 	c[B_OPEN] = c[B_OPEN] - c[B_NPOP] + c[B_NNEW];
+	if (c[B_OPEN] > merge_width) { c[B_ERROR] = 1; c[B_DONE] = 1; }         // the host's queue-length bound was too small: the merge was cut short
 	c[B_CUR] ^= 1;
 	if (c[B_WON]) c[B_DONE] = 1;
 }
@@ -499,7 +500,7 @@ int rk_astarb_step_commit(rk_astarb_t *h, const float *d_values, void *stream)
 	hipLaunchKernelGGL(kb_relax_1b, gK, dim3(256), 0, st, d);
 	hipLaunchKernelGGL(kb_relax_2a, gK, dim3(256), 0, st, d);
 	hipLaunchKernelGGL(kb_relax_2b, dim3(nblk(d.N), d.S), dim3(256), 0, st, d);
-	hipLaunchKernelGGL(kb_end, gS, dim3(256), 0, st, d);
+	hipLaunchKernelGGL(kb_end, gS, dim3(256), 0, st, d, h->merge_bound + d.K);
 	RK_HIP(hipGetLastError());
 	h->pending = false;
 	return RK_OK;
@@ -515,8 +516,8 @@ int rk_astarb_status(rk_astarb_t *h, long long *h_status, void *stream)
 	RK_HIP(hipStreamSynchronize(st));
 	for (size_t s = 0; s < S; s++) {
 		const int32_t *r = c.data() + s * B_STRIDE;
-		long long *o = h_status + 6 * s;
-		o[0] = r[B_DONE]; o[1] = r[B_WON]; o[2] = r[B_NSTATES]; o[3] = r[B_ITERS]; o[4] = r[B_OPEN]; o[5] = r[B_SOLVED];
+		long long *o = h_status + 7 * s;
+		o[0] = r[B_DONE]; o[1] = r[B_WON]; o[2] = r[B_NSTATES]; o[3] = r[B_ITERS]; o[4] = r[B_OPEN]; o[5] = r[B_SOLVED]; o[6] = r[B_ERROR];
 	}
 	return RK_OK;
 }

@@ -682,8 +682,10 @@ class AStarBatch(DeepAgent):
 			pass
 
 	def _poll(self) -> np.ndarray:
-		st = np.zeros((self.n_searches, 6), np.int64)
+		st = np.zeros((self.n_searches, 7), np.int64)
 		_ffi.check(_ffi.lib().rk_astarb_status(self._h, st.ctypes.data, _ffi.stream_ptr()))
+		if st[:, 6].any():
+			raise _ffi.RubiksHipError(f"batched A* engine error codes {st[:, 6].tolist()} (queue-length bound too small)")
 		self.status = st
 		return st
 

@@ -73,3 +73,28 @@ def test_mcts_budget_and_done_trees_are_frozen():
 	alone = agent2.tree_arrays(0)
 	for k in ("states", "neighbors", "N", "W", "L", "leaves"):
 		assert (snap[k] == alone[k]).all(), k
+
+
+def test_astar_batch_argument_and_bound_errors():
+	lib = _ffi.lib()
+	h = C.c_void_p()
+	assert lib.rk_astarb_create(C.byref(h), 0, 1000, 10) == -1
+	assert lib.rk_astarb_create(C.byref(h), 2, 100, 10) == -1 and b"12 * expansions" in lib.rk_last_error()
+	_ffi.check(lib.rk_astarb_create(C.byref(h), 2, 5000, 10))
+	oh = torch.empty((2 * 120, 480), dtype=torch.float32, device="cuda")
+	assert lib.rk_astarb_step_expand(h, oh.data_ptr(), 0, None) == -4              # not reset
+	np.random.seed(77)
+	starts = np.array([orc.scramble(15, True)[0] for _ in range(2)])
+	_ffi.check(lib.rk_astarb_reset(h, starts.ctypes.data, None, 0.5, None))
+	vals = torch.zeros(240, dtype=torch.float32, device="cuda")
+	assert lib.rk_astarb_step_commit(h, vals.data_ptr(), None) == -4               # nothing pending
+	# a deliberately wrong (too small) queue bound must be reported, not silently truncate the queue
+	for it in range(8):
+		_ffi.check(lib.rk_astarb_set_merge_bound(h, 1))
+		_ffi.check(lib.rk_astarb_step_expand(h, oh.data_ptr(), 0, None))
+		assert lib.rk_astarb_step_expand(h, oh.data_ptr(), 0, None) == -4          # pending
+		_ffi.check(lib.rk_astarb_step_commit(h, vals.data_ptr(), None))
+	st = np.zeros((2, 7), np.int64)
+	_ffi.check(lib.rk_astarb_status(h, st.ctypes.data, None))
+	assert st[:, 6].all() and st[:, 0].all(), st
+	_ffi.check(lib.rk_astarb_destroy(h))
