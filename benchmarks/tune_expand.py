@@ -35,6 +35,8 @@ NAMES = {0: "nt, tile256", 1: "plain, tile256", 3: "plain, tile64",
          54: "PURE STORES: 4 KiB per wave interleaved in the workgroup, plain", 55: "PURE STORES: 15 KiB per wave interleaved, nt",
          56: "PURE STORES: 1 KiB per wave, plain", 57: "PURE STORES: 1 KiB per wave, nt", 58: "PURE STORES: 60 KiB contiguous per wave, nt",
          59: "PURE STORES: 16 KiB per wave interleaved, plain",
+         70: "GEOMETRY ONLY: one 1 KiB store per wave (16-wave workgroup per 64 parents: 15 chunk waves + 1 flag wave), nt",
+         71: "GEOMETRY ONLY: one 1 KiB store per wave, plain",
          42: "GEOMETRY ONLY: plain stores from registers", 43: "GEOMETRY ONLY: LDS round trip + plain stores",
          28: "nt, tile64, 4 waves/WG, half-round staging (16 waves/CU)", 29: "nt, tile64, 4 waves/WG, half-round staging, pipelined input"}
 # (dropped from the code after losing clearly, results kept in profiles/r01_tune_expand*.json: atomic tile counter on a

@@ -751,6 +751,43 @@ void k_expand12_geometry(const uint32_t *__restrict__ parents, u32x4 *__restrict
 	}
 }
 
+// Diagnostic only: the memory geometry of a "one 1 KiB store per wave" shape.  A 16-wave workgroup owns 64 parents:
+// waves 0..14 each read the parent dwords their 1 KiB chunk depends on (four cached 4-byte loads per lane) and issue ONE
+// 16 B/lane store; wave 15 reads the 64 parents and writes their 768 flag bytes.  Junk data, real addresses.
+template <bool NT>
+__global__ __launch_bounds__(1024)
+void k_expand12_geometry_chunk(const uint32_t *__restrict__ parents, u32x4 *__restrict__ children, uint32_t *__restrict__ solved, size_t n_groups)
+{
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const size_t g = blockIdx.x;
+	if (g >= n_groups) return;
+	const uint32_t *src = parents + g * 64 * STATE_DWORDS;
+	if (wv < 15) {
+		uint32_t v[4];
+		#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			const int D = wv * 256 + lane * 4 + i;          // dword of the group's 3 840-dword output
+			const int child = D / 5, j = D - child * 5;
+			const int parent = child / 12;
+			v[i] = src[parent * 5 + j] + (uint32_t)(child - parent * 12);
+		}
+		const u32x4 val = u32x4{v[0], v[1], v[2], v[3]};
+		u32x4 *dst = children + g * 960 + wv * 64 + lane;
+		if (NT) __builtin_nontemporal_store(val, dst);
+		else *dst = val;
+	} else {
+		uint32_t x = 0;
+		#pragma unroll
+		for (int j = 0; j < 5; j++) x ^= src[lane * 5 + j];
+		if (lane < 48) {
+			const u32x4 val = u32x4{x, x, x, x};
+			u32x4 *dst = reinterpret_cast<u32x4 *>(solved + g * 192) + lane;
+			if (NT) __builtin_nontemporal_store(val, dst);
+			else *dst = val;
+		}
+	}
+}
+
 // Diagnostic only: a pure store stream of `total_kib` KiB in configurable geometry, no LDS, no loads.  Each wave writes
 // CH chunks of 1 KiB, either as one contiguous run or interleaved with the other waves of its workgroup.
 template <int CH, bool INTERLEAVE, bool NT>
@@ -828,6 +865,12 @@ void launch_expand12_variant(int variant, const int8_t *parents, int8_t *childre
 			if (variant == 58) RK_ST(60, false, true);
 			if (variant == 59) RK_ST(16, true, false);
 			#undef RK_ST
+			break;
+		}
+		case 70: case 71: {
+			const size_t n_groups = n / 64;
+			if (variant == 70) hipLaunchKernelGGL((k_expand12_geometry_chunk<true>), dim3((unsigned)n_groups), dim3(1024), 0, st, (const uint32_t *)parents, (u32x4 *)children, (uint32_t *)solved, n_groups);
+			else hipLaunchKernelGGL((k_expand12_geometry_chunk<false>), dim3((unsigned)n_groups), dim3(1024), 0, st, (const uint32_t *)parents, (u32x4 *)children, (uint32_t *)solved, n_groups);
 			break;
 		}
 		default: RK_LAUNCH(1, true, 4, false, 1); break;       // 16: the shipping shape
