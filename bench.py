@@ -176,7 +176,7 @@ def main():
 			"transitions_per_s": 12 * value,
 			"roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
 			             "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
-			             "kernel": "rk::k_expand12<true, 1, true, false>", "kernel_ms": kernel_ms,
+			             "kernel": "rk::k_expand12<true, 1, true, 4, false, 1>", "kernel_ms": kernel_ms,
 			             "algorithmic_bytes_per_launch": BYTES_PER_PARENT * N_PARENTS},
 		}
 		if world == 1 and not args.no_cpu_baseline:
