@@ -543,12 +543,13 @@ class MCTS(DeepAgent):
 	"""
 	default_capacity = 200_000
 
-	def __init__(self, net, c: float, search_graph: bool, capacity: int = None):
+	def __init__(self, net, c: float, search_graph: bool, capacity: int = None, use_hipgraph: bool = False):
 		super().__init__(net)
 		self.c = c
 		self.search_graph = search_graph
 		self.nu = 100
 		self.capacity = capacity
+		self.use_hipgraph = use_hipgraph          # replay the simulation step as a captured hipGraph (the net must be capturable)
 		self._batch = None
 		self._arrays = None
 		self._n = 0
@@ -565,7 +566,8 @@ class MCTS(DeepAgent):
 		if self._batch is None or self._batch.capacity != cap or self._batch.c != float(self.c):
 			self._batch = MCTSBatch(self.net, self.c, 1, capacity=cap, nu=self.nu)
 		self._batch.net = self.net
-		solved = bool(self._batch.search(np.asarray(state)[None], time_limit=time_limit, max_states=cap, poll=8)[0])
+		solved = bool(self._batch.search(np.asarray(state)[None], time_limit=time_limit, max_states=cap, poll=8,
+		                                 use_graph=self.use_hipgraph)[0])
 		self._n = int(self._batch.status[0, 2])
 		self.action_queue = self._batch.action_queue_of(0)
 		if solved and self.search_graph and len(self.action_queue):

@@ -35,7 +35,7 @@ def test_reference_traces(golden, tag):
 	t = golden["mcts_trace"]
 	_, _, search_graph, max_states = (int(x) for x in t[f"{tag}_params"])
 	start = t[f"{tag}_start"]
-	agent = MCTS(StubNet(), float(t[f"{tag}_c"]), bool(search_graph))
+	agent = MCTS(StubNet(), float(t[f"{tag}_c"]), bool(search_graph), use_hipgraph=tag in ("b", "d"))
 	solved = agent.search(start, time_limit=None, max_states=max_states)
 	n = int(t[f"{tag}_n"])
 	assert solved == bool(t[f"{tag}_solved"]) and len(agent) == n
