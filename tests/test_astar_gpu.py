@@ -123,7 +123,8 @@ def test_real_net_invariants():
 	st, G, par, act = agent.states, agent.G, agent.parents, agent.parent_actions
 	pick = np.random.randint(2, n + 1, 300)
 	moved = orc.multi_rotate(st[par[pick]], act[pick] // 2, 1 - act[pick] % 2)
-	assert (moved == st[pick]).all() and (G[pick] == G[par[pick]] + 1).all()
+	# relaxation can lower a parent's G later without touching its children (as in the reference), hence >=
+	assert (moved == st[pick]).all() and (G[pick] >= G[par[pick]] + 1).all()
 	q = agent.open_queue
 	assert q == sorted(q)
 
