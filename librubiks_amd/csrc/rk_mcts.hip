@@ -230,26 +230,32 @@ void k_mcts_backup_select(MctsDev d, const float *probs, const float *values)
 	fence_wave_to_wave();
 
 	// ---- find_leaf ----
-	int cur = 1, len = 1;
+	// One round of loads per tree level: the leaf flag and the node's five rows are requested together, and the virtual
+	// loss the previous step owes this node's reverse edge (agents.py:591) is applied on arrival by the lane that owns
+	// that column, so there is no second dependent round trip for the read-modify-write.
+	int cur = 1, len = 1, owed_lane = -1;
 	for (;;) {
-		if (d.leaves[node0 + cur]) break;
 		const size_t r = (node0 + cur) * 12 + lane;
+		const uint8_t leaf = d.leaves[node0 + cur];
 		const int nA = active ? d.N[r] : 0;
+		const double pA = active ? d.P[r] : 0.0, wA = active ? d.W[r] : 0.0;
+		double lval = active ? d.L[r] : 0.0;
+		const int nb = active ? d.neighbors[r] : 0;
+		if (lane == owed_lane) { lval += d.nu; d.L[r] = lval; }            // agents.py:591
+		if (leaf) break;
 		int sumN = nA;
 		#pragma unroll
 		for (int m = 8; m > 0; m >>= 1) sumN += __shfl_xor(sumN, m, 16);
 		sumN = __shfl(sumN, 0, 64);
-		double x = -INFINITY, lval = 0.0;
-		int nb = 0, best_a = lane;
+		double x = -INFINITY;
+		int best_a = lane;
 		if (active) {
 			const double sqrtN = sqrt((double)sumN);
-			double U = d.c * d.P[r];
+			double U = d.c * pA;
 			U = U * sqrtN;
 			U = U / (double)(1 + nA);
-			lval = d.L[r];
-			const double Q = d.W[r] - lval;
+			const double Q = wA - lval;
 			x = U + Q;
-			nb = d.neighbors[r];
 		}
 		#pragma unroll
 		for (int m = 8; m > 0; m >>= 1) {                                  // first arg-max (np.argmax)
@@ -260,7 +266,7 @@ void k_mcts_backup_select(MctsDev d, const float *probs, const float *values)
 		best_a = __shfl(best_a, 0, 64);
 		const int next = __shfl(nb, best_a, 64);
 		if (lane == best_a) d.L[r] = lval + d.nu;                          // agents.py:589
-		if (lane == (best_a ^ 1)) d.L[(node0 + next) * 12 + lane] += d.nu; // agents.py:591
+		owed_lane = best_a ^ 1;
 		if (lane == 0) {
 			pacts[len - 1] = (uint8_t)best_a;
 			d.path_nodes[(size_t)t * d.max_path + len] = next;
