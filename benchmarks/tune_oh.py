@@ -1,0 +1,34 @@
+"""A/B of the one-hot kernel's tiling (states per workgroup step, persistent vs one-shot grid); tuning hook rkx_as_oh_variant."""
+import ctypes as C
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from librubiks_amd import _ffi, cube  # noqa: E402
+from benchmarks.kernels import timed  # noqa: E402
+
+lib = _ffi.lib()
+lib.rkx_as_oh_variant.restype = C.c_int
+lib.rkx_as_oh_variant.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+
+n = 500_000
+g = torch.Generator(device="cuda")
+g.manual_seed(1)
+states = cube.device.apply_sequences(torch.randint(0, 12, (20, n), device="cuda", dtype=torch.uint8, generator=g), False, True)
+for dt, code, width in ((torch.float32, 0, 1920), (torch.bfloat16, 2, 960)):
+	ref = cube.device.as_oh(states, dtype=dt)
+	bufs = [torch.empty_like(ref) for _ in range(3)]          # rotate outputs: 2.9 GB (f32) written between reuses
+	for tile in (64, 32, 16, 8):
+		for cap in (2048, 0):
+			i = [0]
+			def run():
+				i[0] += 1
+				_ffi.check(lib.rkx_as_oh_variant(tile, cap, states.data_ptr(), bufs[i[0] % 3].data_ptr(), code, n, _ffi.stream_ptr()))
+			run()
+			ok = bool(torch.equal(bufs[i[0] % 3], ref))
+			t = timed(run, 30)
+			print(json.dumps({"dtype": str(dt), "states_per_workgroup": tile, "grid": "persistent 2048" if cap else "one workgroup per tile",
+			                  "correct": ok, "ms": t * 1e3, "GB/s": round((20 + width) * n / t / 1e9, 1), "frac_of_8TBs": round((20 + width) * n / t / 8e12, 4)}), flush=True)

@@ -241,6 +241,14 @@ int rkx_expand12_variant(int variant, const int8_t *d_parents, int8_t *d_childre
 	return RK_OK;
 }
 
+int rkx_as_oh_variant(int tile, int grid_cap, const int8_t *d_states, void *d_out, int out_dtype, size_t n, void *stream)
+{
+	if (!d_states || !d_out || misaligned(d_out, 16)) return fail(RK_EINVAL, "rkx_as_oh_variant: bad argument");
+	launch_as_oh_variant(tile, grid_cap, d_states, d_out, out_dtype, n, (hipStream_t)stream);
+	RK_HIP(hipGetLastError());
+	return RK_OK;
+}
+
 int rk_multi_is_solved(int repr, const int8_t *d_states, uint8_t *d_flags, long long *d_stats, size_t n, void *stream)
 {
 	if (int e = check_repr(repr)) return e;

@@ -477,7 +477,7 @@ void k_apply_sequences(const uint8_t *__restrict__ actions, int moves, int games
 // ================================================================================================================
 // as_oh: (n, 20) int8 -> (n, 480) one-hot, oh[r][24 i + s[r][i]] = 1                            cube.py:265-277
 // Algorithmic bytes per state: 20 read + 480 * sizeof(T) written (1 920 for f32): a pure store stream.  A workgroup
-// encodes 64 states per step; each thread emits 16-byte chunks (4 f32 or 8 half/bf16 columns of one cubie).
+// encodes TILE states per step; each thread emits 16-byte chunks (4 f32 or 8 half/bf16 columns of one cubie).
 // ================================================================================================================
 template <typename T> struct OhOne;
 template <> struct OhOne<float>    { static constexpr uint32_t bits = 0x3F800000u; };
@@ -485,22 +485,22 @@ template <> struct OhOne<_Float16> { static constexpr uint32_t bits = 0x3C00u; }
 struct bf16_tag {};
 template <> struct OhOne<bf16_tag> { static constexpr uint32_t bits = 0x3F80u; };
 
-template <typename T, int ELEM_BYTES>
+template <typename T, int ELEM_BYTES, int TILE = 64>
 __global__ __launch_bounds__(256)
 void k_as_oh(const uint32_t *__restrict__ states, u32x4 *__restrict__ out, size_t n, size_t n_tiles)
 {
 	constexpr int E = 16 / ELEM_BYTES;            // columns per 16-byte chunk: 4 or 8
 	constexpr int CHUNKS_PER_ROW = 480 / E;       // 120 or 60
 	constexpr int CHUNKS_PER_CUBIE = 24 / E;      // 6 or 3
-	__shared__ uint32_t s_st[64 * STATE_DWORDS];
+	__shared__ uint32_t s_st[TILE * STATE_DWORDS];
 	const int tid = threadIdx.x;
 	const uint8_t *s_bytes = reinterpret_cast<const uint8_t *>(s_st);
 
 	for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-		const size_t p0 = tile * 64;
-		const int np = (int)((n - p0 < 64) ? (n - p0) : 64);
+		const size_t p0 = tile * TILE;
+		const int np = (int)((n - p0 < (size_t)TILE) ? (n - p0) : (size_t)TILE);
 		const int ndw = np * STATE_DWORDS;
-		for (int idx = tid; idx < 64 * STATE_DWORDS; idx += 256) s_st[idx] = idx < ndw ? states[p0 * STATE_DWORDS + idx] : 0u;
+		for (int idx = tid; idx < TILE * STATE_DWORDS; idx += 256) s_st[idx] = idx < ndw ? states[p0 * STATE_DWORDS + idx] : 0u;
 		__syncthreads();
 		const int nchunks = np * CHUNKS_PER_ROW;
 		u32x4 *dst = out + p0 * CHUNKS_PER_ROW;
@@ -937,16 +937,32 @@ void launch_apply_sequences(const uint8_t *actions, int moves, int games, int wi
 	hipLaunchKernelGGL(k_apply_sequences, dim3(grid), dim3(256), 0, st, actions, moves, games, with_solved, only_last, (uint32_t *)out);
 }
 
+// tuning aid (benchmarks/tune_oh.py): states per workgroup step and grid cap (0 = one workgroup per tile)
+void launch_as_oh_variant(int tile, int grid_cap, const int8_t *states, void *out, int out_dtype, size_t n, hipStream_t st)
+{
+	#define RK_OH(TL) do { const size_t nt = (n + (TL) - 1) / (TL); const unsigned grid = grid_for(nt, 1, grid_cap > 0 ? (unsigned)grid_cap : (1u << 22)); \
+		if (out_dtype == 0) hipLaunchKernelGGL((k_as_oh<float, 4, TL>), dim3(grid), dim3(256), 0, st, (const uint32_t *)states, (u32x4 *)out, n, nt); \
+		else hipLaunchKernelGGL((k_as_oh<bf16_tag, 2, TL>), dim3(grid), dim3(256), 0, st, (const uint32_t *)states, (u32x4 *)out, n, nt); } while (0)
+	if (tile == 8) RK_OH(8); else if (tile == 16) RK_OH(16); else if (tile == 32) RK_OH(32); else RK_OH(64);
+	#undef RK_OH
+}
+
+// Shipping tiling (benchmarks/tune_oh.py, outputs rotated so that nothing is rewritten in cache): one workgroup per tile
+// and about four 16-byte stores per thread -- 8 states per workgroup for f32, 16 for the 16-bit types: 5.6 / 6.1 TB/s
+// against 5.3 / 5.0 TB/s for 64-state tiles on a persistent grid (the same "few stores per wave" effect as in the fan-out).
 void launch_as_oh(const int8_t *states, void *out, int out_dtype, size_t n, hipStream_t st)
 {
-	const size_t n_tiles = (n + 63) / 64;
-	const unsigned grid = grid_for(n_tiles, 1, 256u * 8u);
-	if (out_dtype == 0)
-		hipLaunchKernelGGL((k_as_oh<float, 4>), dim3(grid), dim3(256), 0, st, (const uint32_t *)states, (u32x4 *)out, n, n_tiles);
-	else if (out_dtype == 1)
-		hipLaunchKernelGGL((k_as_oh<_Float16, 2>), dim3(grid), dim3(256), 0, st, (const uint32_t *)states, (u32x4 *)out, n, n_tiles);
-	else
-		hipLaunchKernelGGL((k_as_oh<bf16_tag, 2>), dim3(grid), dim3(256), 0, st, (const uint32_t *)states, (u32x4 *)out, n, n_tiles);
+	if (out_dtype == 0) {
+		const size_t n_tiles = (n + 7) / 8;
+		hipLaunchKernelGGL((k_as_oh<float, 4, 8>), dim3(grid_for(n_tiles, 1, 1u << 22)), dim3(256), 0, st, (const uint32_t *)states, (u32x4 *)out, n, n_tiles);
+	} else {
+		const size_t n_tiles = (n + 15) / 16;
+		const unsigned grid = grid_for(n_tiles, 1, 1u << 22);
+		if (out_dtype == 1)
+			hipLaunchKernelGGL((k_as_oh<_Float16, 2, 16>), dim3(grid), dim3(256), 0, st, (const uint32_t *)states, (u32x4 *)out, n, n_tiles);
+		else
+			hipLaunchKernelGGL((k_as_oh<bf16_tag, 2, 16>), dim3(grid), dim3(256), 0, st, (const uint32_t *)states, (u32x4 *)out, n, n_tiles);
+	}
 }
 
 void launch_rotate686(const int8_t *states, const uint8_t *actions, int8_t *out, size_t n_out, bool fanout, hipStream_t st)

@@ -20,6 +20,7 @@ void launch_multi_rotate(const int8_t *states, const uint8_t *actions_or_faces, 
 void launch_multi_is_solved(const int8_t *states, uint8_t *flags, long long *stats, size_t n, hipStream_t st);
 void launch_apply_sequences(const uint8_t *actions, int moves, int games, int with_solved, int only_last, int8_t *out,
                             hipStream_t st);
+void launch_as_oh_variant(int tile, int grid_cap, const int8_t *states, void *out, int out_dtype, size_t n, hipStream_t st);
 void launch_as_oh(const int8_t *states, void *out, int out_dtype, size_t n, hipStream_t st);
 
 void launch_rotate686(const int8_t *states, const uint8_t *actions, int8_t *out, size_t n_out, bool fanout, hipStream_t st);
