@@ -915,7 +915,7 @@ void launch_states_soa(const int8_t *states, uint32_t *planes, size_t n, bool to
 void launch_multi_rotate(const int8_t *states, const uint8_t *actions, const uint8_t *dirs, int8_t *out, size_t n, hipStream_t st)
 {
 	const size_t n_tiles = (n + ROW_TILE - 1) / ROW_TILE;
-	const unsigned grid = grid_for(n_tiles, ROW_WAVES, 256u * 8u);
+	const unsigned grid = grid_for(n_tiles, ROW_WAVES, 1u << 22);
 	if (dirs != nullptr)
 		hipLaunchKernelGGL(k_multi_rotate<true>, dim3(grid), dim3(ROW_WAVES * WAVE), 0, st, (const uint32_t *)states, actions, dirs,
 		                   (uint32_t *)out, n, n_tiles);
@@ -927,7 +927,7 @@ void launch_multi_rotate(const int8_t *states, const uint8_t *actions, const uin
 void launch_multi_is_solved(const int8_t *states, uint8_t *flags, long long *stats, size_t n, hipStream_t st)
 {
 	const size_t n_tiles = (n + ROW_TILE - 1) / ROW_TILE;
-	const unsigned grid = grid_for(n_tiles, ROW_WAVES, 256u * 8u);
+	const unsigned grid = grid_for(n_tiles, ROW_WAVES, 1u << 22);
 	hipLaunchKernelGGL(k_multi_is_solved, dim3(grid), dim3(ROW_WAVES * WAVE), 0, st, (const uint32_t *)states, flags, stats, n, n_tiles);
 }
 
