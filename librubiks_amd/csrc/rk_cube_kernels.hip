@@ -548,7 +548,7 @@ template <bool FANOUT>
 __global__ __launch_bounds__(256)
 void k_rotate686(const uint16_t *__restrict__ states, const uint8_t *__restrict__ actions, u32x4 *__restrict__ out, size_t n_in)
 {
-	constexpr int GROUP = FANOUT ? 16 : 64;               // source states per workgroup step
+	constexpr int GROUP = FANOUT ? 4 : 64;                // source states per workgroup step (about four stores per thread)
 	constexpr int OUT_PER_IN = FANOUT ? 12 : 1;
 	__shared__ __attribute__((aligned(16))) uint8_t s_src[N_ACTIONS * 144];
 	__shared__ __attribute__((aligned(16))) uint16_t s_in[GROUP * 144];
@@ -969,7 +969,7 @@ void launch_rotate686(const int8_t *states, const uint8_t *actions, int8_t *out,
 {
 	if (fanout) {
 		const size_t n_in = n_out / 12;
-		const unsigned grid = grid_for(n_in, 16, 1u << 20);
+		const unsigned grid = grid_for(n_in, 4, 1u << 22);
 		hipLaunchKernelGGL(k_rotate686<true>, dim3(grid), dim3(256), 0, st, (const uint16_t *)states, actions, (u32x4 *)out, n_in);
 	} else {
 		const unsigned grid = grid_for(n_out, 64, 1u << 20);
