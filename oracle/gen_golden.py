@@ -13,7 +13,8 @@ Fixtures
                     at n=10 000 and n=1 000 000), sequence_scrambler K5, one-hot, 6x8x6 moves
   cube_text.json    stringify() texts, iter_actions literals, hashes
   astar_trace.npz   unmodified reference AStar driven by an exact-integer stub net
-  mcts_trace.npz    unmodified reference MCTS driven by the same stub
+  mcts_trace.npz    unmodified reference MCTS driven by the same stub (one case with a non-uniform exact policy)
+  adi_trace.npz     unmodified reference Train.ADI_traindata (train.py:256-339), stub net, all four reward methods
 """
 import argparse
 import hashlib
@@ -228,11 +229,12 @@ def mcts_traces():
 		"c": dict(seed=2, depth=4, c=5.0, search_graph=False, max_states=10_000),   # solves at 3 307 states
 		"d": dict(seed=23, depth=12, c=2.5, search_graph=False, max_states=2_500),
 		"e": dict(seed=2, depth=2, c=1.0, search_graph=True, max_states=10_000),    # solves at 1 568 states
+		"f": dict(seed=31, depth=9, c=3.0, search_graph=False, max_states=3_000, net="policy"),   # non-uniform priors
 	}
 	for tag, c in cases.items():
 		np.random.seed(c["seed"])
 		state, faces, dirs = cube.scramble(c["depth"], True)
-		agent = agents.MCTS(StubNet(), c=c["c"], search_graph=c["search_graph"])
+		agent = agents.MCTS(PolicyStubNet() if c.get("net") == "policy" else StubNet(), c=c["c"], search_graph=c["search_graph"])
 		sims = [0]
 		inner = agent.expand_leaf
 		def counted(v, a, inner=inner, sims=sims):
@@ -254,10 +256,69 @@ def mcts_traces():
 		out[f"{tag}_W"] = agent.W[1:n + 1].astype(np.float32)   # exact: stub values are small integers
 		out[f"{tag}_L"] = agent.L[1:n + 1].astype(np.float32)
 		out[f"{tag}_V"] = agent.V[1:n + 1].astype(np.float32)
+		if c.get("net") == "policy":
+			out[f"{tag}_P"] = agent.P[1:n + 1].copy()                       # float64 of float32 softmax outputs
 		out[f"{tag}_action_queue"] = np.array(list(agent.action_queue), dtype=np.int64)
 		assert (agent.W[1:n + 1] == out[f"{tag}_W"]).all() and (agent.L[1:n + 1] == out[f"{tag}_L"]).all()
 		print(f"mcts {tag}: solved={solved} n={n} sims={sims[0]} queue_len={len(agent.action_queue)}")
 	np.savez_compressed(os.path.join(OUT, "mcts_trace.npz"), **out)
+
+
+class PolicyStubNet(StubNet):
+	"""
+	The stub with a NON-uniform policy whose softmax is exact on any hardware: every logit is 0 or -inf, and the number
+	of finite logits is 8 (corner 0 has an even code) or 4 (odd code), so the probabilities are exactly 0, 1/8 or 1/4
+	whether an implementation divides by the sum or multiplies by its reciprocal.  Used for one MCTS trace so that
+	selection with unequal priors is pinned to the reference and not only to the oracle port.
+	"""
+	@staticmethod
+	def logits_table() -> np.ndarray:
+		t = np.zeros((24, 12), np.float32)
+		for c in range(24):
+			banned = [(c + 3 * j) % 12 for j in range(4)] if c % 2 == 0 else [(c + j) % 12 for j in range(8)]
+			t[c, banned] = -np.inf
+		return t
+
+	def __call__(self, x, policy=True, value=True):
+		out = []
+		if policy:
+			code = x[:, :24].argmax(dim=1)                                   # code of corner 0 (0..23)
+			out.append(torch.from_numpy(self.logits_table())[code])
+		if value:
+			out.append(-(20 - (x * self.solved_oh).sum(dim=1, keepdim=True)))
+		return out if len(out) > 1 else out[0]
+
+
+def adi_traces():
+	"""
+	The unmodified reference `Train.ADI_traindata` (train.py:256-339) with the exact-integer stub net, fixed seeds, all
+	four reward methods.  `self` is a bare namespace carrying exactly the attributes the method reads.
+	"""
+	import types
+	from librubiks import train as ref_train
+	from librubiks.utils.ticktock import TickTock
+	out = {}
+	cases = {
+		"lapanfix": dict(seed=12, games=37, depth=9, alpha=0.3, ff=3),
+		"paper": dict(seed=12, games=37, depth=9, alpha=0.3, ff=3),
+		"schultzfix": dict(seed=13, games=20, depth=11, alpha=0.0, ff=1),
+		"reward0": dict(seed=14, games=50, depth=6, alpha=1.0, ff=4),
+	}
+	for method, c in cases.items():
+		me = types.SimpleNamespace(rollout_games=c["games"], rollout_depth=c["depth"], reward_method=method,
+		                           adi_ff_batches=c["ff"], tt=TickTock(), with_analysis=False)
+		me._get_adi_ff_slices = types.MethodType(ref_train.Train._get_adi_ff_slices, me)
+		np.random.seed(c["seed"])
+		oh, policy, value, lw = ref_train.Train.ADI_traindata(me, StubNet(), c["alpha"])
+		out[f"{method}_params"] = np.array([c["seed"], c["games"], c["depth"], c["ff"]])
+		out[f"{method}_alpha"] = np.array(c["alpha"])
+		out[f"{method}_oh_sha256"] = np.array(sha(oh.cpu().numpy()))
+		out[f"{method}_oh_idx"] = oh.cpu().numpy().reshape(len(oh), 20, 24).argmax(axis=2).astype(np.int8)   # = the states
+		out[f"{method}_policy"] = policy.numpy().astype(np.int64)
+		out[f"{method}_value"] = value.numpy().astype(np.float32)
+		out[f"{method}_loss_weights"] = lw.numpy().astype(np.float32)
+		print(f"adi {method}: n={len(oh)} value range {float(value.min())}..{float(value.max())} zeros={(value == 0).sum().item()}")
+	np.savez_compressed(os.path.join(OUT, "adi_trace.npz"), **out)
 
 
 if __name__ == "__main__":
@@ -266,9 +327,10 @@ if __name__ == "__main__":
 	ap.add_argument("--only", default="")
 	args = ap.parse_args()
 	os.makedirs(OUT, exist_ok=True)
-	todo = args.only.split(",") if args.only else ["tables", "kats", "astar", "mcts"]
+	todo = args.only.split(",") if args.only else ["tables", "kats", "astar", "mcts", "adi"]
 	if "tables" in todo: tables()
 	if "kats" in todo: kats(args.skip_1m)
 	if "astar" in todo: astar_traces()
 	if "mcts" in todo: mcts_traces()
+	if "adi" in todo: adi_traces()
 	print("golden vectors written to", OUT)

@@ -48,6 +48,62 @@ class StubNet:
 		return out if len(out) > 1 else out[0]
 
 
+class PolicyStubNet(StubNet):
+	"""
+	StubNet with a non-uniform policy that is exact on any hardware (the twin of gen_golden.py's PolicyStubNet): every
+	logit is 0 or -inf, 8 finite ones when corner 0 has an even code and 4 when odd, so the softmax is exactly 0, 1/8
+	or 1/4 whether an implementation divides by the sum or multiplies by its reciprocal.
+	"""
+	def __init__(self):
+		super().__init__()
+		t = np.zeros((24, 12), np.float32)
+		for c in range(24):
+			banned = [(c + 3 * j) % 12 for j in range(4)] if c % 2 == 0 else [(c + j) % 12 for j in range(8)]
+			t[c, banned] = -np.inf
+		self.table = t
+		self._tab_dev = {}
+
+	def __call__(self, x, policy=True, value=True):
+		import torch
+		out = []
+		if policy:
+			if isinstance(x, torch.Tensor):
+				if x.device not in self._tab_dev:
+					self._tab_dev[x.device] = torch.from_numpy(self.table).to(x.device)
+				out.append(self._tab_dev[x.device][x[:, :24].float().argmax(dim=1)])
+			else:
+				out.append(self.table[x[:, :24].argmax(axis=1)])
+		if value:
+			out.append(super().__call__(x, policy=False, value=True))
+		return out if len(out) > 1 else out[0]
+
+
+def adi_traindata_oracle(net, games: int, depth: int, alpha: float, method: str):
+	"""
+	`Train.ADI_traindata` (train.py:256-339) on the CPU oracle: scramble (:277), 12-child fan-out (:285), rewards
+	(:294-296), value of every child + reward (:303, :313), targets (:315-324), loss weights (:329-332).
+	Pinned by tests/test_search_oracle.py against tests/golden/adi_trace.npz (captured from the unmodified reference).
+	Returns (one-hot states float32 (n,480), policy int64 (n,), value float32 (n,), loss weights float32 (n,)).
+	"""
+	states, oh_states = orc.sequence_scrambler(games, depth, method == "lapanfix")
+	solved_scrambled = orc.multi_is_solved(states)
+	sub = orc.expand12(states)
+	solved_sub = orc.multi_is_solved(sub)
+	rewards = np.where(solved_sub, 0.0 if method == "reward0" else 1.0, -1.0).astype(np.float32)
+	values = np.asarray(net(orc.as_oh(sub), policy=False, value=True), dtype=np.float32).reshape(-1) + rewards
+	values = values.reshape(-1, 12)
+	policy = values.argmax(axis=1)
+	value = values[np.arange(len(values)), policy].copy()
+	if method == "lapanfix":
+		value[solved_scrambled] = 0
+	elif method == "schultzfix":
+		value[np.arange(0, len(states), depth)] = 0
+	w = np.tile(1 / np.arange(1, depth + 1), games)
+	u = np.ones_like(w)
+	lw = ((1 - alpha) * w / w.sum() + alpha * u / len(u)) * (w.sum() + len(u))
+	return oh_states, policy.astype(np.int64), value.astype(np.float32), lw.astype(np.float32)
+
+
 def _values(net, states: np.ndarray) -> np.ndarray:
 	"""float32 value vector of the net for a batch of 20-byte states."""
 	v = net(orc.as_oh(states), policy=False, value=True)

@@ -33,7 +33,7 @@ def pytest_collection_modifyitems(config, items):
 def golden():
 	"""All committed golden vectors (captured from the real reference by oracle/gen_golden.py)."""
 	g = {}
-	for name in ("cube_tables", "cube_kat", "astar_trace", "mcts_trace"):
+	for name in ("cube_tables", "cube_kat", "astar_trace", "mcts_trace", "adi_trace"):
 		with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
 			g[name] = {k: z[k] for k in z.files}
 	with open(os.path.join(GOLDEN, "cube_text.json")) as f:

@@ -1,50 +1,41 @@
 """
-ADI data generation on the device (librubiks_amd/adi.py) against a NumPy restatement of the reference's
-`Train.ADI_traindata` (librubiks/train.py:256-339) built on the oracle, with the exact-integer stub net.
+ADI data generation on the device (librubiks_amd/adi.py) against outputs of the UNMODIFIED reference
+`Train.ADI_traindata` (librubiks/train.py:256-339) captured by oracle/gen_golden.py with the exact-integer stub net
+(tests/golden/adi_trace.npz), and against the oracle restatement at further shapes.
 """
 import numpy as np
 import pytest
 import torch
 
 from librubiks_amd.adi import adi_traindata
-from oracle import cube_oracle as orc
-from oracle.search_oracle import StubNet
+from oracle.search_oracle import StubNet, adi_traindata_oracle
+from tests.helpers import sha
 
 pytestmark = pytest.mark.gpu
 
 
-def _expected(games, depth, alpha, method):
-	"""train.py:277-332 on the CPU oracle."""
-	net = StubNet()
-	states, oh_states = orc.sequence_scrambler(games, depth, method == "lapanfix")
-	solved_scrambled = orc.multi_is_solved(states)
-	sub = orc.expand12(states)
-	solved_sub = orc.multi_is_solved(sub)
-	rewards = np.where(solved_sub, 0.0 if method == "reward0" else 1.0, -1.0).astype(np.float32)
-	values = net(orc.as_oh(sub), policy=False, value=True).reshape(-1) + rewards
-	values = values.reshape(-1, 12)
-	policy = values.argmax(axis=1)
-	value = values[np.arange(len(values)), policy].copy()
-	if method == "lapanfix":
-		value[solved_scrambled] = 0
-	elif method == "schultzfix":
-		value[np.arange(0, len(states), depth)] = 0
-	w = np.tile(1 / np.arange(1, depth + 1), games)
-	u = np.ones_like(w)
-	lw = ((1 - alpha) * w / w.sum() + alpha * u / len(u)) * (w.sum() + len(u))
-	return oh_states, policy, value, lw.astype(np.float32)
-
-
 @pytest.mark.parametrize("method", ["lapanfix", "paper", "schultzfix", "reward0"])
-def test_adi_matches_reference_algorithm(method):
-	games, depth, alpha = 37, 9, 0.3
-	np.random.seed(12)
-	want = _expected(games, depth, alpha, method)
-	np.random.seed(12)
-	oh, policy, value, lw = adi_traindata(StubNet(), games, depth, alpha, method, ff_batches=3)
-	assert oh.is_cuda and (oh.cpu().numpy() == want[0]).all()
-	assert (policy.numpy() == want[1]).all()
-	assert (value.numpy() == want[2]).all()
+def test_adi_matches_reference(golden, method):
+	"""Against tests/golden/adi_trace.npz: outputs of the UNMODIFIED reference `Train.ADI_traindata` (gen_golden.py)."""
+	t = golden["adi_trace"]
+	seed, games, depth, ff = (int(x) for x in t[f"{method}_params"])
+	np.random.seed(seed)
+	oh, policy, value, lw = adi_traindata(StubNet(), games, depth, float(t[f"{method}_alpha"]), method, ff_batches=ff)
+	assert oh.is_cuda and oh.dtype == torch.float32
+	assert sha(oh.cpu().numpy()) == str(t[f"{method}_oh_sha256"])
+	assert (policy.numpy() == t[f"{method}_policy"]).all() and policy.dtype == torch.int64
+	assert (value.numpy() == t[f"{method}_value"]).all()
+	assert np.allclose(lw.numpy(), t[f"{method}_loss_weights"], rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("method,games,depth", [("lapanfix", 301, 17), ("schultzfix", 64, 30)])
+def test_adi_matches_oracle_at_other_shapes(method, games, depth):
+	"""Shapes the fixture does not hold, against the oracle restatement (itself pinned to the fixture on the CPU)."""
+	np.random.seed(5)
+	want = adi_traindata_oracle(StubNet(), games, depth, 0.5, method)
+	np.random.seed(5)
+	oh, policy, value, lw = adi_traindata(StubNet(), games, depth, 0.5, method, ff_batches=2)
+	assert (oh.cpu().numpy() == want[0]).all() and (policy.numpy() == want[1]).all() and (value.numpy() == want[2]).all()
 	assert np.allclose(lw.numpy(), want[3], rtol=1e-6, atol=0)
 
 

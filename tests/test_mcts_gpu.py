@@ -12,7 +12,7 @@ import torch
 from librubiks_amd import cube
 from librubiks_amd.solving.agents import MCTS, MCTSBatch
 from oracle import cube_oracle as orc
-from oracle.search_oracle import MCTSOracle, StubNet
+from oracle.search_oracle import MCTSOracle, PolicyStubNet, StubNet
 
 pytestmark = pytest.mark.gpu
 
@@ -30,12 +30,13 @@ def _same_tree(arrs: dict, ref: MCTSOracle):
 	assert (arrs["P"][1:n + 1] == ref.P[1:n + 1]).all()
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f"])
 def test_reference_traces(golden, tag):
 	t = golden["mcts_trace"]
 	_, _, search_graph, max_states = (int(x) for x in t[f"{tag}_params"])
 	start = t[f"{tag}_start"]
-	agent = MCTS(StubNet(), float(t[f"{tag}_c"]), bool(search_graph), use_hipgraph=tag in ("b", "d"))
+	net = PolicyStubNet() if f"{tag}_P" in t else StubNet()          # trace f: non-uniform priors (exactly 0, 1/8, 1/4)
+	agent = MCTS(net, float(t[f"{tag}_c"]), bool(search_graph), use_hipgraph=tag in ("b", "d"))
 	solved = agent.search(start, time_limit=None, max_states=max_states)
 	n = int(t[f"{tag}_n"])
 	assert solved == bool(t[f"{tag}_solved"]) and len(agent) == n
@@ -47,6 +48,8 @@ def test_reference_traces(golden, tag):
 	assert (agent.W[1:n + 1] == t[f"{tag}_W"]).all() and agent.W.dtype == np.float64
 	assert (agent.L[1:n + 1] == t[f"{tag}_L"]).all()
 	assert (agent.V[1:n + 1] == t[f"{tag}_V"]).all()
+	if f"{tag}_P" in t:
+		assert (agent.P[1:n + 1] == t[f"{tag}_P"]).all()
 	assert list(agent.action_queue) == t[f"{tag}_action_queue"].tolist()
 	if solved:
 		s = start

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from oracle import cube_oracle as orc
-from oracle.search_oracle import AStarOracle, MCTSOracle, StubNet
+from oracle.search_oracle import AStarOracle, MCTSOracle, PolicyStubNet, StubNet, adi_traindata_oracle
 
 
 def _apply(state, queue):
@@ -47,16 +47,18 @@ def test_astar_trace_a_matches_survey_hashes(golden):
 	assert hashlib.sha256(t["a_parents"].tobytes()).hexdigest() == "a6b721d892115c0198cc62e4e1d1ed58ede395ee6c7806a0eb20eed338c989a3"
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f"])
 def test_mcts_oracle_reproduces_reference_trace(golden, tag):
 	t = golden["mcts_trace"]
 	seed, depth, search_graph, max_states = (int(x) for x in t[f"{tag}_params"])
 	np.random.seed(seed)
 	start, _, _ = orc.scramble(depth, True)
 	assert (start == t[f"{tag}_start"]).all()
-	agent = MCTSOracle(StubNet(), float(t[f"{tag}_c"]), bool(search_graph))
+	agent = MCTSOracle(PolicyStubNet() if f"{tag}_P" in t else StubNet(), float(t[f"{tag}_c"]), bool(search_graph))
 	solved = agent.search(start, max_states)
 	n = len(agent)
+	if f"{tag}_P" in t:                      # trace f: non-uniform priors, exactly 0, 1/8 or 1/4
+		assert (agent.P[1:n + 1] == t[f"{tag}_P"]).all() and len(np.unique(t[f"{tag}_P"])) == 3
 	assert solved == bool(t[f"{tag}_solved"]) and n == int(t[f"{tag}_n"]) and agent.sims == int(t[f"{tag}_sims"])
 	assert (agent.states[1:n + 1] == t[f"{tag}_states"]).all()
 	assert (agent.neighbors[1:n + 1] == t[f"{tag}_neighbors"]).all()
@@ -68,3 +70,18 @@ def test_mcts_oracle_reproduces_reference_trace(golden, tag):
 	assert list(agent.action_queue) == t[f"{tag}_action_queue"].tolist()
 	if solved:
 		assert orc.is_solved(_apply(start, agent.action_queue))
+
+
+@pytest.mark.parametrize("method", ["lapanfix", "paper", "schultzfix", "reward0"])
+def test_adi_oracle_reproduces_reference(golden, method):
+	"""The ADI restatement against the output of the unmodified `Train.ADI_traindata` (train.py:256-339)."""
+	import hashlib
+	t = golden["adi_trace"]
+	seed, games, depth, _ = (int(x) for x in t[f"{method}_params"])
+	np.random.seed(seed)
+	oh, policy, value, lw = adi_traindata_oracle(StubNet(), games, depth, float(t[f"{method}_alpha"]), method)
+	assert hashlib.sha256(np.ascontiguousarray(oh).tobytes()).hexdigest() == str(t[f"{method}_oh_sha256"])
+	assert (oh.reshape(len(oh), 20, 24).argmax(axis=2) == t[f"{method}_oh_idx"]).all()
+	assert (policy == t[f"{method}_policy"]).all()
+	assert (value == t[f"{method}_value"]).all()
+	assert np.allclose(lw, t[f"{method}_loss_weights"], rtol=1e-6, atol=0)
