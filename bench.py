@@ -10,8 +10,16 @@ flags.  Inputs are in HBM before the timed region; nothing is copied over PCIe i
 expands its own 1 M-state batch (independent units, no data-path collective): weak scaling, value = all ranks'
 expansions / max-over-ranks time.
 
+The timed loop is CACHE-NEUTRAL: step i reads parent set i % 4 and writes children/flag set i % 4.  Every set is
+20 MB in + 252 MB out, so 816 MB of other traffic passes between two uses of any line -- more than three times the
+256 MiB Infinity Cache -- and neither the input nor the output can be served from it (MI355X_MICROARCH.md, Infinity
+Cache residency rule).
+
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-  roofline      algorithmic bytes (272 B per parent) / measured kernel time vs the 8 TB/s HBM peak
+  roofline      algorithmic bytes (272 B per parent) / measured kernel time vs the 8 TB/s HBM peak; `frac` is
+                the total-bytes fraction, `frac_read` the read-bytes fraction (20 B per parent: the north star says
+                "HBM-read roofline"); kernel time = HIP events around the K back-to-back launches of the timed region,
+                plus min / median / mean of a second pass with one event pair per launch
   cpu_baseline  the CPU port of the reference's fan-out idiom (oracle/, NumPy, 1 core) timed on a bounded sample,
                 and the C/OpenMP restatement on all host cores
 """
@@ -30,6 +38,9 @@ if ROOT not in sys.path:
 
 N_PARENTS = 1_000_000
 BYTES_PER_PARENT = 20 + 240 + 12          # read parent, write 12 children, write 12 solved flags
+READ_BYTES_PER_PARENT = 20
+N_SETS = 4                                # rotating buffer sets: 3 x 272 MB pass between two uses of a set (> 2 x 256 MiB)
+KERNEL = "rk::k_expand12<true, 1, true, 4, false, 1>"      # the instantiation launch_expand12 picks at 1 M parents
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8.0 TB/s spec (about 6.3 TB/s achievable)
 
 
@@ -42,11 +53,34 @@ def make_parents(n: int, seed: int) -> torch.Tensor:
 	return cube.device.apply_sequences(acts, with_solved=False, only_last=True)
 
 
-def cpu_baseline(sample: int = 1_000_000):
+def _cpu_model() -> str:
+	try:
+		with open("/proc/cpuinfo") as f:
+			for line in f:
+				if line.startswith("model name"):
+					return line.split(":", 1)[1].strip()
+	except OSError:
+		pass
+	return "unknown"
+
+
+def _protocol_stats(samples):
+	"""The reference's timing protocol (analysis/benchmark.py:38-48, 92-103): drop samples > 2x the mean, then mean and
+	the half-width of the 95 % confidence interval of the mean (normal approximation)."""
+	x = np.asarray(samples, dtype=np.float64)
+	kept = x[x <= 2 * x.mean()]
+	mean = float(kept.mean())
+	ci = float(1.96 * kept.std(ddof=1) / np.sqrt(len(kept))) if len(kept) > 1 else 0.0
+	return mean, ci, len(kept)
+
+
+def cpu_baseline(sample: int = 1_000_000, numpy_reps: int = 5, native_reps: int = 20):
 	"""
 	The reference's CPU path, as far as it can travel: the oracle's NumPy port of the fan-out idiom
 	`multi_rotate(np.repeat(S, 12, 0), *iter_actions(n))` + `multi_is_solved` (agents.py:277-281, :321) on one
 	core, and the C/OpenMP restatement on every host core.  Only this function touches oracle/.
+	Protocol of BASELINE.md section 4 / analysis/benchmark.py: fixed batch, repeated calls, input generation
+	excluded, samples above twice the mean dropped, mean +- 95 % CI.
 	"""
 	from oracle import c_oracle, cube_oracle as orc
 	rng = np.random.RandomState(1)
@@ -54,37 +88,59 @@ def cpu_baseline(sample: int = 1_000_000):
 	for _ in range(20):
 		a = rng.randint(0, 12, sample)
 		s = c_oracle.multi_rotate(s, a.astype(np.uint8), threads=4)
-	t0 = time.perf_counter()
-	faces, dirs = orc.iter_actions(sample)
-	children = orc.multi_rotate(np.repeat(s, 12, axis=0), faces, dirs)
-	flags = orc.multi_is_solved(children)
-	t_np = time.perf_counter() - t0
+	t_np = []
+	for _ in range(numpy_reps):
+		t0 = time.perf_counter()
+		faces, dirs = orc.iter_actions(sample)
+		children = orc.multi_rotate(np.repeat(s, 12, axis=0), faces, dirs)
+		flags = orc.multi_is_solved(children)
+		t_np.append(time.perf_counter() - t0)
 	threads = c_oracle.max_threads()
 	out = np.empty((12 * sample, 20), np.int8)
 	fl = np.empty(12 * sample, np.uint8)
 	c_oracle.expand12(s, threads=threads, out=out, solved=fl)          # warm
-	reps, t0 = 5, time.perf_counter()
-	for _ in range(reps):
+	t_c = []
+	for _ in range(native_reps):
+		t0 = time.perf_counter()
 		c_oracle.expand12(s, threads=threads, out=out, solved=fl)
-	t_c = (time.perf_counter() - t0) / reps
+		t_c.append(time.perf_counter() - t0)
 	assert (out == children).all() and (fl.astype(bool) == flags).all()
+	m_np, ci_np, k_np = _protocol_stats(t_np)
+	m_c, ci_c, k_c = _protocol_stats(t_c)
+	# flat on purpose: nested objects were dropped by the driver's parser in round 1
 	return {
-		"value": sample / t_np, "unit": "expansions/s", "cores": 1, "kind": "port",
-		"sample": f"{sample} parents (depth-20 walks), NumPy port of the reference fan-out idiom + goal test, {t_np:.2f} s",
-		"native": {"value": sample / t_c, "unit": "expansions/s", "cores": threads, "kind": "port",
-		           "sample": f"{sample} parents x {reps} reps, C -O3 + OpenMP restatement, {t_c * 1e3:.1f} ms/rep"},
-		"host_cpus": os.cpu_count(),
+		"value": sample / m_np, "unit": "expansions/s", "cores": 1, "kind": "port",
+		"sample": f"{sample} parents (depth-20 walks) x {numpy_reps} reps, NumPy port of the reference fan-out idiom + goal test",
+		"seconds_mean": m_np, "seconds_ci95": ci_np, "reps_kept": k_np,
+		"value_ci95": [sample / (m_np + ci_np), sample / max(m_np - ci_np, 1e-12)],
+		"native_value": sample / m_c, "native_unit": "expansions/s", "native_cores": threads, "native_kind": "port",
+		"native_sample": f"{sample} parents x {native_reps} reps, C -O3 + OpenMP restatement",
+		"native_seconds_mean": m_c, "native_seconds_ci95": ci_c, "native_reps_kept": k_c,
+		"native_value_ci95": [sample / (m_c + ci_c), sample / max(m_c - ci_c, 1e-12)],
+		"cpu_model": _cpu_model(), "host_cpus": os.cpu_count(),
+		"protocol": "fixed batch, input generation excluded, samples > 2x mean dropped, mean +- 1.96 s/sqrt(n) (analysis/benchmark.py:38-48,92-103)",
 	}
 
 
+PMC_FILE = os.path.join("profiles", "r02_expand12_pmc.json")
+
+
 def pmc_traffic():
-	"""HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/), if one exists."""
-	path = os.path.join(ROOT, "profiles", "expand12_pmc.json")
+	"""
+	HBM bytes per launch from the committed rocprofv3 PMC passes of THIS command (profiles/, written by
+	benchmarks/pmc_summary.py from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs; FETCH_SIZE doubled per the
+	guide's gfx950 correction).  PMC counters cannot be collected inside a timed run, so the figure is a record with its
+	provenance; it is null when the record is missing or was taken for a different kernel instantiation.
+	"""
 	try:
-		with open(path) as f:
-			return json.load(f).get("hbm_bytes_per_launch")
+		with open(os.path.join(ROOT, PMC_FILE)) as f:
+			rec = json.load(f)
 	except (OSError, ValueError):
-		return None
+		return None, None
+	if rec.get("kernel") != KERNEL:
+		return None, {"source": PMC_FILE, "stale": f"recorded for {rec.get('kernel')}"}
+	return rec.get("hbm_bytes_per_launch"), {"source": PMC_FILE, "kernel": rec.get("kernel"), "commit": rec.get("commit"),
+	                                         "fetch_bytes": rec.get("fetch_bytes_per_launch"), "write_bytes": rec.get("write_bytes_per_launch")}
 
 
 def max_over_ranks(elapsed: float, dist, device) -> float:
@@ -126,12 +182,17 @@ def main():
 	from librubiks_amd import _ffi, cube
 	_ffi.check(_ffi.lib().rk_init(device_index))
 
-	parents = make_parents(N_PARENTS, seed=1000 + rank)
-	children = torch.empty((12 * N_PARENTS, 20), dtype=torch.int8, device="cuda")
-	solved = torch.empty(12 * N_PARENTS, dtype=torch.uint8, device="cuda")
+	sets = []
+	for k in range(N_SETS):
+		sets.append((make_parents(N_PARENTS, seed=1000 + 16 * rank + k),
+		             torch.empty((12 * N_PARENTS, 20), dtype=torch.int8, device="cuda"),
+		             torch.empty(12 * N_PARENTS, dtype=torch.uint8, device="cuda")))
 	stats = torch.tensor([0, _ffi.INT64_MAX], dtype=torch.int64, device="cuda")
+	counter = [0]
 
 	def step():
+		parents, children, solved = sets[counter[0] % N_SETS]
+		counter[0] += 1
 		cube.device.expand12(parents, children, solved, stats)
 
 	def fence():
@@ -154,14 +215,28 @@ def main():
 	elapsed_max = max_over_ranks(elapsed, dist, reduce_device)
 	kernel_ms = ev0.elapsed_time(ev1) / args.steps          # HIP events on the launch stream: back-to-back launches
 
-	# sanity of the timed work: the children of the last step are a real fan-out (spot check on the device)
-	probe = cube.device.multi_rotate(children[:12 * 4096].contiguous(),
-	                                 torch.arange(12, dtype=torch.uint8, device="cuda").bitwise_xor(1).repeat(4096))
-	assert torch.equal(probe.view(4096, 12, 20), parents[:4096].view(4096, 1, 20).expand(4096, 12, 20))
+	# per-launch distribution (outside the timed region): one event pair per launch, same rotation
+	per = []
+	evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(args.steps, 200))]
+	for e0, e1 in evs:
+		e0.record()
+		step()
+		e1.record()
+	torch.cuda.synchronize()
+	per = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+
+	# sanity of the timed work: every set's children are a real fan-out of its parents (spot check on the device)
+	undo = torch.arange(12, dtype=torch.uint8, device="cuda").bitwise_xor(1).repeat(4096)
+	for parents, children, solved in sets:
+		probe = cube.device.multi_rotate(children[:12 * 4096].contiguous(), undo)
+		assert torch.equal(probe.view(4096, 12, 20), parents[:4096].view(4096, 1, 20).expand(4096, 12, 20))
+	assert int(stats[0]) == 0 or int(stats[1]) < 12 * N_PARENTS
 
 	if rank == 0:
 		value = world * N_PARENTS * args.steps / elapsed_max
 		achieved = BYTES_PER_PARENT * N_PARENTS / (kernel_ms * 1e-3) / 1e9
+		achieved_read = READ_BYTES_PER_PARENT * N_PARENTS / (kernel_ms * 1e-3) / 1e9
+		traffic, traffic_src = pmc_traffic()
 		line = {
 			"metric": "cube node-expansions/sec (12-child fan-out) at 1M-state batch",
 			"value": value, "unit": "expansions/s",
@@ -170,14 +245,19 @@ def main():
 			"higher_is_better": True, "scaling": "weak", "vs_baseline": None,
 			"dtype": "u8", "data": "synthetic",
 			"config": {"workload": f"configs[1]: {world}xMI355X fan-out (12 moves) + is_solved on 1M depth-20 scrambles per GPU, "
-			                       "device-resident, one rk_expand12 launch per step",
-			           "parents_per_gpu": N_PARENTS, "children_per_step": 12 * N_PARENTS * world,
+			                       "device-resident, one rk_expand12 launch per step, inputs and outputs rotating over "
+			                       f"{N_SETS} buffer sets ({N_SETS * BYTES_PER_PARENT * N_PARENTS // 1_000_000} MB) so that nothing is served by the 256 MiB Infinity Cache",
+			           "parents_per_gpu": N_PARENTS, "children_per_step": 12 * N_PARENTS * world, "buffer_sets": N_SETS,
 			           "parallelism": f"independent batches x{world}"},
 			"transitions_per_s": 12 * value,
 			"roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-			             "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
-			             "kernel": "rk::k_expand12<true, 1, true, 4, false, 1>", "kernel_ms": kernel_ms,
-			             "algorithmic_bytes_per_launch": BYTES_PER_PARENT * N_PARENTS},
+			             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_provenance": traffic_src,
+			             "achieved_read": achieved_read, "frac_read": achieved_read / HBM_PEAK_GBS,
+			             "kernel": KERNEL, "kernel_ms": kernel_ms,
+			             "kernel_ms_min": per[0], "kernel_ms_median": per[len(per) // 2], "kernel_ms_mean": sum(per) / len(per),
+			             "algorithmic_bytes_per_launch": BYTES_PER_PARENT * N_PARENTS,
+			             "algorithmic_read_bytes_per_launch": READ_BYTES_PER_PARENT * N_PARENTS,
+			             "cache_neutral": True},
 		}
 		if world == 1 and not args.no_cpu_baseline:
 			line["cpu_baseline"] = cpu_baseline()

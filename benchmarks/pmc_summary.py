@@ -1,0 +1,113 @@
+"""
+Turns the rocprofv3 output directories of ONE bench.py command into the records bench.py and the judge read:
+
+    python benchmarks/pmc_summary.py --stats DIR --fetch DIR --write DIR --kernel k_expand12 --commit HEAD \
+        --out-pmc profiles/r02_expand12_pmc.json --out-stats profiles/r02_expand12_kernel_stats.csv
+
+  --stats  directory of `rocprofv3 --kernel-trace --stats --output-format csv -d DIR -- python3 bench.py ...`
+  --fetch / --write  directories of the two separate PMC passes `rocprofv3 --pmc FETCH_SIZE --kernel-trace ...` and
+           `rocprofv3 --pmc WRITE_SIZE --kernel-trace ...` of the same command (never combined with --stats or a
+           second counter: MI355X_MICROARCH.md, HBM section)
+Corrections per that guide: rocprofv3 reports both counters in KiB; on gfx950 FETCH_SIZE tallies 128-byte requests of
+a wide coalesced stream as 64 B, so it is doubled; WRITE_SIZE is exact for 16 B/lane streaming stores.
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+import statistics
+import sys
+
+csv.field_size_limit(1 << 30)
+
+
+def _one(directory: str, suffix: str) -> str:
+	hits = sorted(glob.glob(os.path.join(directory, "**", "*" + suffix), recursive=True))
+	if not hits:
+		sys.exit(f"no *{suffix} under {directory}")
+	return hits[-1]
+
+
+def counter_rows(directory: str, counter: str, kernel: str):
+	vals, name = [], None
+	with open(_one(directory, "counter_collection.csv"), newline="") as f:
+		for row in csv.DictReader(f):
+			if row["Counter_Name"] == counter and kernel in row["Kernel_Name"]:
+				vals.append(float(row["Counter_Value"]))
+				name = row["Kernel_Name"]
+	return vals, name
+
+
+def short_name(full: str) -> str:
+	"""'void rk::k_expand12<true, 1, true, 4, false, 1>(unsigned int const*, ...)' -> 'rk::k_expand12<true, 1, true, 4, false, 1>'"""
+	s = full[5:] if full.startswith("void ") else full
+	depth = 0
+	for i, ch in enumerate(s):
+		if ch == "<":
+			depth += 1
+		elif ch == ">":
+			depth -= 1
+		elif ch == "(" and depth == 0:
+			return s[:i]
+	return s
+
+
+def main():
+	ap = argparse.ArgumentParser()
+	ap.add_argument("--stats")
+	ap.add_argument("--fetch")
+	ap.add_argument("--write")
+	ap.add_argument("--kernel", default="k_expand12")
+	ap.add_argument("--commit", default="")
+	ap.add_argument("--command", default="python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline")
+	ap.add_argument("--algorithmic", type=float, default=272e6)
+	ap.add_argument("--out-pmc")
+	ap.add_argument("--out-stats")
+	ap.add_argument("--top", type=int, default=12)
+	args = ap.parse_args()
+
+	if args.stats and args.out_stats:
+		with open(_one(args.stats, "kernel_stats.csv"), newline="") as f:
+			rows = list(csv.reader(f))
+		with open(args.out_stats, "w", newline="") as f:
+			w = csv.writer(f)
+			w.writerow(rows[0])
+			for r in rows[1:1 + args.top]:
+				r[0] = short_name(r[0]) if len(r[0]) < 400 else short_name(r[0])[:120] + "..."
+				w.writerow(r)
+		# median of the kernel's dispatch durations from the trace of the same run
+		dur = []
+		with open(_one(args.stats, "kernel_trace.csv"), newline="") as f:
+			for row in csv.DictReader(f):
+				if args.kernel in row["Kernel_Name"]:
+					dur.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+		if dur:
+			print(json.dumps({"kernel": args.kernel, "dispatches": len(dur), "avg_ns": statistics.fmean(dur), "median_ns": statistics.median(dur),
+			                  "min_ns": min(dur), "max_ns": max(dur)}))
+
+	if args.fetch and args.write and args.out_pmc:
+		fv, name_f = counter_rows(args.fetch, "FETCH_SIZE", args.kernel)
+		wv, name_w = counter_rows(args.write, "WRITE_SIZE", args.kernel)
+		if not fv or not wv:
+			sys.exit("kernel not found in the PMC passes")
+		fetch = 2.0 * statistics.fmean(fv) * 1024.0
+		write = statistics.fmean(wv) * 1024.0
+		rec = {
+			"kernel": short_name(name_f), "commit": args.commit,
+			"command": f"rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- {args.command} ; same with --pmc WRITE_SIZE (separate passes)",
+			"units": "rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB",
+			"gfx950_correction": "FETCH_SIZE doubled (128-B requests of a wide coalesced stream are tallied at 64 B); WRITE_SIZE exact for 16 B/lane streaming stores (MI355X_MICROARCH.md, HBM)",
+			"FETCH_SIZE_KiB_mean": statistics.fmean(fv), "FETCH_SIZE_dispatches": len(fv),
+			"WRITE_SIZE_KiB_mean": statistics.fmean(wv), "WRITE_SIZE_dispatches": len(wv),
+			"fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
+			"algorithmic_bytes_per_launch": args.algorithmic, "traffic_over_algorithmic": (fetch + write) / args.algorithmic,
+			"note": "the bench rotates inputs and outputs over 4 buffer sets (1.09 GB), so these fabric-side bytes cannot be Infinity-Cache hits of a previous launch",
+		}
+		with open(args.out_pmc, "w") as f:
+			json.dump(rec, f, indent=1)
+		print(json.dumps(rec))
+
+
+if __name__ == "__main__":
+	main()

@@ -19,6 +19,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from librubiks_amd import _ffi, cube  # noqa: E402
 
 N = int(os.environ.get("RK_TUNE_N", "1000000"))
+TUNE_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librubiks_hip_tune.so")   # python -m librubiks_amd.build --tune
+_ffi.LIB_PATH = TUNE_LIB if os.path.exists(TUNE_LIB) else sys.exit("build the tuning library first: python -m librubiks_amd.build --tune")
 lib = _ffi.lib()
 lib.rkx_expand12_variant.restype = C.c_int
 lib.rkx_expand12_variant.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]
@@ -52,11 +54,14 @@ def main(variants):
 	ref_c, ref_f = cube.device.expand12(parents)
 	counter = torch.zeros(4, dtype=torch.int32, device="cuda")
 	bufs = [(torch.empty_like(ref_c), torch.empty_like(ref_f)) for _ in range(6 if N <= 2_000_000 else 2)]
+	# inputs rotate too (round 2): set 0 is `parents` (checked against the shipping kernel), the others are further walks
+	ins = [parents] + [cube.device.apply_sequences(torch.randint(0, 12, (20, N), device="cuda", dtype=torch.uint8, generator=g), False, True)
+	                   for _ in range(len(bufs) - 1)]
 
 	def run(vg, i):
 		v, gb = vg
 		c, f = bufs[i % len(bufs)]
-		_ffi.check(lib.rkx_expand12_variant(v, parents.data_ptr(), c.data_ptr(), f.data_ptr(), None, N, counter.data_ptr(), gb, _ffi.stream_ptr()))
+		_ffi.check(lib.rkx_expand12_variant(v, ins[i % len(ins)].data_ptr(), c.data_ptr(), f.data_ptr(), None, N, counter.data_ptr(), gb, _ffi.stream_ptr()))
 
 	res = {}
 	for v in variants:

@@ -1,7 +1,10 @@
 """
 Builds librubiks_hip.so (the C-ABI HIP library) in-tree with hipcc for gfx950.
 
-    python -m librubiks_amd.build [--force]
+    python -m librubiks_amd.build [--force] [--tune]
+
+--tune additionally builds benchmarks/librubiks_hip_tune.so: the same sources with -DRK_TUNING, which adds the
+kernel-shape variants and geometry diagnostics used by benchmarks/tune_*.py.  The shipped library carries none of them.
 
 hipcc cross-compiles without a GPU; the .so is git-ignored but travels with the gpurun snapshot.
 """
@@ -36,6 +39,18 @@ def stale() -> bool:
 	return any(os.path.getmtime(d) > t for d in deps)
 
 
+TUNE_OUT = os.path.join(HERE, "..", "benchmarks", "librubiks_hip_tune.so")
+
+
+def build_tune(verbose: bool = False) -> str:
+	"""The tuning build (one compile of everything with -DRK_TUNING; not cached, not shipped)."""
+	cmd = [HIPCC] + FLAGS + ["-DRK_TUNING", "-o", os.path.abspath(TUNE_OUT)] + sources()
+	if verbose:
+		print(" ".join(cmd))
+	subprocess.run(cmd, check=True)
+	return os.path.abspath(TUNE_OUT)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
 	if not force and not stale():
 		return OUT
@@ -59,3 +74,5 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 if __name__ == "__main__":
 	print(build(force="--force" in sys.argv, verbose=True))
+	if "--tune" in sys.argv:
+		print(build_tune(verbose=True))

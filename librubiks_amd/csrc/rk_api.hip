@@ -230,6 +230,7 @@ int rk_states_from_soa(const uint32_t *d_planes, int8_t *d_states, size_t n, voi
 	return RK_OK;
 }
 
+#ifdef RK_TUNING
 /* Tuning hook, deliberately outside the public header: other shapes of the fan-out kernel (benchmarks/tune_expand.py). */
 int rkx_expand12_variant(int variant, const int8_t *d_parents, int8_t *d_children, uint8_t *d_solved, long long *d_stats, size_t n,
                          unsigned int *d_counter, int grid_blocks, void *stream)
@@ -248,6 +249,8 @@ int rkx_as_oh_variant(int tile, int grid_cap, const int8_t *d_states, void *d_ou
 	RK_HIP(hipGetLastError());
 	return RK_OK;
 }
+
+#endif  /* RK_TUNING */
 
 int rk_multi_is_solved(int repr, const int8_t *d_states, uint8_t *d_flags, long long *d_stats, size_t n, void *stream)
 {

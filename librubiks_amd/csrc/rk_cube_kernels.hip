@@ -711,6 +711,7 @@ static inline unsigned grid_for(size_t work_items, size_t per_block, unsigned ca
 	return (unsigned)b;
 }
 
+#ifdef RK_TUNING   // tuning aids: compiled only into benchmarks/librubiks_hip_tune.so (python -m librubiks_amd.build --tune)
 // Diagnostic only (never used by the product): the fan-out kernel's memory geometry without its work.  Every wave
 // reads its tile's 1 280 B, then writes 15 KiB + 768 B of junk derived from it with the same store instructions.
 //   mode 0: straight from registers (no LDS staging)     mode 1: through the LDS staging round trip
@@ -878,6 +879,8 @@ void launch_expand12_variant(int variant, const int8_t *parents, int8_t *childre
 	#undef RK_LAUNCH
 }
 
+#endif  // RK_TUNING
+
 // Shipping shape (benchmarks/tune_expand.py, profiles/r01_tune_expand.json): 64-parent wave tiles + non-temporal
 // stores stream at the same 6.1 TB/s whether or not the output buffer is reused; plain stores only win when the
 // 252 MB output is rewritten in place launch after launch (Infinity-Cache hits), and lose with 64-parent tiles.
@@ -937,6 +940,7 @@ void launch_apply_sequences(const uint8_t *actions, int moves, int games, int wi
 	hipLaunchKernelGGL(k_apply_sequences, dim3(grid), dim3(256), 0, st, actions, moves, games, with_solved, only_last, (uint32_t *)out);
 }
 
+#ifdef RK_TUNING
 // tuning aid (benchmarks/tune_oh.py): states per workgroup step and grid cap (0 = one workgroup per tile)
 void launch_as_oh_variant(int tile, int grid_cap, const int8_t *states, void *out, int out_dtype, size_t n, hipStream_t st)
 {
@@ -946,6 +950,8 @@ void launch_as_oh_variant(int tile, int grid_cap, const int8_t *states, void *ou
 	if (tile == 8) RK_OH(8); else if (tile == 16) RK_OH(16); else if (tile == 32) RK_OH(32); else RK_OH(64);
 	#undef RK_OH
 }
+
+#endif  // RK_TUNING
 
 // Shipping tiling (benchmarks/tune_oh.py, outputs rotated so that nothing is rewritten in cache): one workgroup per tile
 // and about four 16-byte stores per thread -- 8 states per workgroup for f32, 16 for the 16-bit types: 5.6 / 6.1 TB/s

@@ -11,8 +11,11 @@ namespace rk {
 const Tables &host_tables();
 
 void launch_expand12(const int8_t *parents, int8_t *children, uint8_t *solved, long long *stats, size_t n, hipStream_t st);
+#ifdef RK_TUNING
 void launch_expand12_variant(int variant, const int8_t *parents, int8_t *children, uint8_t *solved, long long *stats, size_t n,
                              int grid_blocks, hipStream_t st);
+void launch_as_oh_variant(int tile, int grid_cap, const int8_t *states, void *out, int out_dtype, size_t n, hipStream_t st);
+#endif
 void launch_expand12_soa(const uint32_t *parents, uint32_t *children, uint8_t *solved, long long *stats, size_t n, hipStream_t st);
 void launch_states_soa(const int8_t *states, uint32_t *planes, size_t n, bool to_soa, hipStream_t st);
 void launch_multi_rotate(const int8_t *states, const uint8_t *actions_or_faces, const uint8_t *dirs_or_null, int8_t *out,
@@ -20,7 +23,6 @@ void launch_multi_rotate(const int8_t *states, const uint8_t *actions_or_faces, 
 void launch_multi_is_solved(const int8_t *states, uint8_t *flags, long long *stats, size_t n, hipStream_t st);
 void launch_apply_sequences(const uint8_t *actions, int moves, int games, int with_solved, int only_last, int8_t *out,
                             hipStream_t st);
-void launch_as_oh_variant(int tile, int grid_cap, const int8_t *states, void *out, int out_dtype, size_t n, hipStream_t st);
 void launch_as_oh(const int8_t *states, void *out, int out_dtype, size_t n, hipStream_t st);
 
 void launch_rotate686(const int8_t *states, const uint8_t *actions, int8_t *out, size_t n_out, bool fanout, hipStream_t st);

@@ -244,8 +244,8 @@ class MCTSOracle:
 		p = torch.as_tensor(np.asarray(p)).float().softmax(dim=1).numpy()       # float32 softmax, as agents.py:552
 		return p.astype(np.float64), np.asarray(v, dtype=np.float32).reshape(-1).astype(np.float64)
 
-	def search(self, start: np.ndarray, max_states: int) -> bool:
-		"""agents.py:461-494 with the deterministic budget."""
+	def search(self, start: np.ndarray, max_states: int, max_sims: int = None) -> bool:
+		"""agents.py:461-494 with the deterministic budget (`max_sims` additionally bounds the number of simulations)."""
 		self.reset(max_states + 12)
 		self.index[start.tobytes()] = 1
 		self.states[1] = start
@@ -254,7 +254,7 @@ class MCTSOracle:
 		p, v = self._policy_value(start[None])
 		self.P[1], self.V[1] = p[0], v[0]
 		path, actions = [1], []
-		while len(self) + 12 <= max_states:
+		while len(self) + 12 <= max_states and (max_sims is None or self.sims < max_sims):
 			leaf, action = self.expand_leaf(path, actions)
 			if leaf != -1:
 				self.action_queue = deque(actions + [action])
