@@ -21,6 +21,7 @@ from librubiks_amd import _ffi, cube  # noqa: E402
 N = int(os.environ.get("RK_TUNE_N", "1000000"))
 TUNE_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librubiks_hip_tune.so")   # python -m librubiks_amd.build --tune
 _ffi.LIB_PATH = TUNE_LIB if os.path.exists(TUNE_LIB) else sys.exit("build the tuning library first: python -m librubiks_amd.build --tune")
+_ffi._lib = None          # drop the shipped library that importing the package loaded
 lib = _ffi.lib()
 lib.rkx_expand12_variant.restype = C.c_int
 lib.rkx_expand12_variant.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]

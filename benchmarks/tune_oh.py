@@ -12,6 +12,7 @@ from benchmarks.kernels import timed  # noqa: E402
 
 TUNE_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librubiks_hip_tune.so")   # python -m librubiks_amd.build --tune
 _ffi.LIB_PATH = TUNE_LIB if os.path.exists(TUNE_LIB) else sys.exit("build the tuning library first: python -m librubiks_amd.build --tune")
+_ffi._lib = None          # drop the shipped library that importing the package loaded
 lib = _ffi.lib()
 lib.rkx_as_oh_variant.restype = C.c_int
 lib.rkx_as_oh_variant.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]

@@ -194,8 +194,7 @@ int rk_expand12(int repr, const int8_t *d_parents, int8_t *d_children, uint8_t *
 		launch_expand12(d_parents, d_children, d_solved, d_stats, n, (hipStream_t)stream);
 	} else {
 		if (misaligned(d_parents, 16)) return fail(RK_EINVAL, "rk_expand12: 6x8x6 parents must be 16-byte aligned");
-		launch_rotate686(d_parents, nullptr, d_children, 12 * n, true, (hipStream_t)stream);
-		if (d_solved || d_stats) launch_fanout_flags686(d_parents, d_solved, d_stats, n, (hipStream_t)stream);
+		launch_rotate686(d_parents, nullptr, d_children, 12 * n, true, (hipStream_t)stream, d_solved, d_stats);   // flags fused: one launch
 	}
 	RK_HIP(hipGetLastError());
 	return RK_OK;

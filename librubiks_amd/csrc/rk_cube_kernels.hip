@@ -544,26 +544,51 @@ __device__ __forceinline__ void stage_perm686(uint8_t *lds, int tid, int nthread
 // thread then produces 16-byte chunks (8 ushorts) of the output, gathering its 8 source ushorts from LDS through the
 // per-action source-offset table src[a][u] = perm686[a][u/3]*3 + u%3 (also LDS).  Stores are 16 B/lane, contiguous
 // across lanes and non-temporal: a store stream.
-template <bool FANOUT>
+// FLAGS (fan-out only): the 12 solved flags of every parent come from the LDS-resident PARENT in the same launch
+// (cube.py:88-89 on the children without reading them back): child a of p is solved <=> p == move rev(a) of solved.
+// The staged parent is reduced to its 48 slot colours (a slot that is not an exact one-hot gets 255, so that garbage
+// never compares equal) and each (parent, action) pair compares 12 dwords of colours with the "one move from solved"
+// colour pattern near[a][s] = face(perm686[a^1][s]).
+template <bool FANOUT, bool FLAGS = false>
 __global__ __launch_bounds__(256)
-void k_rotate686(const uint16_t *__restrict__ states, const uint8_t *__restrict__ actions, u32x4 *__restrict__ out, size_t n_in)
+void k_rotate686(const uint16_t *__restrict__ states, const uint8_t *__restrict__ actions, u32x4 *__restrict__ out, size_t n_in,
+                 uint8_t *__restrict__ flags = nullptr, long long *__restrict__ stats = nullptr)
 {
 	constexpr int GROUP = FANOUT ? 4 : 64;                // source states per workgroup step (about four stores per thread)
 	constexpr int OUT_PER_IN = FANOUT ? 12 : 1;
 	__shared__ __attribute__((aligned(16))) uint8_t s_src[N_ACTIONS * 144];
 	__shared__ __attribute__((aligned(16))) uint16_t s_in[GROUP * 144];
+	__shared__ __attribute__((aligned(16))) uint8_t s_near[FLAGS ? N_ACTIONS * S686_SLOTS : 16];
+	__shared__ __attribute__((aligned(16))) uint8_t s_col[FLAGS ? GROUP * S686_SLOTS : 16];
 	for (int i = threadIdx.x; i < N_ACTIONS * 144; i += 256) {
 		const int a = i / 144, u = i - a * 144, slot = u / 3;
 		s_src[i] = (uint8_t)(D_TAB.perm686[a][slot] * 3 + (u - slot * 3));
 	}
+	if (FLAGS)
+		for (int i = threadIdx.x; i < N_ACTIONS * S686_SLOTS; i += 256) {
+			const int a = i / S686_SLOTS, slot = i - a * S686_SLOTS;
+			s_near[i] = (uint8_t)(D_TAB.perm686[a ^ 1][slot] >> 3);
+		}
 	const size_t n_groups = (n_in + GROUP - 1) / GROUP;
 	for (size_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
 		const size_t first = g * GROUP;
 		const int ng = (int)((n_in - first < (size_t)GROUP) ? (n_in - first) : (size_t)GROUP);
-		__syncthreads();                                  // previous step's gathers are done (and s_src is ready)
+		__syncthreads();                                  // previous step's gathers are done (and the tables are ready)
 		const u32x4 *src4 = reinterpret_cast<const u32x4 *>(states + first * 144);
 		for (int i = threadIdx.x; i < ng * 18; i += 256) reinterpret_cast<u32x4 *>(s_in)[i] = src4[i];
 		__syncthreads();
+		if (FLAGS && (int)threadIdx.x < ng * S686_SLOTS) {   // slot colours of the staged parents (threads 0..191)
+			const uint16_t *h = s_in + threadIdx.x * 3;       // (parent, slot) -> 3 ushorts = 6 one-hot bytes
+			const uint32_t lo = (uint32_t)h[0] | ((uint32_t)h[1] << 16), hi = h[2];
+			uint32_t col = 255u;
+			if (hi == 0u) {
+				if (lo == 0x00000001u) col = 0; else if (lo == 0x00000100u) col = 1;
+				else if (lo == 0x00010000u) col = 2; else if (lo == 0x01000000u) col = 3;
+			} else if (lo == 0u) {
+				if (hi == 0x0001u) col = 4; else if (hi == 0x0100u) col = 5;
+			}
+			s_col[threadIdx.x] = (uint8_t)col;
+		}
 		u32x4 *dst = out + first * OUT_PER_IN * 18;
 		const int n_chunks = ng * OUT_PER_IN * 18;
 		for (int q = threadIdx.x; q < n_chunks; q += 256) {
@@ -579,48 +604,21 @@ void k_rotate686(const uint16_t *__restrict__ states, const uint8_t *__restrict_
 			for (int i = 0; i < 8; i++) h[i] = row[((i < 4 ? offs.x : offs.y) >> (8 * (i & 3))) & 0xFFu];
 			__builtin_nontemporal_store(u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)}, dst + q);
 		}
-	}
-}
-
-// solved flags of the 12 children WITHOUT reading them back: child a of p is solved  <=>  p == move rev(a) of solved.
-// One wave per parent compares its 72 dwords with the 12 "one move from solved" patterns (built on the fly from the
-// slot table: such a pattern's slot s shows colour face(perm686[a^1][s])).
-__global__ __launch_bounds__(256)
-void k_fanout_flags686(const uint32_t *__restrict__ parents, uint8_t *__restrict__ flags, long long *__restrict__ stats, size_t n)
-{
-	__shared__ uint32_t s_near[N_ACTIONS][72];
-	for (int i = threadIdx.x; i < N_ACTIONS * 72; i += blockDim.x) {
-		const int a = i / 72, d = i - a * 72;
-		uint32_t w = 0;
-		#pragma unroll
-		for (int b = 0; b < 4; b++) {
-			const int byte = d * 4 + b, slot = byte / 6, colour = byte - slot * 6;
-			// near[a] = move (a^1) applied to solved: new[slot] = solved[perm[a^1][slot]], whose colour is its face
-			if ((D_TAB.perm686[a ^ 1][slot] >> 3) == colour) w |= 1u << (8 * b);
-		}
-		s_near[a][d] = w;
-	}
-	__syncthreads();
-	const int lane = threadIdx.x & 63;
-	const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-	const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
-	for (size_t p = wave; p < n; p += nwaves) {
-		const uint32_t *s = parents + p * 72;
-		const uint32_t v0 = s[lane];
-		const uint32_t v1 = lane < 8 ? s[64 + lane] : 0u;
-		uint32_t mine = 0;                               // lane a < 12 ends up with flag a
-		#pragma unroll
-		for (int a = 0; a < N_ACTIONS; a++) {
-			bool diff = v0 != s_near[a][lane];
-			if (lane < 8) diff |= v1 != s_near[a][64 + lane];
-			const bool ok = __ballot(diff) == 0ull;
-			if (lane == a) mine = ok ? 1u : 0u;
-		}
-		if (lane < 12) {
-			if (flags != nullptr) flags[p * 12 + lane] = (uint8_t)mine;
-			if (mine && stats != nullptr) {
-				atomicAdd(reinterpret_cast<unsigned long long *>(&stats[0]), 1ull);
-				atomicMin(&stats[1], (long long)(p * 12 + lane));
+		if (FLAGS) {
+			__syncthreads();                              // s_col complete (the gathers above hid its latency)
+			if ((int)threadIdx.x < ng * N_ACTIONS) {      // one thread per (parent, action): 12 dword compares
+				const int local = threadIdx.x / N_ACTIONS, a = threadIdx.x - local * N_ACTIONS;
+				const uint32_t *c = reinterpret_cast<const uint32_t *>(s_col + local * S686_SLOTS);
+				const uint32_t *w = reinterpret_cast<const uint32_t *>(s_near + a * S686_SLOTS);
+				uint32_t diff = 0;
+				#pragma unroll
+				for (int k = 0; k < S686_SLOTS / 4; k++) diff |= c[k] ^ w[k];
+				const size_t o = first * N_ACTIONS + threadIdx.x;
+				if (flags != nullptr) flags[o] = diff == 0u ? 1 : 0;
+				if (diff == 0u && stats != nullptr) {
+					atomicAdd(reinterpret_cast<unsigned long long *>(&stats[0]), 1ull);
+					atomicMin(&stats[1], (long long)o);
+				}
 			}
 		}
 	}
@@ -971,22 +969,22 @@ void launch_as_oh(const int8_t *states, void *out, int out_dtype, size_t n, hipS
 	}
 }
 
-void launch_rotate686(const int8_t *states, const uint8_t *actions, int8_t *out, size_t n_out, bool fanout, hipStream_t st)
+void launch_rotate686(const int8_t *states, const uint8_t *actions, int8_t *out, size_t n_out, bool fanout, hipStream_t st,
+                      uint8_t *flags, long long *stats)
 {
 	if (fanout) {
 		const size_t n_in = n_out / 12;
 		const unsigned grid = grid_for(n_in, 4, 1u << 22);
-		hipLaunchKernelGGL(k_rotate686<true>, dim3(grid), dim3(256), 0, st, (const uint16_t *)states, actions, (u32x4 *)out, n_in);
+		if (flags != nullptr || stats != nullptr)          // children and their solved flags in ONE launch
+			hipLaunchKernelGGL((k_rotate686<true, true>), dim3(grid), dim3(256), 0, st, (const uint16_t *)states, actions, (u32x4 *)out, n_in, flags, stats);
+		else
+			hipLaunchKernelGGL((k_rotate686<true, false>), dim3(grid), dim3(256), 0, st, (const uint16_t *)states, actions, (u32x4 *)out, n_in,
+			                   (uint8_t *)nullptr, (long long *)nullptr);
 	} else {
 		const unsigned grid = grid_for(n_out, 64, 1u << 20);
-		hipLaunchKernelGGL(k_rotate686<false>, dim3(grid), dim3(256), 0, st, (const uint16_t *)states, actions, (u32x4 *)out, n_out);
+		hipLaunchKernelGGL((k_rotate686<false, false>), dim3(grid), dim3(256), 0, st, (const uint16_t *)states, actions, (u32x4 *)out, n_out,
+		                   (uint8_t *)nullptr, (long long *)nullptr);
 	}
-}
-
-void launch_fanout_flags686(const int8_t *parents, uint8_t *flags, long long *stats, size_t n, hipStream_t st)
-{
-	const unsigned grid = grid_for(n, 4, 256u * 8u);
-	hipLaunchKernelGGL(k_fanout_flags686, dim3(grid), dim3(256), 0, st, (const uint32_t *)parents, flags, stats, n);
 }
 
 void launch_is_solved686(const int8_t *states, uint8_t *flags, long long *stats, size_t n, hipStream_t st)

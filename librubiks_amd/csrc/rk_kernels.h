@@ -25,8 +25,8 @@ void launch_apply_sequences(const uint8_t *actions, int moves, int games, int wi
                             hipStream_t st);
 void launch_as_oh(const int8_t *states, void *out, int out_dtype, size_t n, hipStream_t st);
 
-void launch_rotate686(const int8_t *states, const uint8_t *actions, int8_t *out, size_t n_out, bool fanout, hipStream_t st);
-void launch_fanout_flags686(const int8_t *parents, uint8_t *flags, long long *stats, size_t n, hipStream_t st);
+void launch_rotate686(const int8_t *states, const uint8_t *actions, int8_t *out, size_t n_out, bool fanout, hipStream_t st,
+                      uint8_t *flags = nullptr, long long *stats = nullptr);
 void launch_is_solved686(const int8_t *states, uint8_t *flags, long long *stats, size_t n, hipStream_t st);
 void launch_as_oh686(const int8_t *states, void *out, int out_dtype, size_t n, hipStream_t st);
 void launch_as_correct686(const int8_t *states, float *out, size_t n, hipStream_t st);

@@ -139,6 +139,39 @@ def test_repr686_golden(golden):
 	assert (s == ref).all()
 
 
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 257, 4099])
+def test_repr686_fanout_flags_one_launch(n):
+	"""6x8x6 fan-out with the goal test fused into the same launch: children, flags, count and first index against the
+	oracle, with parents one move from solved, solved parents and slots that are NOT one-hot (must never read as solved)."""
+	cube.set_is2024(False)
+	np.random.seed(600 + n)
+	p = np.broadcast_to(orc.SOLVED686, (n, 6, 8, 6)).copy()
+	for _ in range(7):
+		p = orc.multi_rotate686(p, np.random.randint(0, 6, n), np.random.randint(0, 2, n))
+	p[n // 2] = orc.rotate686(orc.SOLVED686, 4, 0)                    # child `rev` of this parent is solved
+	if n > 2:
+		p[0] = orc.SOLVED686                                         # a solved parent has no solved child
+		p[n - 1] = orc.rotate686(orc.SOLVED686, 2, 1)
+	if n > 4:
+		junk = orc.rotate686(orc.SOLVED686, 1, 1).copy()
+		junk[3, 5] = [1, 0, 0, 1, 0, 0]                              # two ones in a slot
+		p[1] = junk
+		junk2 = orc.rotate686(orc.SOLVED686, 5, 0).copy()
+		junk2[0, 0] = 0                                              # an empty slot
+		junk2[0, 0, 2] = 2                                           # and a byte that is not 0/1
+		p[2] = junk2
+	ref_ch = np.stack([orc.rotate686(s, a // 2, 1 - a % 2) for s in p for a in range(12)])
+	ref_fl = orc.multi_is_solved686(ref_ch)
+	assert ref_fl.sum() == (1 if n <= 2 else 2)
+	stats = torch.tensor([0, _ffi.INT64_MAX], dtype=torch.int64, device="cuda")
+	ch, fl = cube.device.expand12(dev(p), stats=stats)
+	assert (ch.cpu().numpy() == ref_ch).all() and (fl.cpu().numpy().astype(bool) == ref_fl).all()
+	st = stats.cpu().numpy()
+	assert st[0] == ref_fl.sum() and st[1] == np.flatnonzero(ref_fl)[0]
+	ch2, none = cube.device.expand12(dev(p), want_flags=False)
+	assert none is None and (ch2.cpu().numpy() == ref_ch).all()
+
+
 # ------------------------------------------------------------------------------------------------- oracle parity
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 256, 257, 1000, 4099, 70_001])
 def test_ragged_sizes_against_oracle(n):
