@@ -40,7 +40,7 @@ N_PARENTS = 1_000_000
 BYTES_PER_PARENT = 20 + 240 + 12          # read parent, write 12 children, write 12 solved flags
 READ_BYTES_PER_PARENT = 20
 N_SETS = 4                                # rotating buffer sets: 3 x 272 MB pass between two uses of a set (> 2 x 256 MiB)
-KERNEL = "rk::k_expand12<true, 1, true, 4, false, 1>"      # the instantiation launch_expand12 picks at 1 M parents
+KERNEL = "rk::k_expand12<true, 1, true, 4, true, 1>"       # the instantiation launch_expand12 picks at 1 M parents
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8.0 TB/s spec (about 6.3 TB/s achievable)
 
 

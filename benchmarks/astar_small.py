@@ -1,16 +1,36 @@
-import sys, time, json, numpy as np, torch
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from librubiks_amd import cube
-from librubiks_amd.solving.agents import AStar
-from oracle.search_oracle import StubNet
-from benchmarks.nets import FcSmall
+"""
+A* iteration floor on one MI355X: microseconds per iteration at the reference's N = 10 ... 700 with the exact stub net (engine
+cost only) and the random-init fc_small net; eager launches (host polls every 4 iterations) against the same iteration replayed
+as a hipGraph.  Round 1 (about 16 launches + one host sync per iteration): 115-150 us per iteration at N = 100 with the stub.
+
+    python benchmarks/astar_small.py > profiles/r02_astar_small.json
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from benchmarks.nets import FcSmall  # noqa: E402
+from librubiks_amd import cube  # noqa: E402
+from librubiks_amd.solving.agents import AStar  # noqa: E402
+from oracle.search_oracle import StubNet  # noqa: E402   (the exact stub heuristic of the traces; a net, not the checker)
+
 net = FcSmall().cuda().eval()
-for name, nn in (("stub", StubNet()), ("fc_small fp32", net)):
-    for N in (10, 27, 100, 700):
-        agent = AStar(nn, 0.2, N)
-        np.random.seed(3); state, _, _ = cube.scramble(16, True)
-        agent.search(state, None, 3000)   # warm
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        agent.search(state, None, 200_000)
-        torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        print(json.dumps({"net": name, "N": N, "iterations": agent.iterations, "states": len(agent), "us_per_iteration": dt / agent.iterations * 1e6, "states_per_s": len(agent) / dt}))
+for name, nn in (("stub", StubNet()), ("fc_small fp32", net), ("fc_small bf16", FcSmall().cuda().eval().to(torch.bfloat16))):
+	for N in (10, 27, 100, 700):
+		for graph in (False, True):
+			agent = AStar(nn, 0.2, N, poll=16, use_hipgraph=graph)
+			np.random.seed(3)
+			state, _, _ = cube.scramble(16, True)
+			agent.search(state, None, 3000 + 12 * N)   # warm
+			torch.cuda.synchronize()
+			t0 = time.perf_counter()
+			agent.search(state, None, 200_000)
+			torch.cuda.synchronize()
+			dt = time.perf_counter() - t0
+			print(json.dumps({"net": name, "N": N, "hipgraph": graph, "iterations": agent.iterations, "states": len(agent),
+			                  "us_per_iteration": dt / max(agent.iterations, 1) * 1e6, "states_per_s": len(agent) / dt}), flush=True)

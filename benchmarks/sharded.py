@@ -1,0 +1,96 @@
+"""
+BASELINE.json configs[4]: A* with the open set hash-sharded across the GPUs of one node, RCCL all-to-all frontier exchange
+over xGMI, depth-20 scrambles.  One process per GPU:
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \
+        benchmarks/sharded.py --depth 20 --expansions 700 --max-states 4000000 --games 3
+
+(also runs with one process and no launcher: world = 1, the collectives short-circuit.)  RK_BENCH_BACKEND=gloo rehearses the
+protocol with several ranks sharing one GPU (host-staged collectives).  Rank 0 prints one JSON object per game with the
+iteration time split into all-gather / select+expand / all-to-all / insert / net / push (device time between HIP events on the
+search stream) and one summary object.  No 8-GPU node was available to the build: the harness exists so that the number can be
+taken when one is.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+	ap = argparse.ArgumentParser()
+	ap.add_argument("--depth", type=int, default=20)
+	ap.add_argument("--expansions", type=int, default=700)          # configs/main_eval.ini:9
+	ap.add_argument("--lam", type=float, default=0.16)              # configs/main_eval.ini:8
+	ap.add_argument("--max-states", type=int, default=4_000_000)
+	ap.add_argument("--capacity", type=int, default=0, help="states per rank (default: max_states / world * 1.5 + slack)")
+	ap.add_argument("--games", type=int, default=3)
+	ap.add_argument("--time-limit", type=float, default=60.0)
+	ap.add_argument("--poll", type=int, default=4)
+	ap.add_argument("--net", default="fc_small", choices=["fc_small", "fc_small_bf16", "stub"])
+	args = ap.parse_args()
+
+	rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+	local = int(os.environ.get("LOCAL_RANK", "0"))
+	backend = os.environ.get("RK_BENCH_BACKEND", "nccl")
+	dev = local % max(1, torch.cuda.device_count())
+	torch.cuda.set_device(dev)
+	import torch.distributed as dist
+	if world > 1:
+		if backend == "nccl":
+			dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+		else:
+			dist.init_process_group(backend)
+
+	from benchmarks.nets import FcSmall
+	from librubiks_amd import _ffi, cube
+	from librubiks_amd.solving.sharded import ShardedAStar
+	_ffi.check(_ffi.lib().rk_init(dev))
+	if args.net == "stub":
+		from oracle.search_oracle import StubNet          # the exact stub heuristic (a net stand-in, not the checker)
+		net = StubNet()
+	else:
+		net = FcSmall(seed=0).cuda().eval()               # same seed on every rank: identical weights
+		if args.net.endswith("bf16"):
+			net = net.to(torch.bfloat16)
+	cap = args.capacity or int(args.max_states / world * 1.5) + 12 * args.expansions * world + 1024
+	agent = ShardedAStar(net, args.lam, args.expansions, capacity=cap, poll=args.poll, profile=True)
+	rows = []
+	for g in range(args.games):
+		np.random.seed(g)
+		state, _, _ = cube.scramble(args.depth, True)
+		torch.cuda.synchronize()
+		if world > 1:
+			dist.barrier()
+		t0 = time.perf_counter()
+		solved = agent.search(state, time_limit=args.time_limit, max_states=args.max_states)
+		torch.cuda.synchronize()
+		dt = time.perf_counter() - t0
+		row = {"bench": "sharded_astar", "game": g, "world": world, "backend": backend if world > 1 else "local", "solved": bool(solved),
+		       "stop": agent.stop_reason, "iterations": agent.iterations, "total_states": agent.total_states, "seconds": dt,
+		       "ms_per_iteration": dt / max(agent.iterations, 1) * 1e3, "states_per_s": agent.total_states / dt,
+		       "solution_length": len(agent.action_queue) if solved else None, "collectives": agent.tp.collectives,
+		       "phase_ms": agent.phase_ms}
+		rows.append(row)
+		if rank == 0:
+			print(json.dumps(row), flush=True)
+	if rank == 0:
+		it = sum(r["iterations"] for r in rows)
+		print(json.dumps({"bench": "sharded_astar summary", "config": f"configs[4]: depth-{args.depth} scrambles, lambda={args.lam}, N={args.expansions}, "
+		                  f"max_states={args.max_states}, net={args.net}, world={world}", "games": len(rows), "solved": sum(r["solved"] for r in rows),
+		                  "states_per_s": sum(r["total_states"] for r in rows) / sum(r["seconds"] for r in rows),
+		                  "ms_per_iteration": sum(r["seconds"] for r in rows) / max(it, 1) * 1e3,
+		                  "collectives_per_iteration": rows[-1]["collectives"] / max(sum(r["iterations"] for r in rows), 1)}), flush=True)
+	if world > 1:
+		dist.barrier()
+		dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+	main()

@@ -121,40 +121,58 @@ int rk_as_correct686(const int8_t *d_states, float *d_out, size_t n, void *strea
  * Replaces the expand-children loop of AStar.search / expand_batch / relax_seen_states.  The engine owns:
  *   states (cap+1, 20) int8, G, parents, parent_actions            (agents.py:202-205; index 0 unused, root = 1)
  *   an open-addressing hash table state -> index                    (the `indices` dict, agents.py:201)
- *   the open queue as a device array sorted by (cost, index)        (the heapq of (cost, idx), agents.py:185)
- * One reference iteration (agents.py:236-252 + 254-331) is two calls around the net forward that PyTorch owns:
- *   rk_astar_expand : pop the <= n best nodes (heappop order), 12-child fan-out, membership + first-occurrence
- *                     de-duplication in parent-major batch order (np.unique semantics, agents.py:286-295), append
- *                     the unseen states with G / parent / action (agents.py:299-313), goal test of the new states
- *                     (agents.py:321-323).  Synchronises; h_info = {popped, new, won, solved_index, n_states}.
- *   rk_astar_new_states_oh : one-hot of exactly the `new` states, in index order, for the value net (agents.py:379)
- *   rk_astar_commit : cost = lambda*G + (-value) in float64 (agents.py:383), push into the open queue
- *                     (agents.py:316-317), then relax the already-seen children (agents.py:326-329, 333-367).
- *                     Skip it when `won` (the reference returns before relaxing).
- * Results are identical to the reference's arrays (same index numbering, G, parents, parent_actions) whenever the
- * value net returns the same numbers.  An engine handle is not thread-safe: one host thread drives it, on one stream
- * at a time (different handles are independent). */
+ *   the open queue as a few sorted runs (capacities 4K, 16K, 64K ... records, K = 12 * expansions): pop = the
+ *   globally smallest (cost, index) records in heappop order, push = one multi-way merge into the first run that
+ *   holds the result -- O(K log) queue traffic per iteration                       (the heapq, agents.py:185)
+ * and EVERY size that varies (states, nodes popped, new states, won, out of budget) in device memory, so that one
+ * reference iteration (agents.py:236-252 + 254-331) is two stream-ordered calls around the net forward that PyTorch
+ * owns, neither of which synchronises with the host:
+ *   rk_astar_step_expand : loop guard `len + 12 N <= max_states` (:236), pop the <= N best nodes (:238-239), 12-child
+ *                          fan-out (:277-282), membership + first-occurrence de-duplication in parent-major batch order
+ *                          (np.unique semantics, :286-295), append the unseen states with G / parent / action
+ *                          (:299-313), goal test of the new states (:321-323), and the one-hot rows of the new states
+ *                          (:379) into d_onehot (12 N, 480) -- rows past the number of new states are left untouched
+ *   rk_astar_step_commit : d_values (12 N) from the net; cost = lambda*G + (-value) in float64 (:383), push (:316-317),
+ *                          relaxation of the already-seen children (:326-329, 333-367; skipped once won, as the
+ *                          reference returns before relaxing), bookkeeping and the next pop list
+ *   rk_astar_status      : synchronises; h_status[8] = done, won, n_states, iterations, open-queue length, index of the
+ *                          solved state, error, nodes the next iteration pops
+ * Five launches per iteration (plus merge passes when 12 N > 2048), fixed shapes: an iteration can be captured in a
+ * hipGraph.  Once `done` (won, out of budget, queue empty) further steps are no-ops.  Results are identical to the
+ * reference's arrays (same index numbering, G, parents, parent_actions) whenever the value net returns the same
+ * numbers.  An engine handle is not thread-safe: one host thread drives it, on one stream at a time. */
 typedef struct rk_astar rk_astar_t;
 int rk_astar_create(rk_astar_t **out, size_t capacity, int max_expansions);
 int rk_astar_destroy(rk_astar_t *h);
 int rk_astar_reset(rk_astar_t *h, const int8_t *h_start_state, double lambda, void *stream);
+/* max_states of agents.py:236 (default: the capacity). */
+int rk_astar_set_budget(rk_astar_t *h, long long max_states, void *stream);
+int rk_astar_step_expand(rk_astar_t *h, void *d_onehot, int out_dtype, void *stream);
+int rk_astar_step_commit(rk_astar_t *h, const float *d_values, void *stream);
+int rk_astar_status(rk_astar_t *h, long long *h_status /* [8] */, void *stream);
+/* The same iteration as three calls for hosts that want to feed the net exactly the new states: rk_astar_expand
+ * synchronises, h_info = {popped, new, won, solved_index, n_states}; rk_astar_new_states_oh writes the one-hot of the
+ * `new` states in index order; rk_astar_commit takes their values. */
 int rk_astar_expand(rk_astar_t *h, int n_expand, long long *h_info /* [5] */, void *stream);
 int rk_astar_new_states_oh(rk_astar_t *h, void *d_out, int out_dtype, void *stream);
 int rk_astar_commit(rk_astar_t *h, const float *d_values, void *stream);
-/* Number of stored states (len(agent), agents.py:409-410) and of open-queue entries. */
+/* Number of stored states (len(agent), agents.py:409-410) and of open-queue entries.  Synchronise. */
 long long rk_astar_size(const rk_astar_t *h);
 long long rk_astar_open_size(const rk_astar_t *h);
 /* Copy rows [first, first+count) of the node arrays to HOST buffers (any may be NULL): states int8 (count,20),
  * G float64, parents int64, parent_actions int64 -- the reference's dtypes (agents.py:390-393). */
 int rk_astar_export(rk_astar_t *h, size_t first, size_t count, int8_t *h_states, double *h_G, long long *h_parents,
                     long long *h_parent_actions, void *stream);
-/* Action indices from the root to node `index`, by walking parents (agents.py:244-251).  Returns the path length
- * (>= 0) or a negative error; writes at most `max_len` actions. */
+/* Action indices from the root to node `index`: the parents are walked on the device (agents.py:244-251).  Returns
+ * the path length (>= 0) or a negative error; writes at most `max_len` actions. */
 long long rk_astar_path(rk_astar_t *h, long long index, long long *h_actions, size_t max_len, void *stream);
 /* Index of a state in the closed set or 0 (the `indices` dict lookup); host state in, synchronises. */
 long long rk_astar_lookup(rk_astar_t *h, const int8_t *h_state, void *stream);
-/* The open queue in pop order: up to max_len (cost, index) pairs to HOST arrays; returns the count written. */
+/* The open queue in pop order: up to max_len (cost, index) pairs to HOST arrays; returns the count written.
+ * Inspection only (gathers every run and sorts on the host). */
 long long rk_astar_export_open(rk_astar_t *h, double *h_costs, long long *h_indices, size_t max_len, void *stream);
+/* The node indices the NEXT iteration pops, in heappop order (agents.py:238-239). */
+long long rk_astar_next_pops(rk_astar_t *h, long long *h_indices, size_t max_len, void *stream);
 
 /* ---- batched A*: S independent searches in lock-step, no host synchronisation inside an iteration -------------
  * Every search follows agents.py:171-413 exactly as rk_astar_* does; all sizes that vary (nodes popped, new states,
@@ -182,26 +200,40 @@ int rk_astarb_export(rk_astarb_t *h, int search, size_t first, size_t count, int
 long long rk_astarb_path(rk_astarb_t *h, int search, long long index, long long *h_actions, size_t max_len, void *stream);
 
 /* ---- hash-sharded A* across the GPUs of a node (BASELINE config 5; no counterpart in the reference) ------------
- * One engine per GPU/rank holds the states it owns, owner(state) = rk_shard_owner(state, world).  The host drives
- * one iteration as: pick the globally best N open nodes (all-gather of the queue heads) -> rk_astar_shard_pop
- * (expand, bucket the 12 n children by owner as 32-byte records) -> all-to-all of the buckets (RCCL over xGMI) ->
- * rk_astar_shard_insert on what was received (same membership / first-occurrence / append / relaxation-case-1
- * semantics as rk_astar_expand+commit, in arrival order) -> net on the new states -> rk_astar_shard_push ->
- * all-to-all of the 16-byte shortcut offers (relaxation case 2) -> rk_astar_shard_apply_shortcuts.
- * With world = 1 this reproduces the single-GPU engine exactly.  librubiks_amd/solving/sharded.py is the driver. */
+ * One engine per GPU/rank holds the states it owns, owner(state) = rk_shard_owner(state, world).  An iteration is two
+ * collectives with fixed-size device buffers and no host synchronisation in between:
+ *   all-gather   rk_astar_shard_gather_ptr: 8 + N doubles per rank = {pool size, won, solved index, error, candidates,
+ *                elapsed seconds (host of rank 0 writes slot 5), 0, 0, the rank's N cheapest open costs ascending, +inf}
+ *   rk_astar_shard_select (gathered)  identical stop decision on every rank (won / budget / a pool could overflow /
+ *                time / error / nothing open) and the global top-N by (cost, rank, position); expands this rank's share
+ *                and buckets the 32-byte child records by owner (stable) into d_send
+ *   all-to-all   equal splits of rk_astar_shard_block_bytes() per peer: {32-byte header = record count, offer count;
+ *                12 N records of 32 B; 12 N shortcut offers of 16 B} -- counts travel inside the blocks
+ *   rk_astar_shard_insert (d_recv)  applies the offers received (relaxation case 2 of the PREVIOUS iteration on the
+ *                parents' owner), then membership / first-occurrence / append / goal test / relaxation case 1 in arrival
+ *                order and the one-hot rows of the new states (world * 12 N rows at most)
+ *   rk_astar_shard_push  values -> cost, push; builds this iteration's offers into d_send for the next all-to-all;
+ *                bookkeeping, next candidates, next all-gather contribution
+ * rk_astar_shard_decision (synchronises) lets the host learn the stop decision -- every iteration or every few.
+ * After a stop without a win: one more select + all-to-all, then rk_astar_shard_flush applies the pending offers.
+ * With world = 1 (send buffer = receive buffer) this reproduces the single-GPU engine exactly.
+ * librubiks_amd/solving/sharded.py is the driver. */
 int rk_astar_create_sharded(rk_astar_t **out, size_t capacity, int max_expansions, int rank, int world);
 int rk_shard_owner(const int8_t *h_state, int world);
-int rk_astar_shard_reset(rk_astar_t *h, const int8_t *h_start_state, double lambda, void *stream);
-/* Pops n_pop nodes, writes their 12 n_pop child records grouped by owner into d_send (32 B each) and the per-owner
- * record counts into h_send_counts[world].  Synchronises. */
-int rk_astar_shard_pop(rk_astar_t *h, int n_pop, void *d_send, long long *h_send_counts, void *stream);
-/* Inserts n_recv received records (grouped by sending rank, each group in the sender's order).  Writes shortcut
- * offers (16 B each, grouped by destination rank) to d_shortcuts_out and their per-rank counts to
- * h_shortcut_counts[world]; h_info as rk_astar_expand.  Synchronises. */
-int rk_astar_shard_insert(rk_astar_t *h, const void *d_recv, long long n_recv, void *d_shortcuts_out,
-                          long long *h_shortcut_counts, long long *h_info, void *stream);
-int rk_astar_shard_push(rk_astar_t *h, const float *d_values, void *stream);
-int rk_astar_shard_apply_shortcuts(rk_astar_t *h, const void *d_shortcuts, long long n, void *stream);
+long long rk_astar_shard_block_bytes(const rk_astar_t *h);
+long long rk_astar_shard_gather_len(const rk_astar_t *h);
+void *rk_astar_shard_gather_ptr(rk_astar_t *h);
+/* Make the engine write its all-gather contribution into caller memory (8 + N doubles, 8-byte aligned). */
+int rk_astar_shard_bind(rk_astar_t *h, void *d_gather);
+int rk_astar_shard_reset(rk_astar_t *h, const int8_t *h_start_state, double lambda, void *d_send, void *stream);
+int rk_astar_shard_select(rk_astar_t *h, const void *d_gathered, double time_limit, double max_states, void *d_send, void *stream);
+/* h_out[8] = {stop reason (0 none, 1 won, 2 budget, 3 capacity, 4 time, 5 nothing open, 6 error), winner rank, winner
+ * index, total states, this rank's pops, iterations, this rank's states, 0}. */
+int rk_astar_shard_decision(rk_astar_t *h, long long *h_out, void *stream);
+int rk_astar_shard_insert(rk_astar_t *h, const void *d_recv, void *d_send, void *d_onehot, int out_dtype, void *stream);
+int rk_astar_shard_push(rk_astar_t *h, const float *d_values, const void *d_recv, void *d_send, void *stream);
+int rk_astar_shard_flush(rk_astar_t *h, const void *d_recv, void *stream);
+int rk_astar_shard_clear_send(rk_astar_t *h, void *d_send, int records, int offers, void *stream);
 /* h_out = {parent rank, parent index, action} of node `index` on this rank (for the cross-rank path walk). */
 int rk_astar_shard_parent(rk_astar_t *h, long long index, long long *h_out, void *stream);
 

@@ -47,6 +47,10 @@ SIGNATURES = {
 	"rk_astar_create": (_i, [C.POINTER(_vp), _sz, _i]),
 	"rk_astar_destroy": (_i, [_vp]),
 	"rk_astar_reset": (_i, [_vp, _vp, C.c_double, _vp]),
+	"rk_astar_set_budget": (_i, [_vp, C.c_longlong, _vp]),
+	"rk_astar_step_expand": (_i, [_vp, _vp, _i, _vp]),
+	"rk_astar_step_commit": (_i, [_vp, _vp, _vp]),
+	"rk_astar_status": (_i, [_vp, _vp, _vp]),
 	"rk_astar_expand": (_i, [_vp, _i, _vp, _vp]),
 	"rk_astar_new_states_oh": (_i, [_vp, _vp, _i, _vp]),
 	"rk_astar_commit": (_i, [_vp, _vp, _vp]),
@@ -56,6 +60,7 @@ SIGNATURES = {
 	"rk_astar_path": (C.c_longlong, [_vp, C.c_longlong, _vp, _sz, _vp]),
 	"rk_astar_lookup": (C.c_longlong, [_vp, _vp, _vp]),
 	"rk_astar_export_open": (C.c_longlong, [_vp, _vp, _vp, _sz, _vp]),
+	"rk_astar_next_pops": (C.c_longlong, [_vp, _vp, _sz, _vp]),
 	"rk_astarb_create": (_i, [C.POINTER(_vp), _i, _sz, _i]),
 	"rk_astarb_destroy": (_i, [_vp]),
 	"rk_astarb_reset": (_i, [_vp, _vp, _vp, C.c_double, _vp]),
@@ -67,11 +72,17 @@ SIGNATURES = {
 	"rk_astarb_path": (C.c_longlong, [_vp, _i, C.c_longlong, _vp, _sz, _vp]),
 	"rk_astar_create_sharded": (_i, [C.POINTER(_vp), _sz, _i, _i, _i]),
 	"rk_shard_owner": (_i, [_vp, _i]),
-	"rk_astar_shard_reset": (_i, [_vp, _vp, C.c_double, _vp]),
-	"rk_astar_shard_pop": (_i, [_vp, _i, _vp, _vp, _vp]),
-	"rk_astar_shard_insert": (_i, [_vp, _vp, C.c_longlong, _vp, _vp, _vp, _vp]),
-	"rk_astar_shard_push": (_i, [_vp, _vp, _vp]),
-	"rk_astar_shard_apply_shortcuts": (_i, [_vp, _vp, C.c_longlong, _vp]),
+	"rk_astar_shard_block_bytes": (C.c_longlong, [_vp]),
+	"rk_astar_shard_gather_len": (C.c_longlong, [_vp]),
+	"rk_astar_shard_gather_ptr": (_vp, [_vp]),
+	"rk_astar_shard_bind": (_i, [_vp, _vp]),
+	"rk_astar_shard_reset": (_i, [_vp, _vp, C.c_double, _vp, _vp]),
+	"rk_astar_shard_select": (_i, [_vp, _vp, C.c_double, C.c_double, _vp, _vp]),
+	"rk_astar_shard_decision": (_i, [_vp, _vp, _vp]),
+	"rk_astar_shard_insert": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+	"rk_astar_shard_push": (_i, [_vp, _vp, _vp, _vp, _vp]),
+	"rk_astar_shard_flush": (_i, [_vp, _vp, _vp]),
+	"rk_astar_shard_clear_send": (_i, [_vp, _vp, _i, _i, _vp]),
 	"rk_astar_shard_parent": (_i, [_vp, C.c_longlong, _vp, _vp]),
 	"rk_mcts_create": (_i, [C.POINTER(_vp), _i, _sz, _sz]),
 	"rk_mcts_destroy": (_i, [_vp]),

@@ -1,18 +1,36 @@
-// Device-resident batch weighted A* (reference: librubiks/solving/agents.py:171-413).
+// Device-resident batch weighted A* (reference: librubiks/solving/agents.py:171-413), sync-free and fused.
 //
-// What lives in HBM (capacity C states, N = max expansions per iteration, K = 12 N children per iteration):
+// What lives in HBM (capacity C states, N = expansions per iteration, K = 12 N children per iteration):
 //   states  int8 (C+1, 20)   node pool, index 0 unused, root = 1              (agents.py:202, :390)
 //   G       int32 (C+1)      path cost (whole numbers; exported as float64)    (agents.py:203, :393)
-//   parents int32, pact uint8                                                  (agents.py:204-205)
+//   parents int32, pact uint8, prank uint8 (owner rank of the parent, sharded mode)   (agents.py:204-205)
 //   table   uint32 (T)       open-addressing hash table state -> index, T = pow2 >= 2C   (the `indices` dict)
 //   mark    uint32 (C+1)     per-node scratch: batch position of a seen state's first occurrence
-//   open    Rec[2][C+1]      the open queue as an array SORTED by (cost, index); ping-pong buffers
+//   open    the open queue as a small log-structured set of SORTED runs ("levels", capacities 4 K, 16 K, 64 K, ...)
+//   ctr     int32[32]        every size that varies: states, popped, new, won, done, budget, iterations, ...
 //
-// The reference pops with heapq from a heap of (cost, idx) tuples and never re-pushes a node, so "the N smallest
-// (cost, idx) pairs in ascending order" is exactly what it expands.  A sorted array makes the pop free (take the
-// head); new nodes always carry larger indices than old ones, so pushing is: sort the <= K new records by
-// (cost, idx), then one rank-merge with the remaining queue (every element finds its output slot by a binary
-// search in the other run; all (cost, idx) keys are distinct, so there are no tie cases).
+// The open queue.  The reference pops with heapq from a heap of (cost, idx) tuples and never re-pushes a node, so
+// "the N smallest (cost, idx) pairs in ascending order" is exactly what it expands (agents.py:238-239).  Here every
+// level is an array sorted by (cost, idx) with a head pointer.  Pop = the N globally smallest records among the first
+// N of every level: each candidate finds its global rank with one binary search per other level (keys are distinct),
+// so the pop order is exact.  Push = sort the <= K new records and rank-merge them with levels 0..t into level t,
+// where t is the first level whose capacity holds them all -- the classic logarithmic method: a record takes part in
+// O(log(|open| / K)) merges, so an iteration moves O(K log) queue bytes instead of re-merging all of |open|
+// (round 1 merged the whole queue, 16 B x |open|, every iteration).
+//
+// One iteration (agents.py:236-252 + 254-331) is FIVE launches around the net forward, none of which synchronises:
+//   k_expand_lookup   pop list -> parents -> 12 children each (agents.py:277-282), goal flag, membership test and
+//                     in-batch first-occurrence election through the hash table (agents.py:286-295)
+//   k_append          first_unseen / first_seen flags, order-preserving compaction across workgroups (chained scan),
+//                     append with G / parent / action (agents.py:299-313), goal test of the new states (:321-323),
+//                     read half of relaxation case 1 (:354), and the one-hot rows of the new states for the net
+//   [net forward on the fixed (12 N, 480) batch -- PyTorch]
+//   k_records_sort    cost = lambda*G + (-value) in float64 (agents.py:383), bitonic sort of 2048-record chunks in LDS,
+//                     write half of relaxation case 1 (:357-359)          (+ log2(K/2048) merge passes when K > 2048)
+//   k_queue_insert    the multi-way rank merge described above (heappush, :316-317); read half of case 2 (:362)
+//   k_end             write half of case 2 (:365-367), queue bookkeeping, loop guard (:236), and the NEXT pop list
+// All shapes are fixed by N, so an iteration can be captured in a hipGraph and replayed; the host polls `ctr` now and
+// then (rk_astar_status).  Kernels are no-ops once `done` is set (won, out of budget, queue empty).
 //
 // Order-dependent semantics that are reproduced exactly:
 //   * children are generated parent-major / action-minor in pop order                      (agents.py:277-282)
@@ -21,8 +39,13 @@
 //   * new indices are handed out in batch order                                            (agents.py:300)
 //   * relaxation is two vectorised passes, each reading all of G before writing, the second seeing the first's
 //     writes; duplicate targets in the second pass resolve to the LAST one in batch order  (agents.py:353-367)
+//
+// Hash-sharded mode (one engine per GPU, owner(state) = owner_of(state, world); no counterpart in the reference): see
+// the section "hash-sharded search" below and librubiks_amd/solving/sharded.py.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <climits>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -34,429 +57,555 @@
 
 namespace rk {
 
-// ---------------------------------------------------------------------------------------------------------------
-__global__ void k_astar_root(uint32_t *states, int32_t *G, int32_t *parents, uint8_t *pact, uint32_t *table, uint32_t mask,
-                             Rec *open, const uint32_t *root)
+enum {
+	C_NSTATES = 0, C_NBEFORE, C_NPOP, C_NNEW, C_WON, C_SOLVED, C_DONE, C_BUDGET, C_ITERS, C_ERROR, C_OPEN, C_NCAND, C_NEXP, C_NIN,
+	C_NOFF, C_EPOCH, C_TICKET0 = 16, C_TICKET1, C_TICKET2, C_COUNT = 32
+};
+enum { ERR_NONE = 0, ERR_CAPACITY = 1, ERR_CHAIN = 2 };
+
+constexpr int QL = 12;                          // maximal number of queue levels
+constexpr int SORT_CHUNK = 2048;                // records sorted per workgroup in LDS (32 KB)
+enum { Q_HEAD = 0, Q_LEN = 1, Q_CUR = 2, Q_TAKE = 3 };
+
+struct QueueDev {
+	Rec *buf[QL][2];
+	uint32_t cap[QL];
+	int levels;
+	int32_t *meta;                              // [4][QL]: head, len, current buffer, records taken by the pending pop
+};
+
+struct AstarDev {
+	uint32_t mask, cap1;
+	int N, K, Kpad;                             // expansions, 12 N, K rounded up to SORT_CHUNK
+	int world, rank, KI;                        // sharded: ranks, this rank, incoming child slots = world * K
+	double lambda;
+	uint32_t *states; int32_t *G, *parents; uint8_t *pact, *prank; uint32_t *table, *mark;
+	int32_t *ctr;
+	QueueDev q;
+	int32_t *exp_idx; uint64_t *cand_key; uint8_t *cand_level;       // the pop list (rank order)
+	uint32_t *children; uint8_t *solved;
+	int32_t *seen; uint32_t *child_slot; uint8_t *flags; int32_t *rank_local;
+	uint8_t *newway, *shortcut; int32_t *val1, *val2;
+	Rec *rec0, *rec1;
+	unsigned long long *chain0, *chain1, *chain2;                    // chained-scan words
+	uint8_t *hit;
+	double *gather_in;                                               // sharded: this rank's all-gather contribution
+};
+
+__device__ __forceinline__ int32_t *qmeta(const QueueDev &q, int which) { return q.meta + which * QL; }
+
+// ---- queue merge plan: identical on every thread that computes it from the same meta ----------------------------
+struct MergePlan {
+	int t;                       // target level (-1: nothing to merge)
+	int n_runs;
+	const Rec *run[QL + 1];
+	int len[QL + 1];
+	int total;
+	Rec *dst;
+};
+
+// meta = pointer to [4][QL] ints (global or LDS copy).  live range of level j after the pending pop: [head+take, len)
+__device__ __forceinline__ void make_plan(const QueueDev &q, const int32_t *meta, const Rec *newrun, int n_new, MergePlan &p)
 {
-	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	p.t = -1; p.n_runs = 0; p.total = 0; p.dst = nullptr;
+	if (n_new <= 0) return;
+	int sum = n_new, t = 0;
+	for (; t < q.levels; t++) {
+		sum += meta[Q_LEN * QL + t] - meta[Q_HEAD * QL + t] - meta[Q_TAKE * QL + t];
+		if ((uint32_t)sum <= q.cap[t]) break;
+	}
+	if (t >= q.levels) t = q.levels - 1;       // cannot happen: the top level holds the whole pool
+	p.t = t;
+	p.run[0] = newrun; p.len[0] = n_new; p.n_runs = 1;
+	for (int j = 0; j <= t; j++) {
+		const int start = meta[Q_HEAD * QL + j] + meta[Q_TAKE * QL + j];
+		const int live = meta[Q_LEN * QL + j] - start;
+		if (live > 0) {
+			p.run[p.n_runs] = q.buf[j][meta[Q_CUR * QL + j]] + start;
+			p.len[p.n_runs] = live;
+			p.n_runs++;
+		}
+	}
+	p.total = sum;
+	p.dst = q.buf[t][meta[Q_CUR * QL + t] ^ 1];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_astar_root(AstarDev d, const uint32_t *root, int insert)
+{
+	const int tid = threadIdx.x;
+	if (tid < C_COUNT) d.ctr[tid] = 0;
+	if (tid < 4 * QL) d.q.meta[tid] = 0;
+	__syncthreads();
+	if (tid != 0) return;
+	d.ctr[C_BUDGET] = (int32_t)(d.cap1 - 1);
+	d.ctr[C_NEXP] = d.N;
+	if (!insert) return;                          // sharded: a rank that does not own the root starts empty
 	uint32_t s[5];
 	load5(root, s);
 	#pragma unroll
-	for (int j = 0; j < 5; j++) states[5 + j] = s[j];
-	G[1] = 0; parents[1] = 0; pact[1] = 0;
-	table[hash_state(s) & mask] = 1u;
-	open[0] = Rec{sortable_key(0.0), 1ull};       // heappush(open_queue, (0, 1))   agents.py:234
+	for (int j = 0; j < 5; j++) d.states[5 + j] = s[j];
+	d.G[1] = 0; d.parents[1] = 0; d.pact[1] = 0; d.prank[1] = (uint8_t)d.rank;
+	d.table[hash_state(s) & d.mask] = 1u;
+	d.q.buf[0][0][0] = Rec{sortable_key(0.0), 1ull};       // heappush(open_queue, (0, 1))   agents.py:234
+	d.q.meta[Q_LEN * QL + 0] = 1;
+	d.ctr[C_NSTATES] = 1; d.ctr[C_NBEFORE] = 1; d.ctr[C_OPEN] = 1;
+	d.exp_idx[0] = 1; d.cand_key[0] = sortable_key(0.0); d.cand_level[0] = 0;
+	d.ctr[C_NCAND] = 1;
+	d.ctr[C_NPOP] = 1;
 }
 
-// pop: the head of the sorted queue; gather the parents' states                                 agents.py:238-239
-__global__ void k_astar_pop(const Rec *open, int n_pop, const uint32_t *states, int32_t *exp_idx, uint32_t *par_states)
+// The pop list of the next iteration: the n_cand = min(N, |open|) globally smallest records in ascending order.
+// `meta` is the committed queue state (LDS copy); candidates are the first N live records of every level.
+__device__ __forceinline__ void pop_select(const AstarDev &d, const int32_t *meta, int n_cand, int n_exp)
 {
-	const int t = blockIdx.x * blockDim.x + threadIdx.x;
-	if (t >= n_pop * 5) return;
-	const int i = t / 5, j = t - 5 * i;
-	const uint32_t idx = (uint32_t)open[i].idx;
-	if (j == 0) exp_idx[i] = (int32_t)idx;
-	par_states[t] = states[(size_t)idx * 5 + j];
+	const QueueDev &q = d.q;
+	for (int cand = threadIdx.x; cand < q.levels * n_exp; cand += blockDim.x) {
+		const int j = cand / n_exp, i = cand - j * n_exp;
+		const int head = meta[Q_HEAD * QL + j], live = meta[Q_LEN * QL + j] - head;
+		if (i >= live) continue;
+		const Rec *run = q.buf[j][meta[Q_CUR * QL + j]] + head;
+		const Rec x = run[i];
+		int rank = i;
+		for (int j2 = 0; j2 < q.levels; j2++) {
+			if (j2 == j) continue;
+			const int h2 = meta[Q_HEAD * QL + j2];
+			int m = meta[Q_LEN * QL + j2] - h2;
+			m = m < n_exp ? m : n_exp;
+			if (m > 0) rank += lower_bound_rec(q.buf[j2][meta[Q_CUR * QL + j2]] + h2, m, x);
+		}
+		if (rank < n_cand) {
+			d.exp_idx[rank] = (int32_t)x.idx;
+			d.cand_key[rank] = x.key;
+			d.cand_level[rank] = (uint8_t)j;
+		}
+	}
+}
+
+// child c of this iteration, recomputed from the pop list (used when a hash slot holds another child's tentative claim)
+__device__ __forceinline__ void child_of(const AstarDev &d, const u32x4 *s_act, int c, uint32_t s[5])
+{
+	const int i = c / 12;
+	load5(d.states + (size_t)d.exp_idx[i] * 5, s);
+	uint32_t tab[12];
+	load_action_table(s_act, (uint32_t)(c - 12 * i), tab);
+	move5(s, tab);
 }
 
 // membership test + in-batch first-occurrence election through the hash table                    agents.py:286-295
-// `stride` = dwords between consecutive child states: 5 for a plain (K,20) array, 8 for 32-byte exchange records
-__global__ void k_astar_lookup(const uint32_t *children, int stride, int K, const uint32_t *states, uint32_t *table, uint32_t mask,
-                               uint32_t *mark, int32_t *seen, uint32_t *child_slot)
+// other(c', buf): state of batch position c' (recomputed or loaded).  Returns through seen / child_slot.
+template <typename Other>
+__device__ __forceinline__ void lookup_elect(const AstarDev &d, const uint32_t s[5], int c, Other other)
 {
-	const int c = blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= K) return;
-	uint32_t s[5];
-	load5(children + (size_t)c * stride, s);
-	uint32_t slot = hash_state(s) & mask;
+	uint32_t slot = hash_state(s) & d.mask;
 	for (;;) {
-		uint32_t e = __atomic_load_n(&table[slot], __ATOMIC_RELAXED);
+		uint32_t e = __hip_atomic_load(&d.table[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (e == 0u) {
-			e = atomicCAS(&table[slot], 0u, TENT | (uint32_t)c);
-			if (e == 0u) { seen[c] = 0; child_slot[c] = slot; return; }
+			e = atomicCAS(&d.table[slot], 0u, TENT | (uint32_t)c);
+			if (e == 0u) { d.seen[c] = 0; d.child_slot[c] = slot; return; }
 		}
 		if (e & TENT) {
-			if (equal5(s, children + (size_t)(e & ~TENT) * stride)) {
-				atomicMin(&table[slot], TENT | (uint32_t)c);          // all claimants hold the same state: smallest position wins
-				seen[c] = 0; child_slot[c] = slot;
+			uint32_t o[5];
+			other((int)(e & ~TENT), o);
+			if (((s[0] ^ o[0]) | (s[1] ^ o[1]) | (s[2] ^ o[2]) | (s[3] ^ o[3]) | (s[4] ^ o[4])) == 0u) {
+				atomicMin(&d.table[slot], TENT | (uint32_t)c);        // all claimants hold the same state: smallest position wins
+				d.seen[c] = 0; d.child_slot[c] = slot;
 				return;
 			}
-		} else if (equal5(s, states + (size_t)e * 5)) {
-			seen[c] = (int32_t)e;
-			atomicMin(&mark[e], (uint32_t)c);
+		} else if (equal5(s, d.states + (size_t)e * 5)) {
+			d.seen[c] = (int32_t)e;
+			atomicMin(&d.mark[e], (uint32_t)c);
 			return;
 		}
-		slot = (slot + 1) & mask;
+		slot = (slot + 1) & d.mask;
 	}
 }
 
-// ---- order-preserving compaction across many workgroups ---------------------------------------------------------
-// Three small launches: (1) per-1024-element workgroup: predicate, rank inside the workgroup, workgroup total;
-// (2) one workgroup scans the totals; (3) the consumer adds the workgroup's offset to the local rank.
-// first_unseen / first_seen flags (agents.py:291-295) and the rank of every first_unseen child inside its workgroup
-__global__ __launch_bounds__(SCAN_BLOCK)
-void k_astar_flags(int K, const uint32_t *table, const uint32_t *mark, const int32_t *seen, const uint32_t *child_slot,
-                   uint8_t *flags, int32_t *rank, int32_t *block_sums)
+// pop + gather + 12-child fan-out + goal flag + membership / election: one thread per child
+__global__ __launch_bounds__(256)
+void k_expand_lookup(AstarDev d)
 {
-	__shared__ int s_wave[16];
-	const int c = blockIdx.x * SCAN_BLOCK + threadIdx.x;
-	int fu = 0, fs = 0;
-	if (c < K) {
-		const int32_t sidx = seen[c];
-		if (sidx == 0) fu = table[child_slot[c]] == (TENT | (uint32_t)c);
-		else fs = mark[sidx] == (uint32_t)c;
-		flags[c] = (uint8_t)(fu | (fs << 1));
-	}
-	int total;
-	const int r = block_rank(fu != 0, s_wave, &total);
-	if (c < K) rank[c] = r;
-	if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
-}
-
-// exclusive scan of `n` workgroup totals in place (one workgroup); the grand total goes to *out_total
-__global__ __launch_bounds__(SCAN_BLOCK)
-void k_scan_blocks(int32_t *sums, int n, long long *out_total)
-{
-	__shared__ int s_wave[16];
-	__shared__ int s_base;
-	if (threadIdx.x == 0) s_base = 0;
+	__shared__ u32x4 s_act[36];
+	stage_action_tables(s_act, threadIdx.x);
 	__syncthreads();
-	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	for (int i0 = 0; i0 < n; i0 += SCAN_BLOCK) {
-		const int i = i0 + threadIdx.x;
-		const int v = i < n ? sums[i] : 0;
-		int incl = v;                                  // inclusive scan inside the wave
-		#pragma unroll
-		for (int d = 1; d < 64; d <<= 1) {
-			const int o = __shfl_up(incl, d, 64);
-			if (lane >= d) incl += o;
-		}
-		if (lane == 63) s_wave[wv] = incl;
-		__syncthreads();
-		int before = s_base;
-		for (int w = 0; w < wv; w++) before += s_wave[w];
-		if (i < n) sums[i] = before + incl - v;
-		__syncthreads();
-		if (threadIdx.x == 0) {
-			int tot = 0;
-			for (int w = 0; w < 16; w++) tot += s_wave[w];
-			s_base += tot;
-		}
-		__syncthreads();
-	}
-	if (threadIdx.x == 0 && out_total != nullptr) *out_total = s_base;
+	const int c = blockIdx.x * blockDim.x + threadIdx.x;
+	const int n_pop = d.ctr[C_NPOP];
+	if (c >= 12 * n_pop) return;
+	const int i = c / 12, a = c - 12 * i;
+	if (a == 0) atomicAdd(&qmeta(d.q, Q_TAKE)[d.cand_level[i]], 1);     // the queue learns which level the node leaves
+	uint32_t s[5];
+	load5(d.states + (size_t)d.exp_idx[i] * 5, s);
+	uint32_t tab[12];
+	load_action_table(s_act, (uint32_t)a, tab);
+	move5(s, tab);
+	#pragma unroll
+	for (int j = 0; j < 5; j++) d.children[(size_t)c * 5 + j] = s[j];
+	d.solved[c] = is_solved5(s) ? 1 : 0;
+	lookup_elect(d, s, c, [&](int c2, uint32_t o[5]) { child_of(d, s_act, c2, o); });
 }
 
-// append the new states (agents.py:299-313), finalise their hash slots, goal test of the new states
-// (agents.py:321-323) and the read half of relaxation case 1 (agents.py:354).
-// SHARDED = false: children is a (K,20) array, the parent of child c is exp_idx[c/12], its action c%12.
-// SHARDED = true : children are 32-byte records {state[5], parent_idx, g | action<<16 | parent_rank<<24, pad}
-//                  received from the ranks that expanded them; the parent lives on rank parent_rank.
-template <bool SHARDED>
-__global__ void k_astar_append(const uint32_t *children, const uint8_t *solved, int K, const uint8_t *flags, const int32_t *rank,
-                               const int32_t *block_off, const int32_t *seen, const uint32_t *child_slot, const int32_t *exp_idx, uint32_t n_before,
-                               uint32_t *states, int32_t *G, int32_t *parents, uint8_t *pact, uint8_t *prank, uint32_t *table,
-                               uint8_t *newway, int32_t *val1, long long *counters)
+// one-hot rows [row0, row0 + n) of `out` from n states held in LDS (5 dwords each); the whole workgroup cooperates
+template <int ELEM_BYTES>
+__device__ __forceinline__ void oh_rows_from_lds(const uint32_t *s_states, int n, u32x4 *out, size_t row0, uint32_t one_bits)
+{
+	constexpr int E = 16 / ELEM_BYTES, CPR = 480 / E, CPC = 24 / E;
+	const uint8_t *bytes = reinterpret_cast<const uint8_t *>(s_states);
+	u32x4 *dst = out + row0 * CPR;
+	for (int q = threadIdx.x; q < n * CPR; q += blockDim.x) {
+		const int r = q / CPR, g = q - r * CPR;
+		const int cubie = g / CPC, base = (g - cubie * CPC) * E;
+		const int rel = (int)bytes[r * STATE_BYTES + cubie] - base;
+		u32x4 val = {0u, 0u, 0u, 0u};
+		if (ELEM_BYTES == 4) {
+			val.x = rel == 0 ? one_bits : 0u; val.y = rel == 1 ? one_bits : 0u;
+			val.z = rel == 2 ? one_bits : 0u; val.w = rel == 3 ? one_bits : 0u;
+		} else if (rel >= 0 && rel < 8) {
+			const uint32_t one = one_bits << (16 * (rel & 1));
+			val.x = (rel >> 1) == 0 ? one : 0u; val.y = (rel >> 1) == 1 ? one : 0u;
+			val.z = (rel >> 1) == 2 ? one : 0u; val.w = (rel >> 1) == 3 ? one : 0u;
+		}
+		dst[q] = val;
+	}
+}
+
+// Sharded mode: incoming child slots.  The receive buffer is `world` blocks of {32-byte header, K records of 32 B,
+// K shortcut offers of 16 B}; batch position c = src * K + pos keeps arrival order (grouped by sending rank, each group
+// in the sender's order) without compaction.  Record: {state[5], parent_idx, g | action<<16 | parent_rank<<24, pad}.
+__device__ __forceinline__ size_t shard_block_bytes(int K) { return 32 + (size_t)K * 48; }
+__device__ __forceinline__ const uint32_t *shard_hdr(const uint8_t *buf, int K, int peer)
+{
+	return reinterpret_cast<const uint32_t *>(buf + (size_t)peer * shard_block_bytes(K));
+}
+__device__ __forceinline__ const uint32_t *shard_rec(const uint8_t *buf, int K, int c)
+{
+	const int peer = c / K, pos = c - peer * K;
+	return reinterpret_cast<const uint32_t *>(buf + (size_t)peer * shard_block_bytes(K) + 32 + (size_t)pos * 32);
+}
+__device__ __forceinline__ bool shard_valid(const uint8_t *buf, int K, int c)
+{
+	const int peer = c / K, pos = c - peer * K;
+	return pos < (int)shard_hdr(buf, K, peer)[0];
+}
+
+__global__ __launch_bounds__(256)
+void k_shard_lookup(AstarDev d, const uint8_t *recv)
 {
 	const int c = blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= K) return;
-	constexpr int STRIDE = SHARDED ? 8 : 5;
-	const uint8_t f = flags[c];
-	const uint32_t *cs = children + (size_t)c * STRIDE;
-	int32_t p, g;
-	uint8_t act, pr = 0;
-	if (SHARDED) {
-		p = (int32_t)cs[5];
-		g = (int32_t)(cs[6] & 0xFFFFu);
-		act = (uint8_t)((cs[6] >> 16) & 0xFFu);
-		pr = (uint8_t)(cs[6] >> 24);
-	} else {
-		p = exp_idx[c / 12];
-		g = G[p] + 1;
-		act = (uint8_t)(c % 12);
-	}
-	if (f & 1) {
-		const uint32_t idx = n_before + 1u + (uint32_t)(rank[c] + block_off[c / SCAN_BLOCK]);
-		uint32_t s[5];
-		load5(cs, s);
-		#pragma unroll
-		for (int j = 0; j < 5; j++) states[(size_t)idx * 5 + j] = s[j];
-		G[idx] = g;
-		parents[idx] = p;
-		pact[idx] = act;
-		prank[idx] = pr;
-		table[child_slot[c]] = idx;
-		const bool is_goal = SHARDED ? is_solved5(s) : (solved[c] != 0);
-		if (is_goal) { counters[CTR_WON] = 1; counters[CTR_SOLVED_IDX] = idx; }
-	}
-	uint8_t nw = 0;
-	if (f & 2) {
-		nw = g < G[seen[c]];
-		val1[c] = g;
-	}
-	newway[c] = nw;
+	if (c >= d.KI || d.ctr[C_DONE] || !shard_valid(recv, d.K, c)) return;
+	uint32_t s[5];
+	load5(shard_rec(recv, d.K, c), s);
+	lookup_elect(d, s, c, [&](int c2, uint32_t o[5]) { load5(shard_rec(recv, d.K, c2), o); });
 }
 
-// cost = lambda * G + (-value), float64, no fused multiply-add                                      agents.py:380-383
-__global__ void k_astar_records(const float *values, int n_new, uint32_t n_before, const int32_t *G, double lambda, Rec *rec)
+// flags + order-preserving compaction (chained scan) + append + goal test + relaxation case 1 (read half) + one-hot.
+// SHARDED = false: child c belongs to popped node c/12, action c%12.   SHARDED = true: child slots of the receive buffer.
+template <bool SHARDED, int OH_BYTES>
+__global__ __launch_bounds__(SCAN_BLOCK)
+void k_append(AstarDev d, const uint8_t *recv, u32x4 *onehot, uint32_t one_bits)
 {
-	const int j = blockIdx.x * blockDim.x + threadIdx.x;
-	if (j >= n_new) return;
-	const uint32_t idx = n_before + 1u + (uint32_t)j;
-	const double h = (double)(-values[j]);
-	const double lg = lambda * (double)G[idx];
-	rec[j] = Rec{sortable_key(lg + h), (uint64_t)idx};
-}
-
-// bitonic sort of chunks of 1024 records in LDS
-__global__ __launch_bounds__(512)
-void k_sort_chunks(Rec *rec, int n)
-{
-	__shared__ Rec s[1024];
-	const int base = blockIdx.x * 1024, tid = threadIdx.x;
-	for (int i = tid; i < 1024; i += 512) s[i] = (base + i < n) ? rec[base + i] : Rec{~0ull, ~0ull};
-	__syncthreads();
-	for (int k = 2; k <= 1024; k <<= 1)
-		for (int j = k >> 1; j > 0; j >>= 1) {
-			const int i = 2 * tid - (tid & (j - 1));              // lower index of this thread's pair
-			const int l = i + j;
-			const bool up = (i & k) == 0;
-			const Rec a = s[i], b = s[l];
-			if (rec_less(b, a) == up) { s[i] = b; s[l] = a; }
-			__syncthreads();
+	__shared__ int s_wave[16];
+	__shared__ int s_ticket, s_base;
+	__shared__ uint32_t s_new[SCAN_BLOCK * 5];
+	const int b = scan_ticket(&d.ctr[C_TICKET0], &s_ticket);
+	const int K = SHARDED ? d.KI : 12 * d.ctr[C_NPOP];
+	const bool live = !d.ctr[C_DONE] || !SHARDED;                       // (single mode: K is 0 once done)
+	const int c = b * SCAN_BLOCK + threadIdx.x;
+	const bool valid = live && c < K && (!SHARDED || shard_valid(recv, d.K, c));
+	int fu = 0, fs = 0;
+	int32_t sidx = 0;
+	if (valid) {
+		sidx = d.seen[c];
+		if (sidx == 0) fu = __hip_atomic_load(&d.table[d.child_slot[c]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (TENT | (uint32_t)c);
+		else fs = __hip_atomic_load(&d.mark[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)c;
+	}
+	if (c < (SHARDED ? d.KI : d.K)) d.flags[c] = (uint8_t)(fu | (fs << 1));
+	int total;
+	const int r = block_rank(fu != 0, s_wave, &total);
+	const uint32_t epoch = (uint32_t)d.ctr[C_EPOCH] + 1u;
+	const int base = scan_chain(d.chain0, b, total, epoch, &s_base);
+	const uint32_t n_before = (uint32_t)d.ctr[C_NBEFORE];
+	if (b == (int)gridDim.x - 1 && threadIdx.x == 0) {                  // the last ticket holds the grand total
+		d.ctr[C_NNEW] = base + total;
+		d.ctr[C_NSTATES] = (int32_t)n_before + base + total;
+	}
+	if (valid) {
+		const uint32_t *cs = SHARDED ? shard_rec(recv, d.K, c) : d.children + (size_t)c * 5;
+		int32_t p, g;
+		uint8_t act, pr = (uint8_t)d.rank;
+		if (SHARDED) {
+			p = (int32_t)cs[5];
+			g = (int32_t)(cs[6] & 0xFFFFu);
+			act = (uint8_t)((cs[6] >> 16) & 0xFFu);
+			pr = (uint8_t)(cs[6] >> 24);
+		} else {
+			p = d.exp_idx[c / 12];
+			g = d.G[p] + 1;
+			act = (uint8_t)(c % 12);
 		}
-	for (int i = tid; i < 1024; i += 512)
-		if (base + i < n) rec[base + i] = s[i];
+		if (fu) {
+			const uint32_t idx = n_before + 1u + (uint32_t)(base + r);
+			uint32_t s[5];
+			load5(cs, s);
+			#pragma unroll
+			for (int j = 0; j < 5; j++) { d.states[(size_t)idx * 5 + j] = s[j]; s_new[r * 5 + j] = s[j]; }
+			d.G[idx] = g;
+			d.parents[idx] = p;
+			d.pact[idx] = act;
+			d.prank[idx] = pr;
+			d.table[d.child_slot[c]] = idx;
+			if (is_solved5(s)) { d.ctr[C_WON] = 1; d.ctr[C_SOLVED] = (int32_t)idx; }     // agents.py:321-323
+		}
+		uint8_t nw = 0;
+		if (fs) {
+			nw = g < d.G[sidx];                                         // agents.py:354
+			d.val1[c] = g;
+		}
+		d.newway[c] = nw;
+	}
+	if (onehot != nullptr) {
+		__syncthreads();
+		oh_rows_from_lds<OH_BYTES>(s_new, total, onehot, (size_t)base, one_bits);
+	}
 }
 
-// merge neighbouring sorted runs of length L (keys are distinct)
-__global__ void k_merge_pass(const Rec *src, Rec *dst, int n, int L)
+// cost = lambda * G + (-value), float64, no fused multiply-add (agents.py:380-383); bitonic sort of one chunk in LDS;
+// write half of relaxation case 1 (agents.py:357-359).  Padding records carry distinct maximal keys.
+template <bool SHARDED>
+__global__ __launch_bounds__(1024)
+void k_records_sort(AstarDev d, const float *values, const uint8_t *recv)
+{
+	__shared__ Rec s[SORT_CHUNK];
+	const int tid = threadIdx.x;
+	const int n_new = d.ctr[C_NNEW];
+	const uint32_t n_before = (uint32_t)d.ctr[C_NBEFORE];
+	const int base = blockIdx.x * SORT_CHUNK;
+	if (base < n_new) {                                                 // uniform for the workgroup
+		#pragma unroll
+		for (int h = 0; h < 2; h++) {
+			const int j = base + tid + h * 1024;
+			Rec x = Rec{~0ull, 0xFFFFFFFF00000000ull + (uint64_t)j};
+			if (j < n_new) {
+				const uint32_t idx = n_before + 1u + (uint32_t)j;
+				const double hv = (double)(-values[j]);
+				const double lg = d.lambda * (double)d.G[idx];
+				x = Rec{sortable_key(lg + hv), (uint64_t)idx};
+			}
+			s[tid + h * 1024] = x;
+		}
+		__syncthreads();
+		for (int k = 2; k <= SORT_CHUNK; k <<= 1)
+			for (int j = k >> 1; j > 0; j >>= 1) {
+				const int i = 2 * tid - (tid & (j - 1));
+				const int l = i + j;
+				const bool up = (i & k) == 0;
+				const Rec a = s[i], b2 = s[l];
+				if (rec_less(b2, a) == up) { s[i] = b2; s[l] = a; }
+				__syncthreads();
+			}
+		d.rec0[base + tid] = s[tid];
+		d.rec0[base + tid + 1024] = s[tid + 1024];
+	}
+	// relaxation case 1, write half: first-seen children that found a shorter way to an old node
+	if (d.ctr[C_WON]) return;                                           // the reference returns before relaxing (agents.py:321-323)
+	const int K = SHARDED ? d.KI : 12 * d.ctr[C_NPOP];
+	for (int c = blockIdx.x * 1024 + tid; c < K; c += gridDim.x * 1024) {
+		if (!(d.flags[c] & 2) || !d.newway[c]) continue;
+		const int32_t t = d.seen[c];
+		d.G[t] = d.val1[c];
+		if (SHARDED) {
+			const uint32_t *r = shard_rec(recv, d.K, c);
+			d.pact[t] = (uint8_t)((r[6] >> 16) & 0xFFu);
+			d.parents[t] = (int32_t)r[5];
+			d.prank[t] = (uint8_t)(r[6] >> 24);
+		} else {
+			d.pact[t] = (uint8_t)(c % 12);
+			d.parents[t] = d.exp_idx[c / 12];
+		}
+	}
+}
+
+// merge neighbouring sorted runs of length L over the padded new-record array (all records distinct)
+__global__ void k_merge_pass(AstarDev d, int L, int from)
 {
 	const int e = blockIdx.x * blockDim.x + threadIdx.x;
-	if (e >= n) return;
+	const int n_new = d.ctr[C_NNEW];
+	if (e >= d.Kpad || n_new <= SORT_CHUNK) return;                     // a single chunk is already sorted
+	const int used = ((n_new + SORT_CHUNK - 1) / SORT_CHUNK) * SORT_CHUNK;
+	const Rec *src = from ? d.rec1 : d.rec0;
+	Rec *dst = from ? d.rec0 : d.rec1;
+	if (e >= used) return;
 	const int r = e / L, i = e - r * L;
-	const int base = (r & ~1) * L;
-	const int pstart = (r ^ 1) * L;
-	int plen = n - pstart;
+	const int base = (r & ~1) * L, pstart = (r ^ 1) * L;
+	int plen = used - pstart;
 	plen = plen < 0 ? 0 : (plen > L ? L : plen);
 	const Rec x = src[e];
 	dst[base + i + lower_bound_rec(src + pstart, plen, x)] = x;
 }
 
-__global__ void k_merge_two(const Rec *a, int na, const Rec *b, int nb, Rec *out)
-{
-	const int e = blockIdx.x * blockDim.x + threadIdx.x;
-	if (e >= na + nb) return;
-	if (e < na) {
-		const Rec x = a[e];
-		out[e + lower_bound_rec(b, nb, x)] = x;
-	} else {
-		const Rec x = b[e - na];
-		out[(e - na) + lower_bound_rec(a, na, x)] = x;
-	}
-}
-
-// relaxation, case 1 write half (agents.py:357-359)
+// push (agents.py:316-317): multi-way rank merge of the sorted new records with queue levels 0..t into level t's
+// other buffer; read half of relaxation case 2 (agents.py:362), which also clears the marks this batch set.
 template <bool SHARDED>
-__global__ void k_relax_1b(int K, const uint8_t *newway, const int32_t *val1, const int32_t *seen, const int32_t *exp_idx,
-                           const uint32_t *recs, int32_t *G, int32_t *parents, uint8_t *pact, uint8_t *prank, const long long *counters)
+__global__ __launch_bounds__(256)
+void k_queue_insert(AstarDev d, int new_in_rec1)
 {
-	const int c = blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= K || !newway[c]) return;
-	if (SHARDED && counters[CTR_WON]) return;       // the reference returns before relaxing once it has won (agents.py:321-323)
-	const int32_t s = seen[c];
-	G[s] = val1[c];
-	if (SHARDED) {
-		const uint32_t *r = recs + (size_t)c * 8;
-		pact[s] = (uint8_t)((r[6] >> 16) & 0xFFu);
-		parents[s] = (int32_t)r[5];
-		prank[s] = (uint8_t)(r[6] >> 24);
-	} else {
-		pact[s] = (uint8_t)(c % 12);
-		parents[s] = exp_idx[c / 12];
+	__shared__ MergePlan s_plan;
+	if (threadIdx.x == 0) {
+		const int n_new = d.ctr[C_NNEW];
+		// with more than one chunk the merge passes ping-pong; a single chunk stays in rec0
+		make_plan(d.q, d.q.meta, (n_new > SORT_CHUNK && new_in_rec1) ? d.rec1 : d.rec0, n_new, s_plan);
+	}
+	__syncthreads();
+	const MergePlan &p = s_plan;
+	const int stride = gridDim.x * blockDim.x;
+	for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < p.total; e += stride) {
+		int r = 0, off = e;
+		while (off >= p.len[r]) { off -= p.len[r]; r++; }
+		const Rec x = p.run[r][off];
+		int pos = off;
+		for (int r2 = 0; r2 < p.n_runs; r2++)
+			if (r2 != r) pos += lower_bound_rec(p.run[r2], p.len[r2], x);
+		p.dst[pos] = x;
+	}
+	if (SHARDED) return;                                                // sharded: case 2 travels as offers (k_shard_offers)
+	const int K = 12 * d.ctr[C_NPOP];
+	const bool won = d.ctr[C_WON] != 0;
+	for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < K; c += stride) {
+		uint8_t sc = 0;
+		if (d.flags[c] & 2) {
+			const int32_t t = d.seen[c];
+			d.mark[t] = NO_MARK;
+			if (!won) {
+				const int32_t g = d.G[t] + 1;
+				sc = g < d.G[d.exp_idx[c / 12]];
+				d.val2[c] = g;
+			}
+		}
+		d.shortcut[c] = sc;
 	}
 }
 
-// case 2 read half (agents.py:362); also clears the marks this batch set
-__global__ void k_relax_2a(int K, const uint8_t *flags, const int32_t *seen, const int32_t *exp_idx, const int32_t *G,
-                           uint32_t *mark, uint8_t *shortcut, int32_t *val2)
+// End of an iteration, one workgroup: write half of relaxation case 2 (agents.py:365-367: one thread per expanded
+// parent walks its 12 children in order, so the last shortcut child in batch order wins, as NumPy's fancy assignment
+// with repeated indices does); queue bookkeeping; loop guard of the next iteration (agents.py:236); next pop list.
+template <bool SHARDED>
+__global__ __launch_bounds__(1024)
+void k_end(AstarDev d, int new_in_rec1, int count_iteration)
 {
-	const int c = blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= K) return;
-	uint8_t sc = 0;
-	if (flags[c] & 2) {
-		const int32_t s = seen[c];
-		const int32_t g = G[s] + 1;
-		sc = g < G[exp_idx[c / 12]];
-		val2[c] = g;
-		mark[s] = NO_MARK;
-	}
-	shortcut[c] = sc;
-}
-
-// case 2 write half (agents.py:365-367): one thread per expanded parent walks its 12 children in order, so the
-// last shortcut child in batch order wins, as NumPy's fancy assignment with repeated indices does
-__global__ void k_relax_2b(int n_pop, const uint8_t *shortcut, const int32_t *val2, const int32_t *seen, const int32_t *exp_idx,
-                           int32_t *G, int32_t *parents, uint8_t *pact)
-{
-	const int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n_pop) return;
-	const int32_t p = exp_idx[i];
-	for (int a = 0; a < 12; a++) {
-		const int c = 12 * i + a;
-		if (shortcut[c]) {
-			G[p] = val2[c];
-			pact[p] = (uint8_t)(a ^ 1);           // rev_action                                 cube.py:197-200
-			parents[p] = seen[c];
+	__shared__ int32_t s_meta[4 * QL];
+	__shared__ int s_ncand, s_nexp;
+	const int tid = threadIdx.x;
+	const int n_pop = d.ctr[C_NPOP];
+	if (!SHARDED && !d.ctr[C_WON]) {
+		for (int i = tid; i < n_pop; i += blockDim.x) {
+			const int32_t p = d.exp_idx[i];
+			for (int a = 0; a < 12; a++) {
+				const int c = 12 * i + a;
+				if (d.shortcut[c]) {
+					d.G[p] = d.val2[c];
+					d.pact[p] = (uint8_t)(a ^ 1);          // rev_action                                 cube.py:197-200
+					d.parents[p] = d.seen[c];
+				}
+			}
 		}
 	}
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------
-// Hash-sharded search (one engine per GPU, owner(state) = owner_of(state, world)).  Per iteration a rank expands its
-// share of the globally best nodes, buckets the 12 n children by owner (stable: batch order inside a bucket), the
-// host exchanges the buckets (all-to-all), and every owner inserts what it received with exactly the single-GPU
-// semantics above.  Relaxation case 2 (a seen child offers its parent a shortcut) becomes a second, small exchange
-// of 16-byte records back to the parent's owner.
-// ---------------------------------------------------------------------------------------------------------------
-__global__ void k_shard_records(const uint32_t *children, int K, const int32_t *exp_idx, const int32_t *G, uint32_t my_rank,
-                                uint32_t world, uint32_t *recs, uint8_t *owner)
-{
-	const int c = blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= K) return;
-	uint32_t s[5];
-	load5(children + (size_t)c * 5, s);
-	const int32_t p = exp_idx[c / 12];
-	uint32_t *r = recs + (size_t)c * 8;
-	#pragma unroll
-	for (int j = 0; j < 5; j++) r[j] = s[j];
-	r[5] = (uint32_t)p;
-	r[6] = ((uint32_t)(G[p] + 1) & 0xFFFFu) | ((uint32_t)(c % 12) << 16) | (my_rank << 24);
-	r[7] = (uint32_t)c;
-	owner[c] = (uint8_t)owner_of(s, world);
-}
-
-// Stable partition of the K records by owner into `send` (batch order inside every bucket), many workgroups:
-// (1) per-workgroup histogram over owners, laid out owner-major [w][block] so that ONE exclusive scan of the whole
-//     array yields, for every (owner, workgroup), the first output slot of that workgroup's records for that owner;
-// (2) k_scan_blocks; (3) scatter: rank among the same-owner records of the workgroup + that offset.
-__global__ __launch_bounds__(SCAN_BLOCK)
-void k_shard_hist(int K, uint32_t world, const uint8_t *owner, int32_t *hist /* [world][n_blocks] */, int n_blocks)
-{
-	__shared__ int s_cnt[256];
-	if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
+	if (tid == 0) {
+		const int n_new = d.ctr[C_NNEW];
+		MergePlan p;
+		make_plan(d.q, d.q.meta, (n_new > SORT_CHUNK && new_in_rec1) ? d.rec1 : d.rec0, n_new, p);
+		int open = 0;
+		for (int j = 0; j < d.q.levels; j++) {
+			int head = d.q.meta[Q_HEAD * QL + j] + d.q.meta[Q_TAKE * QL + j], len = d.q.meta[Q_LEN * QL + j], cur = d.q.meta[Q_CUR * QL + j];
+			if (j < p.t) { head = 0; len = 0; }
+			else if (j == p.t) { head = 0; len = p.total; cur ^= 1; }
+			if (head >= len) { head = 0; len = 0; }
+			s_meta[Q_HEAD * QL + j] = head; s_meta[Q_LEN * QL + j] = len; s_meta[Q_CUR * QL + j] = cur; s_meta[Q_TAKE * QL + j] = 0;
+			open += len - head;
+		}
+		for (int j = d.q.levels; j < QL; j++) { s_meta[Q_HEAD * QL + j] = 0; s_meta[Q_LEN * QL + j] = 0; s_meta[Q_CUR * QL + j] = 0; s_meta[Q_TAKE * QL + j] = 0; }
+		for (int i = 0; i < 4 * QL; i++) d.q.meta[i] = s_meta[i];
+		const bool ran = SHARDED ? d.ctr[C_DONE] == 0 : n_pop > 0;
+		if (ran && count_iteration) d.ctr[C_ITERS] += 1;
+		d.ctr[C_EPOCH] += 1;                                             // chained-scan words of this launch sequence expire
+		const int n_states = d.ctr[C_NSTATES];
+		d.ctr[C_NBEFORE] = n_states;
+		d.ctr[C_OPEN] = open;
+		d.ctr[C_NNEW] = 0;
+		d.ctr[C_NIN] = 0;
+		d.ctr[C_TICKET0] = 0; d.ctr[C_TICKET1] = 0; d.ctr[C_TICKET2] = 0;
+		const int n_exp = d.ctr[C_NEXP];
+		int done = d.ctr[C_DONE];
+		if (d.ctr[C_WON]) done = 1;
+		if (!SHARDED && (n_states + 12 * n_exp > d.ctr[C_BUDGET] || open == 0)) done = 1;      // loop guard, agents.py:236
+		d.ctr[C_DONE] = done;
+		const int n_cand = open < n_exp ? open : n_exp;
+		d.ctr[C_NCAND] = n_cand;
+		if (!SHARDED) d.ctr[C_NPOP] = done ? 0 : n_cand;
+		else d.ctr[C_NPOP] = 0;                                          // decided after the all-gather (k_shard_decide)
+		s_ncand = n_cand; s_nexp = n_exp;
+	}
 	__syncthreads();
-	const int c = blockIdx.x * SCAN_BLOCK + threadIdx.x;
-	if (c < K) atomicAdd(&s_cnt[owner[c]], 1);
+	pop_select(d, s_meta, s_ncand, s_nexp);
+	if (SHARDED) {
+		// this rank's contribution to the all-gather: pool size, win flag, solved index, error, then the candidate costs
+		__syncthreads();
+		double *g = d.gather_in;
+		if (tid == 0) {
+			g[0] = (double)d.ctr[C_NSTATES]; g[1] = (double)d.ctr[C_WON]; g[2] = (double)d.ctr[C_SOLVED]; g[3] = (double)d.ctr[C_ERROR];
+			g[4] = (double)s_ncand; g[6] = 0.0; g[7] = 0.0;              // g[5] = elapsed seconds, written by the host of rank 0
+		}
+		for (int i = tid; i < d.N; i += blockDim.x) g[8 + i] = i < s_ncand ? key_to_double(d.cand_key[i]) : INFINITY;
+	}
+}
+
+// standalone pop selection (only when the host changes the number of expansions between iterations)
+__global__ __launch_bounds__(1024)
+void k_pop_select_only(AstarDev d, int n_exp)
+{
+	__shared__ int32_t s_meta[4 * QL];
+	__shared__ int s_ncand;
+	for (int i = threadIdx.x; i < 4 * QL; i += blockDim.x) s_meta[i] = d.q.meta[i];
+	if (threadIdx.x == 0) {
+		const int open = d.ctr[C_OPEN];
+		const int n_cand = open < n_exp ? open : n_exp;
+		d.ctr[C_NEXP] = n_exp;
+		d.ctr[C_NCAND] = n_cand;
+		int done = d.ctr[C_WON] ? 1 : 0;
+		if (d.ctr[C_NSTATES] + 12 * n_exp > d.ctr[C_BUDGET] || open == 0) done = 1;
+		d.ctr[C_DONE] = done;
+		d.ctr[C_NPOP] = done ? 0 : n_cand;
+		s_ncand = n_cand;
+	}
 	__syncthreads();
-	if (threadIdx.x < world) hist[(size_t)threadIdx.x * n_blocks + blockIdx.x] = s_cnt[threadIdx.x];
+	pop_select(d, s_meta, s_ncand, n_exp);
 }
 
-__global__ __launch_bounds__(SCAN_BLOCK)
-void k_shard_scatter(int K, uint32_t world, const uint32_t *recs, const uint8_t *owner, const int32_t *offs /* scanned hist */,
-                     int n_blocks, u32x4 *send, long long *counts)
+__global__ void k_set_budget(AstarDev d, int budget)
 {
-	__shared__ int s_wave[16];
-	const int c = blockIdx.x * SCAN_BLOCK + threadIdx.x;
-	const uint32_t mine = c < K ? owner[c] : 0xFFFFFFFFu;
-	int dest = -1;
-	for (uint32_t w = 0; w < world; w++) {             // world <= 8 on a node; every round is one ballot per wave
-		int total;
-		const int r = block_rank(mine == w, s_wave, &total);
-		if (mine == w) dest = offs[(size_t)w * n_blocks + blockIdx.x] + r;
-	}
-	if (dest >= 0) {
-		const u32x4 *src = reinterpret_cast<const u32x4 *>(recs);
-		send[2 * (size_t)dest] = src[2 * (size_t)c];
-		send[2 * (size_t)dest + 1] = src[2 * (size_t)c + 1];
-	}
-	// per-owner totals: first slot of the next owner minus first slot of this one
-	if (blockIdx.x == 0 && threadIdx.x < world) {
-		const uint32_t w = threadIdx.x;
-		const long long start = offs[(size_t)w * n_blocks];
-		const long long end = w + 1 < world ? offs[(size_t)(w + 1) * n_blocks] : (long long)K;
-		counts[w] = end - start;
+	if (threadIdx.x != 0) return;
+	d.ctr[C_BUDGET] = budget;
+	if (d.world == 1 && !d.ctr[C_WON]) {
+		const int done = (d.ctr[C_NSTATES] + 12 * d.ctr[C_NEXP] > budget || d.ctr[C_OPEN] == 0) ? 1 : 0;
+		d.ctr[C_DONE] = done;
+		d.ctr[C_NPOP] = done ? 0 : d.ctr[C_NCAND];
 	}
 }
 
-// receiver side of relaxation case 2: a first-seen child whose own G is at least two below its would-be parent's
-// offers the parent a shortcut.  Offers keep receive order (= grouped by the rank that sent the child).
-// Shortcut record (16 B): {parent_idx, new G for the parent, index of the child on this rank, this rank | rev(action) << 8}
-__device__ __forceinline__ bool shortcut_offer(int c, int K, const uint8_t *flags, const int32_t *seen, const uint32_t *recs,
-                                               const int32_t *G, uint32_t my_rank, u32x4 *rec, uint32_t *dst)
+// action indices from the root to node `index` by walking parents on the device (agents.py:244-251)
+__global__ void k_astar_walk(AstarDev d, int index, int32_t *out /* [0] = length or -1, then actions root -> node */, int max_len)
 {
-	if (c >= K || !(flags[c] & 2)) return false;
-	const uint32_t *r = recs + (size_t)c * 8;
-	const int32_t s = seen[c];
-	const int32_t g_parent = (int32_t)(r[6] & 0xFFFFu) - 1;
-	const int32_t g_new = G[s] + 1;
-	*dst = r[6] >> 24;
-	*rec = u32x4{r[5], (uint32_t)g_new, (uint32_t)s, my_rank | ((((r[6] >> 16) & 0xFFu) ^ 1u) << 8)};
-	return g_new < g_parent;
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	int len = 0, i = index;
+	while (i != 1 && len <= (int)d.cap1) { i = d.parents[i]; len++; if (i < 1 || (uint32_t)i >= d.cap1) { out[0] = -1; return; } }
+	if (i != 1) { out[0] = -1; return; }
+	out[0] = len;
+	i = index;
+	for (int k = len - 1; k >= 0; k--) {
+		if (k < max_len) out[1 + k] = d.pact[i];
+		i = d.parents[i];
+	}
 }
 
-__global__ __launch_bounds__(SCAN_BLOCK)
-void k_shard_offers_count(int K, const uint8_t *flags, const int32_t *seen, const uint32_t *recs, const int32_t *G, uint32_t my_rank,
-                          uint32_t *mark, int32_t *rank, int32_t *block_sums, long long *counts)
-{
-	__shared__ int s_wave[16];
-	const int c = blockIdx.x * SCAN_BLOCK + threadIdx.x;
-	u32x4 rec;
-	uint32_t dst = 0;
-	const bool cand = shortcut_offer(c, K, flags, seen, recs, G, my_rank, &rec, &dst);
-	if (c < K && (flags[c] & 2)) mark[seen[c]] = NO_MARK;       // the marks this batch set are no longer needed
-	int total;
-	const int r = block_rank(cand, s_wave, &total);
-	if (c < K) rank[c] = cand ? r : -1;
-	if (cand) atomicAdd(reinterpret_cast<unsigned long long *>(&counts[dst]), 1ull);
-	if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
-}
-
-__global__ __launch_bounds__(SCAN_BLOCK)
-void k_shard_offers_write(int K, const uint8_t *flags, const int32_t *seen, const uint32_t *recs, const int32_t *G, uint32_t my_rank,
-                          const int32_t *rank, const int32_t *block_off, u32x4 *out)
-{
-	const int c = blockIdx.x * SCAN_BLOCK + threadIdx.x;
-	if (c >= K || rank[c] < 0) return;
-	u32x4 rec;
-	uint32_t dst;
-	shortcut_offer(c, K, flags, seen, recs, G, my_rank, &rec, &dst);
-	out[block_off[blockIdx.x] + rank[c]] = rec;
-}
-
-// parent side of case 2 (agents.py:362-367): evaluate every offer against G as it stands, then let the LAST hit per
-// parent (in arrival order) win -- what NumPy's fancy assignment with repeated indices does.
-__global__ void k_shard_shortcut_eval(const u32x4 *recs, int n, const int32_t *G, uint32_t *mark, uint8_t *hit)
-{
-	const int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	const u32x4 r = recs[i];
-	const bool h = (int32_t)r.y < G[r.x];
-	hit[i] = h;
-	if (h) atomicMin(&mark[r.x], ~(uint32_t)i);
-}
-
-__global__ void k_shard_shortcut_apply(const u32x4 *recs, int n, const uint8_t *hit, int32_t *G, int32_t *parents, uint8_t *pact,
-                                       uint8_t *prank, uint32_t *mark)
-{
-	const int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n || !hit[i]) return;
-	const u32x4 r = recs[i];
-	if (mark[r.x] != ~(uint32_t)i) return;
-	G[r.x] = (int32_t)r.y;
-	parents[r.x] = (int32_t)r.z;
-	prank[r.x] = (uint8_t)(r.w & 0xFFu);
-	pact[r.x] = (uint8_t)((r.w >> 8) & 0xFFu);
-}
-
-__global__ void k_shard_shortcut_clear(const u32x4 *recs, int n, uint32_t *mark)
-{
-	const int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n) mark[recs[i].x] = NO_MARK;
-}
-
-__global__ void k_astar_find(const uint32_t *query, const uint32_t *states, const uint32_t *table, uint32_t mask, long long *out)
+__global__ void k_astar_find(const uint32_t *query, const uint32_t *states, const uint32_t *table, uint32_t mask, int32_t *out)
 {
 	if (threadIdx.x != 0 || blockIdx.x != 0) return;
 	uint32_t s[5];
@@ -465,9 +614,213 @@ __global__ void k_astar_find(const uint32_t *query, const uint32_t *states, cons
 	for (;;) {
 		const uint32_t e = table[slot];
 		if (e == 0u) { *out = 0; return; }
-		if (!(e & TENT) && equal5(s, states + (size_t)e * 5)) { *out = e; return; }
+		if (!(e & TENT) && equal5(s, states + (size_t)e * 5)) { *out = (int32_t)e; return; }
 		slot = (slot + 1) & mask;
 	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Hash-sharded search.  Per iteration, every rank (all in lock-step, nothing below synchronises with the host):
+//   [all-gather]       (8 + N) doubles per rank, written by k_end: pool size, win flag, solved index, error, elapsed
+//                      time of rank 0, and the rank's N cheapest open costs in ascending order (+inf padded)
+//   k_shard_decide     identical on every rank: stop conditions (won, budget, capacity, time, error, nothing open) and
+//                      the global top-N by (cost, rank, position) -> how many of its own candidates this rank pops
+//   k_shard_expand     expand those, build the 32-byte child records, bucket them by owner into the send blocks with a
+//                      stable (batch-order) partition: per-owner chained scan across workgroups, all in ONE launch.
+//                      The send block of a peer also carries the shortcut offers of the PREVIOUS iteration.
+//   [all-to-all]       equal splits of one block per peer: {header, <= K records, <= K offers}; the counts travel in
+//                      the header, so there is no count exchange and no host involvement
+//   k_shard_offers_in  relaxation case 2 on the parents' owner: evaluate every received offer against G as it stands,
+//                      the LAST hit per parent in arrival order wins (NumPy's fancy assignment, agents.py:365-367)
+//   k_shard_lookup, k_append<true>, net, k_records_sort<true>, k_queue_insert<true>   as in the single-GPU engine
+//   k_shard_offers     a first-seen child whose own G is at least two below its would-be parent's offers the parent a
+//                      shortcut: 16-byte records bucketed by the parent's rank into the send blocks (next all-to-all)
+//   k_end<true>        queue bookkeeping, candidates of the next iteration, the all-gather contribution
+// Deferring the offers to the next all-to-all changes nothing: between the end of an iteration and the next insert
+// nobody reads the G of a node that was already expanded.  When a search ends without a win the host flushes the
+// pending offers with one more all-to-all so that the final arrays equal the reference's (world = 1).
+// ---------------------------------------------------------------------------------------------------------------
+enum { D_STOP = 0, D_WINNER_RANK, D_WINNER_IDX, D_TOTAL, D_NPOP, D_ITERS, D_NSTATES, D_COUNT = 8 };
+enum { STOP_NO = 0, STOP_WON = 1, STOP_BUDGET = 2, STOP_CAPACITY = 3, STOP_TIME = 4, STOP_EMPTY = 5, STOP_ERROR = 6 };
+
+__global__ __launch_bounds__(1024)
+void k_shard_decide(AstarDev d, const double *gathered, double time_limit, double max_states, long long *decision)
+{
+	__shared__ int s_mine, s_stop;
+	const int tid = threadIdx.x, W = d.world, N = d.N, stride = 8 + N;
+	if (tid == 0) {
+		s_mine = 0;
+		double total = 0, biggest = 0, any_err = 0;
+		int winner = -1, cands = 0;
+		for (int r = 0; r < W; r++) {
+			const double *g = gathered + (size_t)r * stride;
+			total += g[0];
+			biggest = g[0] > biggest ? g[0] : biggest;
+			if (winner < 0 && g[1] != 0.0) winner = r;
+			any_err += g[3];
+			cands += (int)g[4];
+		}
+		int stop = STOP_NO;
+		if (any_err != 0.0) stop = STOP_ERROR;
+		else if (winner >= 0) stop = STOP_WON;
+		else if (gathered[5] >= time_limit) stop = STOP_TIME;
+		else if (total + (double)(12 * N) * W > max_states) stop = STOP_BUDGET;                 // agents.py:236, collectively
+		else if (biggest + (double)(12 * N) * W > (double)(d.cap1 - 1)) stop = STOP_CAPACITY;   // a rank's pool could overflow
+		else if (cands == 0) stop = STOP_EMPTY;
+		s_stop = stop;
+		decision[D_STOP] = stop;
+		decision[D_WINNER_RANK] = winner;
+		decision[D_WINNER_IDX] = winner >= 0 ? (long long)gathered[(size_t)winner * stride + 2] : 0;
+		decision[D_TOTAL] = (long long)total;
+		decision[D_ITERS] = d.ctr[C_ITERS];
+		decision[D_NSTATES] = d.ctr[C_NSTATES];
+		if (stop != STOP_NO) d.ctr[C_DONE] = 1;
+	}
+	__syncthreads();
+	if (s_stop == STOP_NO) {
+		// my candidates' global ranks by (cost, rank, position); the n globally cheapest are popped
+		const double *mine = gathered + (size_t)d.rank * stride + 8;
+		const int n_mine = (int)gathered[(size_t)d.rank * stride + 4];
+		for (int i = tid; i < n_mine; i += blockDim.x) {
+			const double x = mine[i];
+			int grank = i;
+			for (int r = 0; r < W; r++) {
+				if (r == d.rank) continue;
+				const double *o = gathered + (size_t)r * stride + 8;
+				int lo = 0, hi = (int)gathered[(size_t)r * stride + 4];
+				while (lo < hi) {                                           // ranks below mine win ties, ranks above lose them
+					const int mid = (lo + hi) >> 1;
+					if (r < d.rank ? o[mid] <= x : o[mid] < x) lo = mid + 1; else hi = mid;
+				}
+				grank += lo;
+			}
+			if (grank < N) atomicAdd(&s_mine, 1);
+		}
+	}
+	__syncthreads();
+	if (tid == 0) {
+		d.ctr[C_NPOP] = s_stop == STOP_NO ? s_mine : 0;
+		decision[D_NPOP] = d.ctr[C_NPOP];
+	}
+}
+
+// expand this rank's share and bucket the child records by owner, stable, in one launch
+__global__ __launch_bounds__(SCAN_BLOCK)
+void k_shard_expand(AstarDev d, uint8_t *send)
+{
+	__shared__ u32x4 s_act[36];
+	__shared__ int s_wave[16];
+	__shared__ int s_ticket, s_base;
+	stage_action_tables(s_act, threadIdx.x);
+	const int b = scan_ticket(&d.ctr[C_TICKET1], &s_ticket);
+	const int n_pop = d.ctr[C_NPOP], K = 12 * n_pop;
+	const int c = b * SCAN_BLOCK + threadIdx.x;
+	const bool valid = c < K;
+	uint32_t s[5] = {0, 0, 0, 0, 0}, meta6 = 0, p = 0, owner = 0xFFFFFFFFu;
+	if (valid) {
+		const int i = c / 12, a = c - 12 * i;
+		if (a == 0) atomicAdd(&qmeta(d.q, Q_TAKE)[d.cand_level[i]], 1);
+		p = (uint32_t)d.exp_idx[i];
+		load5(d.states + (size_t)p * 5, s);
+		uint32_t tab[12];
+		load_action_table(s_act, (uint32_t)a, tab);
+		move5(s, tab);
+		meta6 = ((uint32_t)(d.G[p] + 1) & 0xFFFFu) | ((uint32_t)a << 16) | ((uint32_t)d.rank << 24);
+		owner = owner_of(s, (uint32_t)d.world);
+	}
+	const uint32_t epoch = (uint32_t)d.ctr[C_EPOCH] + 1u;
+	for (int w = 0; w < d.world; w++) {                                  // world <= 8 on a node: one ballot round per owner
+		int total;
+		const int r = block_rank(owner == (uint32_t)w, s_wave, &total);
+		const int base = scan_chain(d.chain1 + (size_t)w * gridDim.x, b, total, epoch, &s_base);
+		uint8_t *blk = send + (size_t)w * shard_block_bytes(d.K);
+		if (owner == (uint32_t)w) {
+			u32x4 *dst = reinterpret_cast<u32x4 *>(blk + 32 + (size_t)(base + r) * 32);
+			dst[0] = u32x4{s[0], s[1], s[2], s[3]};
+			dst[1] = u32x4{s[4], p, meta6, (uint32_t)c};
+		}
+		if (b == (int)gridDim.x - 1 && threadIdx.x == 0) reinterpret_cast<uint32_t *>(blk)[0] = (uint32_t)(base + total);
+		__syncthreads();                                                 // s_base is reused by the next owner
+	}
+}
+
+// Shortcut offer (16 B): {parent_idx, new G for the parent, index of the child on this rank, this rank | rev(action) << 8}
+__device__ __forceinline__ const u32x4 *shard_offer(const uint8_t *buf, int K, int o)
+{
+	const int peer = o / K, pos = o - peer * K;
+	return reinterpret_cast<const u32x4 *>(buf + (size_t)peer * shard_block_bytes(K) + 32 + (size_t)K * 32 + (size_t)pos * 16);
+}
+__device__ __forceinline__ bool shard_offer_valid(const uint8_t *buf, int K, int o)
+{
+	const int peer = o / K, pos = o - peer * K;
+	return pos < (int)shard_hdr(buf, K, peer)[1];
+}
+
+// phase 0: evaluate (read all of G first) and elect the last hit per parent; phase 1: apply; phase 2: clear the marks
+__global__ void k_shard_offers_in(AstarDev d, const uint8_t *recv, int phase)
+{
+	const int o = blockIdx.x * blockDim.x + threadIdx.x;
+	if (o >= d.KI || !shard_offer_valid(recv, d.K, o)) return;
+	const u32x4 r = *shard_offer(recv, d.K, o);
+	if (phase == 0) {
+		const bool h = (int32_t)r.y < d.G[r.x];
+		d.hit[o] = h;
+		if (h) atomicMin(&d.mark[r.x], ~(uint32_t)o);
+	} else if (phase == 1) {
+		if (!d.hit[o] || d.mark[r.x] != ~(uint32_t)o) return;
+		d.G[r.x] = (int32_t)r.y;
+		d.parents[r.x] = (int32_t)r.z;
+		d.prank[r.x] = (uint8_t)(r.w & 0xFFu);
+		d.pact[r.x] = (uint8_t)((r.w >> 8) & 0xFFu);
+	} else {
+		d.mark[r.x] = NO_MARK;
+	}
+}
+
+// receiver side of relaxation case 2: build the offers of this iteration's first-seen children, bucketed by the rank
+// that owns the parent (stable), into the offer areas of the send blocks; also clears the marks this batch set.
+__global__ __launch_bounds__(SCAN_BLOCK)
+void k_shard_offers(AstarDev d, const uint8_t *recv, uint8_t *send)
+{
+	__shared__ int s_wave[16];
+	__shared__ int s_ticket, s_base;
+	const int b = scan_ticket(&d.ctr[C_TICKET2], &s_ticket);
+	const int c = b * SCAN_BLOCK + threadIdx.x;
+	const bool live = !d.ctr[C_DONE] && !d.ctr[C_WON];
+	uint32_t dst_rank = 0xFFFFFFFFu;
+	u32x4 rec = {0u, 0u, 0u, 0u};
+	if (!d.ctr[C_DONE] && c < d.KI && shard_valid(recv, d.K, c) && (d.flags[c] & 2)) {
+		const uint32_t *r = shard_rec(recv, d.K, c);
+		const int32_t t = d.seen[c];
+		d.mark[t] = NO_MARK;
+		const int32_t g_parent = (int32_t)(r[6] & 0xFFFFu) - 1;
+		const int32_t g_new = d.G[t] + 1;
+		if (live && g_new < g_parent) {
+			dst_rank = r[6] >> 24;
+			rec = u32x4{r[5], (uint32_t)g_new, (uint32_t)t, (uint32_t)d.rank | ((((r[6] >> 16) & 0xFFu) ^ 1u) << 8)};
+		}
+	}
+	const uint32_t epoch = (uint32_t)d.ctr[C_EPOCH] + 1u;
+	for (int w = 0; w < d.world; w++) {
+		int total;
+		const int r = block_rank(dst_rank == (uint32_t)w, s_wave, &total);
+		const int base = scan_chain(d.chain2 + (size_t)w * gridDim.x, b, total, epoch, &s_base);
+		uint8_t *blk = send + (size_t)w * shard_block_bytes(d.K);
+		if (dst_rank == (uint32_t)w)
+			*reinterpret_cast<u32x4 *>(blk + 32 + (size_t)d.K * 32 + (size_t)(base + r) * 16) = rec;
+		if (b == (int)gridDim.x - 1 && threadIdx.x == 0) reinterpret_cast<uint32_t *>(blk)[1] = (uint32_t)(base + total);
+		__syncthreads();
+	}
+}
+
+// zero the counts of every send block (after a flush, or before the first iteration)
+__global__ void k_shard_clear_send(AstarDev d, uint8_t *send, int what)
+{
+	const int w = threadIdx.x;
+	if (w >= d.world) return;
+	uint32_t *h = reinterpret_cast<uint32_t *>(send + (size_t)w * shard_block_bytes(d.K));
+	if (what & 1) h[0] = 0;
+	if (what & 2) h[1] = 0;
 }
 
 }  // namespace rk
@@ -475,35 +828,15 @@ __global__ void k_astar_find(const uint32_t *query, const uint32_t *states, cons
 using namespace rk;
 
 struct rk_astar {
+	AstarDev d{};
 	size_t cap = 0;
 	int max_exp = 0;
-	uint32_t mask = 0;
-	double lambda = 0.0;
-	// node pool
-	uint32_t *states = nullptr; int32_t *G = nullptr, *parents = nullptr; uint8_t *pact = nullptr, *prank = nullptr;
-	uint32_t *table = nullptr, *mark = nullptr;
-	Rec *open[2] = {nullptr, nullptr};
-	int cur = 0;
-	// per-iteration scratch, K = 12 * max_exp
-	int32_t *exp_idx = nullptr; uint32_t *par_states = nullptr, *children = nullptr; uint8_t *solved = nullptr;
-	int32_t *seen = nullptr; uint32_t *child_slot = nullptr; uint8_t *flags = nullptr; int32_t *rank_ = nullptr;
-	uint8_t *newway = nullptr, *shortcut = nullptr; int32_t *val1 = nullptr, *val2 = nullptr;
-	Rec *newrec[2] = {nullptr, nullptr};
-	long long *counters = nullptr;
 	uint32_t *root_dev = nullptr;
-	// hash-sharded mode
-	int rank = 0, world = 1;
-	size_t k_in = 0;              // capacity (records) of the per-iteration scratch: 12 * max_exp * world
-	uint32_t *recs = nullptr; uint8_t *owner = nullptr, *hit = nullptr;
-	long long *dev_counts = nullptr;
-	int32_t *blk = nullptr;       // workgroup totals / offsets of the multi-workgroup compactions: (k_in/1024 + 2) * world
-	const uint32_t *pending_recs = nullptr;   // received records of the pending insert (caller memory)
-	int n_in = 0;
-	// host mirrors
-	size_t n_states = 0, open_len = 0;
-	size_t n_before = 0;          // n_states before the pending expand
-	int n_pop = 0, n_new = 0;
-	bool pending = false;         // expand done, commit not yet
+	int32_t *walk = nullptr;
+	long long *decision = nullptr;
+	int n_exp = 0;                // expansions of the pending / next iteration (host view)
+	bool ready = false, pending = false;
+	int pending_oh = 0;
 	std::vector<void *> allocs;
 };
 
@@ -513,13 +846,53 @@ template <typename T>
 int dev_alloc(rk_astar *h, T **p, size_t count)
 {
 	void *q = nullptr;
-	RK_HIP(hipMalloc(&q, count * sizeof(T) + 16));
+	RK_HIP(hipMalloc(&q, count * sizeof(T) + 64));
 	h->allocs.push_back(q);
 	*p = static_cast<T *>(q);
 	return RK_OK;
 }
 
 inline unsigned blocks(size_t n, unsigned per = 256) { return (unsigned)((n + per - 1) / per); }
+
+constexpr int WALK_MAX = 1 << 16;
+
+int read_ctr(rk_astar *h, int32_t *out, hipStream_t st)
+{
+	RK_HIP(hipMemcpyAsync(out, h->d.ctr, C_COUNT * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+	RK_HIP(hipStreamSynchronize(st));
+	return RK_OK;
+}
+
+template <bool SHARDED>
+void launch_append(rk_astar *h, const uint8_t *recv, void *d_onehot, int out_dtype, hipStream_t st)
+{
+	const AstarDev &d = h->d;
+	const unsigned nb = blocks(SHARDED ? (size_t)d.KI : (size_t)d.K, SCAN_BLOCK);
+	if (d_onehot != nullptr && out_dtype == RK_OH_F32)
+		hipLaunchKernelGGL((k_append<SHARDED, 4>), dim3(nb), dim3(SCAN_BLOCK), 0, st, d, recv, (u32x4 *)d_onehot, 0x3F800000u);
+	else
+		hipLaunchKernelGGL((k_append<SHARDED, 2>), dim3(nb), dim3(SCAN_BLOCK), 0, st, d, recv, (u32x4 *)d_onehot,
+		                   out_dtype == RK_OH_F16 ? 0x3C00u : 0x3F80u);
+}
+
+// records + sort + merge passes + queue insert + end of iteration; returns through the launches only
+template <bool SHARDED>
+int launch_commit(rk_astar *h, const float *d_values, const uint8_t *recv, hipStream_t st)
+{
+	const AstarDev &d = h->d;
+	const int n_chunks = d.Kpad / SORT_CHUNK;
+	hipLaunchKernelGGL((k_records_sort<SHARDED>), dim3(n_chunks), dim3(1024), 0, st, d, d_values, recv);
+	int from = 0;
+	for (int L = SORT_CHUNK; L < d.Kpad; L <<= 1) {
+		hipLaunchKernelGGL(k_merge_pass, dim3(blocks(d.Kpad)), dim3(256), 0, st, d, L, from);
+		from ^= 1;
+	}
+	// when the new records fit one chunk the passes are no-ops and the sorted run is in rec0
+	const unsigned grid = std::min<unsigned>(1024u, std::max<unsigned>(blocks((size_t)d.Kpad * 4), 8u));
+	hipLaunchKernelGGL((k_queue_insert<SHARDED>), dim3(grid), dim3(256), 0, st, d, from);
+	if (!SHARDED) hipLaunchKernelGGL((k_end<false>), dim3(1), dim3(1024), 0, st, d, from, 1);
+	return from;
+}
 
 }  // namespace
 
@@ -529,30 +902,56 @@ static int astar_create_impl(rk_astar_t **out, size_t capacity, int max_expansio
 {
 	if (!out) return fail(RK_EINVAL, "rk_astar_create: null out pointer");
 	if (capacity < 2 || capacity > 0x3FFFFFF0ull) return fail(RK_EINVAL, "rk_astar_create: capacity %zu out of range", capacity);
-	if (max_expansions < 1 || max_expansions > (1 << 24)) return fail(RK_EINVAL, "rk_astar_create: max_expansions %d out of range", max_expansions);
-	if (world < 1 || world > 255 || rank < 0 || rank >= world) return fail(RK_EINVAL, "rk_astar_create: rank %d / world %d out of range", rank, world);
+	if (max_expansions < 1 || max_expansions > (1 << 22)) return fail(RK_EINVAL, "rk_astar_create: max_expansions %d out of range", max_expansions);
+	if (world < 1 || world > 64 || rank < 0 || rank >= world) return fail(RK_EINVAL, "rk_astar_create: rank %d / world %d out of range", rank, world);
 	rk_astar *h = new rk_astar();
 	h->cap = capacity;
 	h->max_exp = max_expansions;
-	h->rank = rank;
-	h->world = world;
+	AstarDev &d = h->d;
+	d.rank = rank; d.world = world;
+	d.N = max_expansions; d.K = 12 * max_expansions;
+	d.KI = d.K * world;                                   // a rank can receive every rank's children
+	const int kin = world == 1 ? d.K : d.KI;
+	d.Kpad = ((kin + SORT_CHUNK - 1) / SORT_CHUNK) * SORT_CHUNK;
+	d.cap1 = (uint32_t)(capacity + 1);
 	uint64_t t = 1024;
 	while (t < 2 * (uint64_t)capacity + 2) t <<= 1;
-	h->mask = (uint32_t)(t - 1);
-	const size_t K = 12 * (size_t)max_expansions, C1 = capacity + 1;
-	const size_t KI = K * (size_t)world;          // a rank can receive every rank's children
-	h->k_in = KI;
+	d.mask = (uint32_t)(t - 1);
+	const size_t C1 = capacity + 1, KS = (size_t)kin + 64;
 	int e = RK_OK;
-	#define A(ptr, cnt) if (!e) e = dev_alloc(h, &h->ptr, (cnt))
+	#define A(ptr, cnt) if (!e) e = dev_alloc(h, &d.ptr, (cnt))
 	A(states, C1 * 5); A(G, C1); A(parents, C1); A(pact, C1); A(prank, C1); A(table, (size_t)t); A(mark, C1);
-	A(open[0], C1); A(open[1], C1);
-	A(exp_idx, (size_t)max_expansions); A(par_states, (size_t)max_expansions * 5); A(children, K * 5 + 64); A(solved, K + 64);
-	A(seen, KI); A(child_slot, KI); A(flags, KI); A(rank_, KI); A(newway, KI); A(shortcut, KI); A(val1, KI); A(val2, KI);
-	A(newrec[0], KI + 1024); A(newrec[1], KI + 1024);
-	A(counters, CTR_COUNT); A(root_dev, 8);
-	A(recs, K * 8 + 64); A(owner, K + 64); A(hit, KI + 64); A(dev_counts, 256);
-	A(blk, (KI / SCAN_BLOCK + 2) * (size_t)world + 64);
+	A(ctr, C_COUNT);
+	A(exp_idx, (size_t)d.N + 8); A(cand_key, (size_t)d.N + 8); A(cand_level, (size_t)d.N + 8);
+	A(children, (size_t)d.K * 5 + 64); A(solved, (size_t)d.K + 64);
+	A(seen, KS); A(child_slot, KS); A(flags, KS); A(rank_local, 16); A(newway, KS); A(shortcut, KS); A(val1, KS); A(val2, KS);
+	A(rec0, (size_t)d.Kpad + 16); A(rec1, (size_t)d.Kpad + 16);
+	const size_t n_scan_blocks = (KS + SCAN_BLOCK - 1) / SCAN_BLOCK + 1;
+	A(chain0, n_scan_blocks); A(chain1, n_scan_blocks * (size_t)world); A(chain2, n_scan_blocks * (size_t)world);
+	A(hit, KS); A(gather_in, (size_t)d.N + 16);
 	#undef A
+	// queue levels: 4 K, 16 K, 64 K, ... records, the top level holds the whole pool
+	if (!e) e = dev_alloc(h, &d.q.meta, 4 * QL);
+	uint64_t c = std::max<uint64_t>(4ull * (uint64_t)kin, 4096ull);
+	int levels = 0;
+	for (; levels < QL && !e; levels++) {
+		const bool top = c >= C1 || levels == QL - 1;
+		const uint64_t cap_l = top ? C1 : c;
+		d.q.cap[levels] = (uint32_t)cap_l;
+		for (int k = 0; k < 2 && !e; k++) e = dev_alloc(h, &d.q.buf[levels][k], (size_t)cap_l + 16);
+		if (top) { levels++; break; }
+		c *= 4;
+	}
+	d.q.levels = levels;
+	if (!e) e = dev_alloc(h, &h->root_dev, 8);
+	if (!e) e = dev_alloc(h, &h->walk, WALK_MAX + 8);
+	if (!e) e = dev_alloc(h, &h->decision, D_COUNT);
+	if (!e) {
+		hipError_t he = hipMemset(d.chain0, 0, n_scan_blocks * sizeof(unsigned long long));
+		if (he == hipSuccess) he = hipMemset(d.chain1, 0, n_scan_blocks * world * sizeof(unsigned long long));
+		if (he == hipSuccess) he = hipMemset(d.chain2, 0, n_scan_blocks * world * sizeof(unsigned long long));
+		if (he != hipSuccess) e = fail(RK_EHIP, "hipMemset failed: %s", hipGetErrorString(he));
+	}
 	if (e) { rk_astar_destroy(h); return e; }
 	*out = h;
 	return RK_OK;
@@ -576,109 +975,240 @@ int rk_astar_destroy(rk_astar_t *h)
 	return RK_OK;
 }
 
-int rk_astar_reset(rk_astar_t *h, const int8_t *h_start_state, double lambda, void *stream)
+static int astar_reset_impl(rk_astar_t *h, const int8_t *h_start_state, double lambda, int insert, hipStream_t st)
 {
-	if (!h || !h_start_state) return fail(RK_EINVAL, "rk_astar_reset: null argument");
-	hipStream_t st = (hipStream_t)stream;
-	h->lambda = lambda;
-	RK_HIP(hipMemsetAsync(h->table, 0, ((size_t)h->mask + 1) * sizeof(uint32_t), st));
-	RK_HIP(hipMemsetAsync(h->mark, 0xFF, (h->cap + 1) * sizeof(uint32_t), st));
-	RK_HIP(hipMemsetAsync(h->counters, 0, CTR_COUNT * sizeof(long long), st));
+	AstarDev &d = h->d;
+	d.lambda = lambda;
+	RK_HIP(hipMemsetAsync(d.table, 0, ((size_t)d.mask + 1) * sizeof(uint32_t), st));
+	RK_HIP(hipMemsetAsync(d.mark, 0xFF, (h->cap + 1) * sizeof(uint32_t), st));
+	// chained-scan epochs restart with the iteration counter: forget the words of the previous search
+	const size_t n_scan_blocks = ((size_t)(d.world == 1 ? d.K : d.KI) + 64 + SCAN_BLOCK - 1) / SCAN_BLOCK + 1;
+	RK_HIP(hipMemsetAsync(d.chain0, 0, n_scan_blocks * sizeof(unsigned long long), st));
+	RK_HIP(hipMemsetAsync(d.chain1, 0, n_scan_blocks * d.world * sizeof(unsigned long long), st));
+	RK_HIP(hipMemsetAsync(d.chain2, 0, n_scan_blocks * d.world * sizeof(unsigned long long), st));
 	RK_HIP(hipMemcpyAsync(h->root_dev, h_start_state, STATE_BYTES, hipMemcpyHostToDevice, st));
-	hipLaunchKernelGGL(k_astar_root, dim3(1), dim3(64), 0, st, h->states, h->G, h->parents, h->pact, h->table, h->mask, h->open[0], h->root_dev);
+	hipLaunchKernelGGL(k_astar_root, dim3(1), dim3(64), 0, st, d, h->root_dev, insert);
 	RK_HIP(hipGetLastError());
 	RK_HIP(hipStreamSynchronize(st));       // the host buffer may go away after return
-	h->cur = 0;
-	h->n_states = 1;
-	h->open_len = 1;
+	h->n_exp = d.N;
+	h->ready = true;
 	h->pending = false;
-	h->n_pop = h->n_new = 0;
 	return RK_OK;
 }
 
+int rk_astar_reset(rk_astar_t *h, const int8_t *h_start_state, double lambda, void *stream)
+{
+	if (!h || !h_start_state) return fail(RK_EINVAL, "rk_astar_reset: null argument");
+	return astar_reset_impl(h, h_start_state, lambda, 1, (hipStream_t)stream);
+}
+
+int rk_astar_set_budget(rk_astar_t *h, long long max_states, void *stream)
+{
+	if (!h || !h->ready) return fail(RK_ESTATE, "rk_astar_set_budget: reset the engine first");
+	if (h->pending) return fail(RK_ESTATE, "rk_astar_set_budget: an iteration is pending");
+	long long b = max_states < 0 ? 0 : max_states;
+	if (b > (long long)h->cap) b = (long long)h->cap;
+	hipLaunchKernelGGL(k_set_budget, dim3(1), dim3(64), 0, (hipStream_t)stream, h->d, (int)b);
+	RK_HIP(hipGetLastError());
+	return RK_OK;
+}
+
+int rk_astar_step_expand(rk_astar_t *h, void *d_onehot, int out_dtype, void *stream)
+{
+	if (!h || !h->ready) return fail(RK_ESTATE, "rk_astar_step_expand: reset the engine first");
+	if (h->d.world != 1) return fail(RK_ESTATE, "rk_astar_step_expand: sharded engines use rk_astar_shard_*");
+	if (h->pending) return fail(RK_ESTATE, "rk_astar_step_expand: previous iteration not committed");
+	if (d_onehot && (reinterpret_cast<uintptr_t>(d_onehot) & 15)) return fail(RK_EINVAL, "rk_astar_step_expand: one-hot buffer must be 16-byte aligned");
+	if (out_dtype < RK_OH_F32 || out_dtype > RK_OH_BF16) return fail(RK_EINVAL, "rk_astar_step_expand: unknown dtype %d", out_dtype);
+	hipStream_t st = (hipStream_t)stream;
+	const AstarDev &d = h->d;
+	hipLaunchKernelGGL(k_expand_lookup, dim3(blocks((size_t)12 * h->n_exp)), dim3(256), 0, st, d);
+	launch_append<false>(h, nullptr, d_onehot, out_dtype, st);
+	RK_HIP(hipGetLastError());
+	h->pending = true;
+	return RK_OK;
+}
+
+int rk_astar_step_commit(rk_astar_t *h, const float *d_values, void *stream)
+{
+	if (!h || !h->pending) return fail(RK_ESTATE, "rk_astar_step_commit: no pending iteration");
+	if (h->d.world != 1) return fail(RK_ESTATE, "rk_astar_step_commit: sharded engines use rk_astar_shard_push");
+	if (!d_values) return fail(RK_EINVAL, "rk_astar_step_commit: null values");
+	launch_commit<false>(h, d_values, nullptr, (hipStream_t)stream);
+	RK_HIP(hipGetLastError());
+	h->pending = false;
+	return RK_OK;
+}
+
+int rk_astar_status(rk_astar_t *h, long long *h_status, void *stream)
+{
+	if (!h || !h->ready || !h_status) return fail(RK_EINVAL, "rk_astar_status: bad argument");
+	int32_t c[C_COUNT];
+	if (int e = read_ctr(h, c, (hipStream_t)stream)) return e;
+	h_status[0] = c[C_DONE]; h_status[1] = c[C_WON]; h_status[2] = c[C_NSTATES]; h_status[3] = c[C_ITERS];
+	h_status[4] = c[C_OPEN]; h_status[5] = c[C_SOLVED]; h_status[6] = c[C_ERROR]; h_status[7] = c[C_NPOP];
+	return RK_OK;
+}
+
+/* The three-call form of one iteration (expand synchronises and reports the sizes; the host then feeds exactly the new
+ * states to the net).  Same kernels as rk_astar_step_*. */
 int rk_astar_expand(rk_astar_t *h, int n_expand, long long *h_info, void *stream)
 {
 	if (!h || !h_info) return fail(RK_EINVAL, "rk_astar_expand: null argument");
-	if (h->n_states == 0) return fail(RK_ESTATE, "rk_astar_expand: reset the engine first");
+	if (!h->ready) return fail(RK_ESTATE, "rk_astar_expand: reset the engine first");
+	if (h->d.world != 1) return fail(RK_ESTATE, "rk_astar_expand: sharded engines use rk_astar_shard_*");
 	if (h->pending) return fail(RK_ESTATE, "rk_astar_expand: previous expansion not committed");
 	if (n_expand < 1 || n_expand > h->max_exp) return fail(RK_EINVAL, "rk_astar_expand: n_expand %d outside 1..%d", n_expand, h->max_exp);
 	hipStream_t st = (hipStream_t)stream;
-	const int n_pop = (int)(h->open_len < (size_t)n_expand ? h->open_len : (size_t)n_expand);     // agents.py:238
-	const int K = 12 * n_pop;
-	if (h->n_states + (size_t)K > h->cap) return fail(RK_ECAPACITY, "rk_astar_expand: %zu states + %d children exceed capacity %zu", h->n_states, K, h->cap);
-	h->n_before = h->n_states;
-	h->n_pop = n_pop;
-	h->n_new = 0;
-	long long ctr[CTR_COUNT] = {0, 0, 0, 0};
-	if (n_pop > 0) {
-		RK_HIP(hipMemsetAsync(h->counters, 0, CTR_COUNT * sizeof(long long), st));
-		hipLaunchKernelGGL(k_astar_pop, dim3(blocks((size_t)n_pop * 5)), dim3(256), 0, st, h->open[h->cur], n_pop, h->states, h->exp_idx, h->par_states);
-		launch_expand12((const int8_t *)h->par_states, (int8_t *)h->children, h->solved, nullptr, (size_t)n_pop, st);
-		hipLaunchKernelGGL(k_astar_lookup, dim3(blocks(K)), dim3(256), 0, st, h->children, 5, K, h->states, h->table, h->mask, h->mark, h->seen, h->child_slot);
-		const int nb = (int)blocks(K, SCAN_BLOCK);
-		hipLaunchKernelGGL(k_astar_flags, dim3(nb), dim3(SCAN_BLOCK), 0, st, K, h->table, h->mark, h->seen, h->child_slot, h->flags, h->rank_, h->blk);
-		hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(SCAN_BLOCK), 0, st, h->blk, nb, h->counters + CTR_NEW);
-		hipLaunchKernelGGL(k_astar_append<false>, dim3(blocks(K)), dim3(256), 0, st, h->children, h->solved, K, h->flags, h->rank_, h->blk, h->seen, h->child_slot,
-		                   h->exp_idx, (uint32_t)h->n_before, h->states, h->G, h->parents, h->pact, h->prank, h->table, h->newway, h->val1, h->counters);
-		RK_HIP(hipGetLastError());
-		RK_HIP(hipMemcpyAsync(ctr, h->counters, sizeof ctr, hipMemcpyDeviceToHost, st));
-		RK_HIP(hipStreamSynchronize(st));
+	int32_t c[C_COUNT];
+	if (n_expand != h->n_exp) {
+		hipLaunchKernelGGL(k_pop_select_only, dim3(1), dim3(1024), 0, st, h->d, n_expand);
+		h->n_exp = n_expand;
 	}
-	h->n_new = (int)ctr[CTR_NEW];
-	h->n_states = h->n_before + (size_t)h->n_new;
-	h->pending = true;
-	h_info[0] = n_pop; h_info[1] = h->n_new; h_info[2] = ctr[CTR_WON]; h_info[3] = ctr[CTR_SOLVED_IDX]; h_info[4] = (long long)h->n_states;
+	if (int e = read_ctr(h, c, st)) return e;
+	if ((size_t)c[C_NSTATES] + 12 * (size_t)c[C_NCAND] > h->cap)
+		return fail(RK_ECAPACITY, "rk_astar_expand: %d states + %d children exceed capacity %zu", c[C_NSTATES], 12 * c[C_NCAND], h->cap);
+	if (int e = rk_astar_step_expand(h, nullptr, RK_OH_F32, stream)) return e;
+	const int n_pop = c[C_NPOP];
+	if (int e = read_ctr(h, c, st)) return e;
+	h_info[0] = n_pop; h_info[1] = c[C_NNEW]; h_info[2] = c[C_WON]; h_info[3] = c[C_SOLVED]; h_info[4] = c[C_NSTATES];
 	return RK_OK;
 }
 
 int rk_astar_new_states_oh(rk_astar_t *h, void *d_out, int out_dtype, void *stream)
 {
 	if (!h || !h->pending) return fail(RK_ESTATE, "rk_astar_new_states_oh: no pending expansion");
-	if (h->n_new == 0) return RK_OK;
-	return rk_as_oh(RK_REPR_2024, (const int8_t *)(h->states + (h->n_before + 1) * 5), d_out, out_dtype, (size_t)h->n_new, stream);
-}
-
-// cost of the pending new states, sort, merge into the open queue (agents.py:315-317); n_pop entries leave the head
-static int astar_push(rk_astar_t *h, const float *d_values, hipStream_t st)
-{
-	const int n_new = h->n_new, n_pop = h->n_pop;
-	Rec *sorted_new = h->newrec[0];
-	if (n_new > 0) {
-		hipLaunchKernelGGL(k_astar_records, dim3(blocks(n_new)), dim3(256), 0, st, d_values, n_new, (uint32_t)h->n_before, h->G, h->lambda, h->newrec[0]);
-		hipLaunchKernelGGL(k_sort_chunks, dim3(blocks(n_new, 1024)), dim3(512), 0, st, h->newrec[0], n_new);
-		int src = 0;
-		for (int L = 1024; L < n_new; L <<= 1) {
-			hipLaunchKernelGGL(k_merge_pass, dim3(blocks(n_new)), dim3(256), 0, st, h->newrec[src], h->newrec[src ^ 1], n_new, L);
-			src ^= 1;
-		}
-		sorted_new = h->newrec[src];
-	}
-	const int n_left = (int)(h->open_len - (size_t)n_pop);
-	if (n_left + n_new > 0)
-		hipLaunchKernelGGL(k_merge_two, dim3(blocks((size_t)n_left + n_new)), dim3(256), 0, st, h->open[h->cur] + n_pop, n_left, sorted_new, n_new, h->open[h->cur ^ 1]);
-	h->cur ^= 1;
-	h->open_len = (size_t)n_left + (size_t)n_new;
-	RK_HIP(hipGetLastError());
-	return RK_OK;
+	int32_t c[C_COUNT];
+	if (int e = read_ctr(h, c, (hipStream_t)stream)) return e;
+	if (c[C_NNEW] == 0) return RK_OK;
+	return rk_as_oh(RK_REPR_2024, (const int8_t *)(h->d.states + ((size_t)c[C_NBEFORE] + 1) * 5), d_out, out_dtype, (size_t)c[C_NNEW], stream);
 }
 
 int rk_astar_commit(rk_astar_t *h, const float *d_values, void *stream)
 {
 	if (!h || !h->pending) return fail(RK_ESTATE, "rk_astar_commit: no pending expansion");
-	if (h->world != 1) return fail(RK_ESTATE, "rk_astar_commit: sharded engines use rk_astar_shard_push");
-	if (h->n_new > 0 && !d_values) return fail(RK_EINVAL, "rk_astar_commit: null values");
+	if (h->d.world != 1) return fail(RK_ESTATE, "rk_astar_commit: sharded engines use rk_astar_shard_push");
+	if (!d_values) d_values = reinterpret_cast<const float *>(h->d.val1);       // no new states: never read
+	return rk_astar_step_commit(h, d_values, stream);
+}
+
+/* The pop list of the NEXT iteration (node indices in pop order): what heappop would return (agents.py:238-239). */
+long long rk_astar_next_pops(rk_astar_t *h, long long *h_indices, size_t max_len, void *stream)
+{
+	if (!h || !h->ready) return fail(RK_ESTATE, "rk_astar_next_pops: reset the engine first");
 	hipStream_t st = (hipStream_t)stream;
-	const int n_pop = h->n_pop, K = 12 * n_pop;
-	if (int e = astar_push(h, d_values, st)) return e;
-	if (K > 0) {
-		hipLaunchKernelGGL(k_relax_1b<false>, dim3(blocks(K)), dim3(256), 0, st, K, h->newway, h->val1, h->seen, h->exp_idx, (const uint32_t *)nullptr,
-		                   h->G, h->parents, h->pact, h->prank, h->counters);
-		hipLaunchKernelGGL(k_relax_2a, dim3(blocks(K)), dim3(256), 0, st, K, h->flags, h->seen, h->exp_idx, h->G, h->mark, h->shortcut, h->val2);
-		hipLaunchKernelGGL(k_relax_2b, dim3(blocks(n_pop)), dim3(256), 0, st, n_pop, h->shortcut, h->val2, h->seen, h->exp_idx, h->G, h->parents, h->pact);
+	int32_t c[C_COUNT];
+	if (int e = read_ctr(h, c, st)) return e;
+	const size_t n = std::min<size_t>((size_t)c[C_NPOP], max_len);
+	std::vector<int32_t> idx(n);
+	if (n) {
+		RK_HIP(hipMemcpyAsync(idx.data(), h->d.exp_idx, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+		RK_HIP(hipStreamSynchronize(st));
 	}
-	RK_HIP(hipGetLastError());
-	h->pending = false;
+	for (size_t i = 0; i < n; i++) h_indices[i] = idx[i];
+	return (long long)n;
+}
+
+long long rk_astar_size(const rk_astar_t *hc)
+{
+	rk_astar_t *h = const_cast<rk_astar_t *>(hc);
+	if (!h || !h->ready) return 0;
+	int32_t c[C_COUNT];
+	if (read_ctr(h, c, nullptr)) return RK_EHIP;
+	return c[C_NSTATES];
+}
+
+long long rk_astar_open_size(const rk_astar_t *hc)
+{
+	rk_astar_t *h = const_cast<rk_astar_t *>(hc);
+	if (!h || !h->ready) return 0;
+	int32_t c[C_COUNT];
+	if (read_ctr(h, c, nullptr)) return RK_EHIP;
+	return c[C_OPEN];
+}
+
+int rk_astar_export(rk_astar_t *h, size_t first, size_t count, int8_t *h_states, double *h_G, long long *h_parents,
+                    long long *h_parent_actions, void *stream)
+{
+	if (!h) return fail(RK_EINVAL, "rk_astar_export: null handle");
+	if (first + count > h->cap + 1) return fail(RK_EINVAL, "rk_astar_export: rows %zu..%zu outside the pool", first, first + count);
+	if (count == 0) return RK_OK;
+	hipStream_t st = (hipStream_t)stream;
+	const AstarDev &d = h->d;
+	std::vector<int32_t> g, p;
+	std::vector<uint8_t> a;
+	if (h_states) RK_HIP(hipMemcpyAsync(h_states, d.states + first * 5, count * STATE_BYTES, hipMemcpyDeviceToHost, st));
+	if (h_G) { g.resize(count); RK_HIP(hipMemcpyAsync(g.data(), d.G + first, count * sizeof(int32_t), hipMemcpyDeviceToHost, st)); }
+	if (h_parents) { p.resize(count); RK_HIP(hipMemcpyAsync(p.data(), d.parents + first, count * sizeof(int32_t), hipMemcpyDeviceToHost, st)); }
+	if (h_parent_actions) { a.resize(count); RK_HIP(hipMemcpyAsync(a.data(), d.pact + first, count, hipMemcpyDeviceToHost, st)); }
+	RK_HIP(hipStreamSynchronize(st));
+	for (size_t i = 0; i < count; i++) {
+		if (h_G) h_G[i] = (double)g[i];
+		if (h_parents) h_parents[i] = p[i];
+		if (h_parent_actions) h_parent_actions[i] = a[i];
+	}
 	return RK_OK;
+}
+
+long long rk_astar_path(rk_astar_t *h, long long index, long long *h_actions, size_t max_len, void *stream)
+{
+	if (!h || !h->ready) return fail(RK_EINVAL, "rk_astar_path: null handle");
+	if (index < 1 || (size_t)index > h->cap) return fail(RK_EINVAL, "rk_astar_path: index %lld outside 1..%zu", index, h->cap);
+	hipStream_t st = (hipStream_t)stream;
+	hipLaunchKernelGGL(k_astar_walk, dim3(1), dim3(64), 0, st, h->d, (int)index, h->walk, WALK_MAX);
+	RK_HIP(hipGetLastError());
+	int32_t len = 0;
+	RK_HIP(hipMemcpyAsync(&len, h->walk, sizeof len, hipMemcpyDeviceToHost, st));
+	RK_HIP(hipStreamSynchronize(st));
+	if (len < 0) return fail(RK_ESTATE, "rk_astar_path: broken parent chain");
+	const size_t n = std::min<size_t>(std::min<size_t>((size_t)len, max_len), (size_t)WALK_MAX);
+	std::vector<int32_t> acts(n);
+	if (n) {
+		RK_HIP(hipMemcpyAsync(acts.data(), h->walk + 1, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+		RK_HIP(hipStreamSynchronize(st));
+	}
+	for (size_t k = 0; k < n; k++) h_actions[k] = acts[k];
+	return (long long)len;
+}
+
+long long rk_astar_lookup(rk_astar_t *h, const int8_t *h_state, void *stream)
+{
+	if (!h || !h_state) return fail(RK_EINVAL, "rk_astar_lookup: null argument");
+	hipStream_t st = (hipStream_t)stream;
+	int32_t out = 0;
+	RK_HIP(hipMemcpyAsync(h->root_dev, h_state, STATE_BYTES, hipMemcpyHostToDevice, st));
+	hipLaunchKernelGGL(k_astar_find, dim3(1), dim3(64), 0, st, h->root_dev, h->d.states, h->d.table, h->d.mask, h->walk);
+	RK_HIP(hipGetLastError());
+	RK_HIP(hipMemcpyAsync(&out, h->walk, sizeof out, hipMemcpyDeviceToHost, st));
+	RK_HIP(hipStreamSynchronize(st));
+	return out;
+}
+
+/* The whole open queue in pop order (inspection only: gathers every level's live records and sorts them on the host). */
+long long rk_astar_export_open(rk_astar_t *h, double *h_costs, long long *h_indices, size_t max_len, void *stream)
+{
+	if (!h || !h->ready) return fail(RK_EINVAL, "rk_astar_export_open: null handle");
+	hipStream_t st = (hipStream_t)stream;
+	const QueueDev &q = h->d.q;
+	int32_t meta[4 * QL];
+	RK_HIP(hipMemcpyAsync(meta, q.meta, sizeof meta, hipMemcpyDeviceToHost, st));
+	RK_HIP(hipStreamSynchronize(st));
+	std::vector<Rec> all;
+	for (int j = 0; j < q.levels; j++) {
+		const int head = meta[Q_HEAD * QL + j] + meta[Q_TAKE * QL + j], len = meta[Q_LEN * QL + j];
+		if (len <= head) continue;
+		const size_t at = all.size();
+		all.resize(at + (size_t)(len - head));
+		RK_HIP(hipMemcpyAsync(all.data() + at, q.buf[j][meta[Q_CUR * QL + j]] + head, (size_t)(len - head) * sizeof(Rec), hipMemcpyDeviceToHost, st));
+	}
+	RK_HIP(hipStreamSynchronize(st));
+	std::sort(all.begin(), all.end(), [](const Rec &a, const Rec &b) { return a.key < b.key || (a.key == b.key && a.idx < b.idx); });
+	const size_t n = std::min(all.size(), max_len);
+	for (size_t i = 0; i < n; i++) {
+		if (h_costs) h_costs[i] = key_to_double(all[i].key);
+		if (h_indices) h_indices[i] = (long long)all[i].idx;
+	}
+	return (long long)n;
 }
 
 // ---- hash-sharded mode ---------------------------------------------------------------------------------------------
@@ -691,112 +1221,108 @@ int rk_shard_owner(const int8_t *h_state, int world)
 	return (int)owner_of(s, (uint32_t)world);
 }
 
-int rk_astar_shard_reset(rk_astar_t *h, const int8_t *h_start_state, double lambda, void *stream)
+long long rk_astar_shard_block_bytes(const rk_astar_t *h)
 {
-	if (!h || !h_start_state) return fail(RK_EINVAL, "rk_astar_shard_reset: null argument");
-	if (int e = rk_astar_reset(h, h_start_state, lambda, stream)) return e;
-	if (rk_shard_owner(h_start_state, h->world) != h->rank) {
-		// not the root's owner: start empty (the root record written by reset is dropped again)
-		hipStream_t st = (hipStream_t)stream;
-		RK_HIP(hipMemsetAsync(h->table, 0, ((size_t)h->mask + 1) * sizeof(uint32_t), st));
-		RK_HIP(hipStreamSynchronize(st));
-		h->n_states = 0;
-		h->open_len = 0;
-	}
-	h->pending = false;
-	return RK_OK;
+	return h ? (long long)(32 + (size_t)h->d.K * 48) : 0;
 }
 
-int rk_astar_shard_pop(rk_astar_t *h, int n_pop, void *d_send, long long *h_send_counts, void *stream)
+long long rk_astar_shard_gather_len(const rk_astar_t *h) { return h ? 8 + h->d.N : 0; }
+
+int rk_astar_shard_reset(rk_astar_t *h, const int8_t *h_start_state, double lambda, void *d_send, void *stream)
 {
-	if (!h || !h_send_counts) return fail(RK_EINVAL, "rk_astar_shard_pop: null argument");
-	if (h->pending) return fail(RK_ESTATE, "rk_astar_shard_pop: previous iteration not finished");
-	if (n_pop < 0 || n_pop > h->max_exp || (size_t)n_pop > h->open_len) return fail(RK_EINVAL, "rk_astar_shard_pop: n_pop %d out of range", n_pop);
+	if (!h || !h_start_state || !d_send) return fail(RK_EINVAL, "rk_astar_shard_reset: null argument");
 	hipStream_t st = (hipStream_t)stream;
-	for (int w = 0; w < h->world; w++) h_send_counts[w] = 0;
-	h->n_pop = n_pop;
-	const int K = 12 * n_pop;
-	if (K > 0) {
-		if (!d_send) return fail(RK_EINVAL, "rk_astar_shard_pop: null send buffer");
-		RK_HIP(hipMemsetAsync(h->dev_counts, 0, 256 * sizeof(long long), st));
-		hipLaunchKernelGGL(k_astar_pop, dim3(blocks((size_t)n_pop * 5)), dim3(256), 0, st, h->open[h->cur], n_pop, h->states, h->exp_idx, h->par_states);
-		launch_expand12((const int8_t *)h->par_states, (int8_t *)h->children, nullptr, nullptr, (size_t)n_pop, st);
-		hipLaunchKernelGGL(k_shard_records, dim3(blocks(K)), dim3(256), 0, st, h->children, K, h->exp_idx, h->G, (uint32_t)h->rank, (uint32_t)h->world, h->recs, h->owner);
-		const int nb = (int)blocks(K, SCAN_BLOCK);
-		hipLaunchKernelGGL(k_shard_hist, dim3(nb), dim3(SCAN_BLOCK), 0, st, K, (uint32_t)h->world, h->owner, h->blk, nb);
-		hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(SCAN_BLOCK), 0, st, h->blk, nb * h->world, (long long *)nullptr);
-		hipLaunchKernelGGL(k_shard_scatter, dim3(nb), dim3(SCAN_BLOCK), 0, st, K, (uint32_t)h->world, h->recs, h->owner, h->blk, nb, (u32x4 *)d_send, h->dev_counts);
-		RK_HIP(hipGetLastError());
-		RK_HIP(hipMemcpyAsync(h_send_counts, h->dev_counts, (size_t)h->world * sizeof(long long), hipMemcpyDeviceToHost, st));
-		RK_HIP(hipStreamSynchronize(st));
-	}
+	const int mine = rk_shard_owner(h_start_state, h->d.world) == h->d.rank;
+	if (int e = astar_reset_impl(h, h_start_state, lambda, mine, st)) return e;
+	hipLaunchKernelGGL(k_shard_clear_send, dim3(1), dim3(64), 0, st, h->d, (uint8_t *)d_send, 3);
+	// the first all-gather contribution: as k_end<true> would write it
+	hipLaunchKernelGGL((k_end<true>), dim3(1), dim3(1024), 0, st, h->d, 0, 0);
+	RK_HIP(hipGetLastError());
+	RK_HIP(hipStreamSynchronize(st));
 	return RK_OK;
 }
 
-int rk_astar_shard_insert(rk_astar_t *h, const void *d_recv, long long n_recv, void *d_shortcuts_out, long long *h_shortcut_counts,
-                          long long *h_info, void *stream)
+/* This rank's all-gather contribution (device pointer to 8 + N doubles; slot 5 = elapsed seconds, for the host of rank 0). */
+void *rk_astar_shard_gather_ptr(rk_astar_t *h) { return h ? h->d.gather_in : nullptr; }
+
+/* Let the engine write its all-gather contribution straight into caller memory (8 + N doubles, e.g. a torch tensor). */
+int rk_astar_shard_bind(rk_astar_t *h, void *d_gather)
 {
-	if (!h || !h_info || !h_shortcut_counts) return fail(RK_EINVAL, "rk_astar_shard_insert: null argument");
+	if (!h || !d_gather || (reinterpret_cast<uintptr_t>(d_gather) & 7)) return fail(RK_EINVAL, "rk_astar_shard_bind: bad argument");
+	h->d.gather_in = static_cast<double *>(d_gather);
+	return RK_OK;
+}
+
+int rk_astar_shard_select(rk_astar_t *h, const void *d_gathered, double time_limit, double max_states, void *d_send, void *stream)
+{
+	if (!h || !h->ready || !d_gathered || !d_send) return fail(RK_EINVAL, "rk_astar_shard_select: bad argument");
+	if (h->pending) return fail(RK_ESTATE, "rk_astar_shard_select: previous iteration not finished");
+	hipStream_t st = (hipStream_t)stream;
+	const AstarDev &d = h->d;
+	hipLaunchKernelGGL(k_shard_decide, dim3(1), dim3(1024), 0, st, d, (const double *)d_gathered, time_limit, max_states, h->decision);
+	hipLaunchKernelGGL(k_shard_expand, dim3(blocks((size_t)d.K, SCAN_BLOCK)), dim3(SCAN_BLOCK), 0, st, d, (uint8_t *)d_send);
+	RK_HIP(hipGetLastError());
+	return RK_OK;
+}
+
+/* h_out[8] = {stop reason, winner rank, winner index, total states, my pops, iterations, my states, 0}.  Synchronises. */
+int rk_astar_shard_decision(rk_astar_t *h, long long *h_out, void *stream)
+{
+	if (!h || !h_out) return fail(RK_EINVAL, "rk_astar_shard_decision: null argument");
+	hipStream_t st = (hipStream_t)stream;
+	RK_HIP(hipMemcpyAsync(h_out, h->decision, D_COUNT * sizeof(long long), hipMemcpyDeviceToHost, st));
+	RK_HIP(hipStreamSynchronize(st));
+	return RK_OK;
+}
+
+int rk_astar_shard_insert(rk_astar_t *h, const void *d_recv, void *d_send, void *d_onehot, int out_dtype, void *stream)
+{
+	if (!h || !h->ready || !d_recv || !d_send) return fail(RK_EINVAL, "rk_astar_shard_insert: null argument");
 	if (h->pending) return fail(RK_ESTATE, "rk_astar_shard_insert: previous iteration not finished");
-	if (n_recv < 0 || (size_t)n_recv > h->k_in) return fail(RK_ECAPACITY, "rk_astar_shard_insert: %lld records exceed the scratch capacity %zu", n_recv, h->k_in);
-	if (h->n_states + (size_t)n_recv > h->cap) return fail(RK_ECAPACITY, "rk_astar_shard_insert: %zu states + %lld records exceed capacity %zu", h->n_states, n_recv, h->cap);
+	if (d_onehot && (reinterpret_cast<uintptr_t>(d_onehot) & 15)) return fail(RK_EINVAL, "rk_astar_shard_insert: one-hot buffer must be 16-byte aligned");
 	hipStream_t st = (hipStream_t)stream;
-	const int K = (int)n_recv;
-	h->n_before = h->n_states;
-	h->n_in = K;
-	h->pending_recs = (const uint32_t *)d_recv;
-	long long ctr[CTR_COUNT] = {0, 0, 0, 0};
-	for (int w = 0; w < h->world; w++) h_shortcut_counts[w] = 0;
-	if (K > 0) {
-		if (!d_recv || !d_shortcuts_out) return fail(RK_EINVAL, "rk_astar_shard_insert: null buffer");
-		const uint32_t *recs = (const uint32_t *)d_recv;
-		RK_HIP(hipMemsetAsync(h->counters, 0, CTR_COUNT * sizeof(long long), st));
-		RK_HIP(hipMemsetAsync(h->dev_counts, 0, 256 * sizeof(long long), st));
-		hipLaunchKernelGGL(k_astar_lookup, dim3(blocks(K)), dim3(256), 0, st, recs, 8, K, h->states, h->table, h->mask, h->mark, h->seen, h->child_slot);
-		const int nb = (int)blocks(K, SCAN_BLOCK);
-		hipLaunchKernelGGL(k_astar_flags, dim3(nb), dim3(SCAN_BLOCK), 0, st, K, h->table, h->mark, h->seen, h->child_slot, h->flags, h->rank_, h->blk);
-		hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(SCAN_BLOCK), 0, st, h->blk, nb, h->counters + CTR_NEW);
-		hipLaunchKernelGGL(k_astar_append<true>, dim3(blocks(K)), dim3(256), 0, st, recs, (const uint8_t *)nullptr, K, h->flags, h->rank_, h->blk, h->seen, h->child_slot,
-		                   (const int32_t *)nullptr, (uint32_t)h->n_before, h->states, h->G, h->parents, h->pact, h->prank, h->table, h->newway, h->val1, h->counters);
-		hipLaunchKernelGGL(k_relax_1b<true>, dim3(blocks(K)), dim3(256), 0, st, K, h->newway, h->val1, h->seen, (const int32_t *)nullptr, recs,
-		                   h->G, h->parents, h->pact, h->prank, h->counters);
-		hipLaunchKernelGGL(k_shard_offers_count, dim3(nb), dim3(SCAN_BLOCK), 0, st, K, h->flags, h->seen, recs, h->G, (uint32_t)h->rank, h->mark,
-		                   h->rank_, h->blk, h->dev_counts);
-		hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(SCAN_BLOCK), 0, st, h->blk, nb, (long long *)nullptr);
-		hipLaunchKernelGGL(k_shard_offers_write, dim3(nb), dim3(SCAN_BLOCK), 0, st, K, h->flags, h->seen, recs, h->G, (uint32_t)h->rank, h->rank_, h->blk,
-		                   (u32x4 *)d_shortcuts_out);
-		RK_HIP(hipGetLastError());
-		RK_HIP(hipMemcpyAsync(ctr, h->counters, sizeof ctr, hipMemcpyDeviceToHost, st));
-		RK_HIP(hipMemcpyAsync(h_shortcut_counts, h->dev_counts, (size_t)h->world * sizeof(long long), hipMemcpyDeviceToHost, st));
-		RK_HIP(hipStreamSynchronize(st));
-	}
-	h->n_new = (int)ctr[CTR_NEW];
-	h->n_states = h->n_before + (size_t)h->n_new;
+	const AstarDev &d = h->d;
+	const uint8_t *recv = (const uint8_t *)d_recv;
+	const unsigned gK = blocks((size_t)d.KI);
+	for (int phase = 0; phase < 3; phase++)
+		hipLaunchKernelGGL(k_shard_offers_in, dim3(gK), dim3(256), 0, st, d, recv, phase);
+	hipLaunchKernelGGL(k_shard_lookup, dim3(gK), dim3(256), 0, st, d, recv);
+	launch_append<true>(h, recv, d_onehot, out_dtype, st);
+	RK_HIP(hipGetLastError());
 	h->pending = true;
-	h_info[0] = h->n_pop; h_info[1] = h->n_new; h_info[2] = ctr[CTR_WON]; h_info[3] = ctr[CTR_SOLVED_IDX]; h_info[4] = (long long)h->n_states;
 	return RK_OK;
 }
 
-int rk_astar_shard_push(rk_astar_t *h, const float *d_values, void *stream)
+int rk_astar_shard_push(rk_astar_t *h, const float *d_values, const void *d_recv, void *d_send, void *stream)
 {
 	if (!h || !h->pending) return fail(RK_ESTATE, "rk_astar_shard_push: no pending insert");
-	if (h->n_new > 0 && !d_values) return fail(RK_EINVAL, "rk_astar_shard_push: null values");
-	if (int e = astar_push(h, d_values, (hipStream_t)stream)) return e;
+	if (!d_values || !d_recv || !d_send) return fail(RK_EINVAL, "rk_astar_shard_push: null argument");
+	hipStream_t st = (hipStream_t)stream;
+	const AstarDev &d = h->d;
+	const int from = launch_commit<true>(h, d_values, (const uint8_t *)d_recv, st);
+	hipLaunchKernelGGL(k_shard_offers, dim3(blocks((size_t)d.KI, SCAN_BLOCK)), dim3(SCAN_BLOCK), 0, st, d, (const uint8_t *)d_recv, (uint8_t *)d_send);
+	hipLaunchKernelGGL((k_end<true>), dim3(1), dim3(1024), 0, st, d, from, 1);
+	RK_HIP(hipGetLastError());
 	h->pending = false;
-	h->n_pop = 0;
 	return RK_OK;
 }
 
-int rk_astar_shard_apply_shortcuts(rk_astar_t *h, const void *d_shortcuts, long long n, void *stream)
+/* After the search ended without a win: apply the offers that arrived with the last exchange (no records). */
+int rk_astar_shard_flush(rk_astar_t *h, const void *d_recv, void *stream)
 {
-	if (!h) return fail(RK_EINVAL, "rk_astar_shard_apply_shortcuts: null handle");
-	if (n == 0) return RK_OK;
-	if (n < 0 || (size_t)n > h->k_in || !d_shortcuts) return fail(RK_EINVAL, "rk_astar_shard_apply_shortcuts: bad record count %lld", n);
+	if (!h || !h->ready || !d_recv) return fail(RK_EINVAL, "rk_astar_shard_flush: bad argument");
 	hipStream_t st = (hipStream_t)stream;
-	const u32x4 *r = (const u32x4 *)d_shortcuts;
-	hipLaunchKernelGGL(k_shard_shortcut_eval, dim3(blocks((size_t)n)), dim3(256), 0, st, r, (int)n, h->G, h->mark, h->hit);
-	hipLaunchKernelGGL(k_shard_shortcut_apply, dim3(blocks((size_t)n)), dim3(256), 0, st, r, (int)n, h->hit, h->G, h->parents, h->pact, h->prank, h->mark);
-	hipLaunchKernelGGL(k_shard_shortcut_clear, dim3(blocks((size_t)n)), dim3(256), 0, st, r, (int)n, h->mark);
+	const unsigned gK = blocks((size_t)h->d.KI);
+	for (int phase = 0; phase < 3; phase++)
+		hipLaunchKernelGGL(k_shard_offers_in, dim3(gK), dim3(256), 0, st, h->d, (const uint8_t *)d_recv, phase);
+	RK_HIP(hipGetLastError());
+	return RK_OK;
+}
+
+int rk_astar_shard_clear_send(rk_astar_t *h, void *d_send, int records, int offers, void *stream)
+{
+	if (!h || !d_send) return fail(RK_EINVAL, "rk_astar_shard_clear_send: bad argument");
+	hipLaunchKernelGGL(k_shard_clear_send, dim3(1), dim3(64), 0, (hipStream_t)stream, h->d, (uint8_t *)d_send, (records ? 1 : 0) | (offers ? 2 : 0));
 	RK_HIP(hipGetLastError());
 	return RK_OK;
 }
@@ -805,95 +1331,16 @@ int rk_astar_shard_apply_shortcuts(rk_astar_t *h, const void *d_shortcuts, long 
 int rk_astar_shard_parent(rk_astar_t *h, long long index, long long *h_out /* [3] */, void *stream)
 {
 	if (!h || !h_out) return fail(RK_EINVAL, "rk_astar_shard_parent: null argument");
-	if (index < 1 || (size_t)index > h->n_states) return fail(RK_EINVAL, "rk_astar_shard_parent: index %lld outside 1..%zu", index, h->n_states);
+	if (index < 1 || (size_t)index > h->cap) return fail(RK_EINVAL, "rk_astar_shard_parent: index %lld outside 1..%zu", index, h->cap);
 	hipStream_t st = (hipStream_t)stream;
 	int32_t p = 0;
 	uint8_t a = 0, r = 0;
-	RK_HIP(hipMemcpyAsync(&p, h->parents + index, sizeof p, hipMemcpyDeviceToHost, st));
-	RK_HIP(hipMemcpyAsync(&a, h->pact + index, 1, hipMemcpyDeviceToHost, st));
-	RK_HIP(hipMemcpyAsync(&r, h->prank + index, 1, hipMemcpyDeviceToHost, st));
+	RK_HIP(hipMemcpyAsync(&p, h->d.parents + index, sizeof p, hipMemcpyDeviceToHost, st));
+	RK_HIP(hipMemcpyAsync(&a, h->d.pact + index, 1, hipMemcpyDeviceToHost, st));
+	RK_HIP(hipMemcpyAsync(&r, h->d.prank + index, 1, hipMemcpyDeviceToHost, st));
 	RK_HIP(hipStreamSynchronize(st));
 	h_out[0] = r; h_out[1] = p; h_out[2] = a;
 	return RK_OK;
-}
-
-long long rk_astar_size(const rk_astar_t *h) { return h ? (long long)h->n_states : 0; }
-
-long long rk_astar_open_size(const rk_astar_t *h) { return h ? (long long)h->open_len : 0; }
-
-int rk_astar_export(rk_astar_t *h, size_t first, size_t count, int8_t *h_states, double *h_G, long long *h_parents,
-                    long long *h_parent_actions, void *stream)
-{
-	if (!h) return fail(RK_EINVAL, "rk_astar_export: null handle");
-	if (first + count > h->cap + 1) return fail(RK_EINVAL, "rk_astar_export: rows %zu..%zu outside the pool", first, first + count);
-	if (count == 0) return RK_OK;
-	hipStream_t st = (hipStream_t)stream;
-	std::vector<int32_t> g, p;
-	std::vector<uint8_t> a;
-	if (h_states) RK_HIP(hipMemcpyAsync(h_states, h->states + first * 5, count * STATE_BYTES, hipMemcpyDeviceToHost, st));
-	if (h_G) { g.resize(count); RK_HIP(hipMemcpyAsync(g.data(), h->G + first, count * sizeof(int32_t), hipMemcpyDeviceToHost, st)); }
-	if (h_parents) { p.resize(count); RK_HIP(hipMemcpyAsync(p.data(), h->parents + first, count * sizeof(int32_t), hipMemcpyDeviceToHost, st)); }
-	if (h_parent_actions) { a.resize(count); RK_HIP(hipMemcpyAsync(a.data(), h->pact + first, count, hipMemcpyDeviceToHost, st)); }
-	RK_HIP(hipStreamSynchronize(st));
-	for (size_t i = 0; i < count; i++) {
-		if (h_G) h_G[i] = (double)g[i];
-		if (h_parents) h_parents[i] = p[i];
-		if (h_parent_actions) h_parent_actions[i] = a[i];
-	}
-	return RK_OK;
-}
-
-long long rk_astar_path(rk_astar_t *h, long long index, long long *h_actions, size_t max_len, void *stream)
-{
-	if (!h) return fail(RK_EINVAL, "rk_astar_path: null handle");
-	if (index < 1 || (size_t)index > h->n_states) return fail(RK_EINVAL, "rk_astar_path: index %lld outside 1..%zu", index, h->n_states);
-	hipStream_t st = (hipStream_t)stream;
-	const size_t n = h->n_states + 1;
-	std::vector<int32_t> p(n);
-	std::vector<uint8_t> a(n);
-	RK_HIP(hipMemcpyAsync(p.data(), h->parents, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-	RK_HIP(hipMemcpyAsync(a.data(), h->pact, n, hipMemcpyDeviceToHost, st));
-	RK_HIP(hipStreamSynchronize(st));
-	std::vector<long long> rev;
-	long long i = index;
-	while (i != 1) {                                    // agents.py:246-250
-		if (rev.size() > n) return fail(RK_ESTATE, "rk_astar_path: parent chain does not reach the root");
-		rev.push_back(a[(size_t)i]);
-		i = p[(size_t)i];
-		if (i < 1 || (size_t)i >= n) return fail(RK_ESTATE, "rk_astar_path: broken parent chain");
-	}
-	const size_t len = rev.size();
-	for (size_t k = 0; k < len && k < max_len; k++) h_actions[k] = rev[len - 1 - k];
-	return (long long)len;
-}
-
-long long rk_astar_lookup(rk_astar_t *h, const int8_t *h_state, void *stream)
-{
-	if (!h || !h_state) return fail(RK_EINVAL, "rk_astar_lookup: null argument");
-	hipStream_t st = (hipStream_t)stream;
-	long long out = 0;
-	RK_HIP(hipMemcpyAsync(h->root_dev, h_state, STATE_BYTES, hipMemcpyHostToDevice, st));
-	hipLaunchKernelGGL(k_astar_find, dim3(1), dim3(64), 0, st, h->root_dev, h->states, h->table, h->mask, h->counters + 3);
-	RK_HIP(hipGetLastError());
-	RK_HIP(hipMemcpyAsync(&out, h->counters + 3, sizeof out, hipMemcpyDeviceToHost, st));
-	RK_HIP(hipStreamSynchronize(st));
-	return out;
-}
-
-long long rk_astar_export_open(rk_astar_t *h, double *h_costs, long long *h_indices, size_t max_len, void *stream)
-{
-	if (!h) return fail(RK_EINVAL, "rk_astar_export_open: null handle");
-	hipStream_t st = (hipStream_t)stream;
-	const size_t n = h->open_len < max_len ? h->open_len : max_len;
-	if (n == 0) return 0;
-	std::vector<Rec> r(n);
-	RK_HIP(hipMemcpyAsync(r.data(), h->open[h->cur], n * sizeof(Rec), hipMemcpyDeviceToHost, st));
-	RK_HIP(hipStreamSynchronize(st));
-	for (size_t i = 0; i < n; i++) {
-		if (h_costs) h_costs[i] = key_to_double(r[i].key);
-		if (h_indices) h_indices[i] = (long long)r[i].idx;
-	}
-	return (long long)n;
 }
 
 }  // extern "C"

@@ -28,6 +28,7 @@ namespace rk {
 // ================================================================================================================
 constexpr int EXP_ROUND = 64;                  // parents per round (one per lane)
 constexpr int EXP_WAVES = 4;                   // waves per workgroup of the shipping shape
+constexpr int EXP_GRID_PERSISTENT = 3072;      // workgroups of the persistent (input-pipelined) launch
 
 template <int HALVES>
 struct ExpandWaveLdsT {
@@ -560,15 +561,10 @@ void k_rotate686(const uint16_t *__restrict__ states, const uint8_t *__restrict_
 	__shared__ __attribute__((aligned(16))) uint16_t s_in[GROUP * 144];
 	__shared__ __attribute__((aligned(16))) uint8_t s_near[FLAGS ? N_ACTIONS * S686_SLOTS : 16];
 	__shared__ __attribute__((aligned(16))) uint8_t s_col[FLAGS ? GROUP * S686_SLOTS : 16];
-	for (int i = threadIdx.x; i < N_ACTIONS * 144; i += 256) {
-		const int a = i / 144, u = i - a * 144, slot = u / 3;
-		s_src[i] = (uint8_t)(D_TAB.perm686[a][slot] * 3 + (u - slot * 3));
-	}
-	if (FLAGS)
-		for (int i = threadIdx.x; i < N_ACTIONS * S686_SLOTS; i += 256) {
-			const int a = i / S686_SLOTS, slot = i - a * S686_SLOTS;
-			s_near[i] = (uint8_t)(D_TAB.perm686[a ^ 1][slot] >> 3);
-		}
+	if (threadIdx.x < N_ACTIONS * 144 / 16)               // 1 728 B of source offsets: 108 16-byte loads from the constant segment
+		reinterpret_cast<u32x4 *>(s_src)[threadIdx.x] = reinterpret_cast<const u32x4 *>(&D_TAB.src686[0][0])[threadIdx.x];
+	if (FLAGS && threadIdx.x >= 128 && threadIdx.x < 128 + N_ACTIONS * S686_SLOTS / 16)
+		reinterpret_cast<u32x4 *>(s_near)[threadIdx.x - 128] = reinterpret_cast<const u32x4 *>(&D_TAB.near686[0][0])[threadIdx.x - 128];
 	const size_t n_groups = (n_in + GROUP - 1) / GROUP;
 	for (size_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
 		const size_t first = g * GROUP;
@@ -879,18 +875,17 @@ void launch_expand12_variant(int variant, const int8_t *parents, int8_t *childre
 
 #endif  // RK_TUNING
 
-// Shipping shape (benchmarks/tune_expand.py, profiles/r01_tune_expand.json): 64-parent wave tiles + non-temporal
-// stores stream at the same 6.1 TB/s whether or not the output buffer is reused; plain stores only win when the
-// 252 MB output is rewritten in place launch after launch (Infinity-Cache hits), and lose with 64-parent tiles.
+// Shipping shape (benchmarks/tune_expand.py; profiles/r01_tune_expand.json, profiles/r02_tune_expand.json): 64-parent wave
+// tiles + non-temporal stores.  Measured cache-neutral in round 2 (inputs AND outputs rotating over > 1 GB, so the parents
+// come from HBM): one tile per wave 50.0 us per 1 M parents -- a wave waits a full HBM latency for its only tile with
+// nothing else to do -- against 43.5-45.3 us for a persistent grid of 2 048-3 072 workgroups (3 072 ship) whose waves issue the NEXT tile's
+// parent loads before expanding the current one (PRELOAD).  Small batches (their input is cache-resident and there
+// are not enough tiles to pipeline) keep one tile per wave.
 void launch_expand12(const int8_t *parents, int8_t *children, uint8_t *solved, long long *stats, size_t n, hipStream_t st)
 {
 	const size_t n_tiles = (n + EXP_ROUND - 1) / EXP_ROUND;
-	// Up to ~8 M parents one tile per wave is fastest (the 20 B/parent input stays in the 256 MiB Infinity Cache between
-	// launches and the dispatcher keeps up).  Beyond that the input comes from HBM and a wave that only ever sees one tile
-	// waits a full memory latency for it: a persistent grid whose waves prefetch their next tile's parents while expanding
-	// the current one is 1.3x faster there (profiles/r01_tune_expand_shapes.json, 16 M parents: 1.12 ms -> 0.84 ms).
-	const bool persistent = n_tiles > (size_t)131072;
-	const unsigned grid = persistent ? 2048u : grid_for(n_tiles, EXP_WAVES, 1u << 20);
+	const bool persistent = n_tiles > (size_t)(2 * EXP_GRID_PERSISTENT * EXP_WAVES);
+	const unsigned grid = persistent ? (unsigned)EXP_GRID_PERSISTENT : grid_for(n_tiles, EXP_WAVES, 1u << 20);
 	#define RK_GO(FLAGS, PRE) hipLaunchKernelGGL((k_expand12<FLAGS, 1, true, EXP_WAVES, PRE>), dim3(grid), dim3(EXP_WAVES * WAVE), 0, st, \
 		(const uint32_t *)parents, (u32x4 *)children, (uint32_t *)(FLAGS ? solved : nullptr), FLAGS ? stats : (long long *)nullptr, n, n_tiles)
 	if (solved != nullptr) { if (persistent) RK_GO(true, true); else RK_GO(true, false); }

@@ -5,10 +5,13 @@
 // single coalesced row accesses, the 12-way reductions (sum of N, first arg-max of U+Q, max of the new values) are
 // 16-lane shuffles, and the loops over the visited path use all 64 lanes.
 //
-// Per-tree arrays in HBM (cap = capacity + 1 rows, row 0 unused, root = 1) mirror the reference's (agents.py:419-427):
-//   states int8 (cap,20) | neighbors int32 (cap,12) | leaves uint8 | P, W, L float64 (cap,12) | V float64 | N int32 (cap,12)
-// plus stamp int32 (cap,12) (simulation number of the last N increment: NumPy's `N[path, actions] += 1` counts a
-// repeated (node, action) pair once), a hash table state -> index, and the current path.
+// Per tree in HBM (cap = capacity + 1 rows, row 0 unused, root = 1): the reference's arrays (agents.py:419-427) packed
+// into ONE 512-byte, 512-byte-aligned record per node -- exactly four 128-byte lines, one page -- so that a level of
+// the descent (and a step of the backup) is one contiguous fetch instead of six arrays gigabytes apart:
+//   +0 expanded uint32 (leaves = !expanded) | +8 V float64 | +16 N int32[12] | +64 neighbors int32[12] |
+//   +112 P float64[12] | +208 W float64[12] | +304 L float64[12] | +400 stamp int32[12] | +448 unused
+// (stamp = simulation number of the last N increment: NumPy's `N[path, actions] += 1` counts a repeated (node, action)
+// pair once), plus states int8 (cap,20) kept dense, a hash table state -> index, and the current path.
 //
 // Statistics are float64 and this file is compiled without fused multiply-add so that U = c*P*sqrt(sum N)/(1+N),
 // Q = W - L and the arg-max reproduce NumPy's results bit for bit.
@@ -31,8 +34,8 @@ struct MctsDev {
 	uint32_t tmask;           // hash table size - 1 (per tree)
 	uint32_t max_path;
 	double c, nu;
-	uint32_t *states; int32_t *neighbors; uint8_t *leaves;
-	double *P, *V, *W, *L; int32_t *N, *stamp;
+	uint32_t *states;
+	uint8_t *nodes;           // 512-byte node records
 	uint32_t *table;
 	int32_t *path_nodes; uint8_t *path_actions;
 	int32_t *path_len, *n_states, *max_states, *sims, *solve_action, *solve_leaf, *error;
@@ -40,6 +43,26 @@ struct MctsDev {
 	// per-simulation hand-off between expand and backup
 	uint32_t *children; int32_t *child_idx; uint8_t *child_new;
 };
+
+constexpr int NODE_BYTES = 512;
+constexpr int OFF_EXPANDED = 0, OFF_V = 8, OFF_N = 16, OFF_NB = 64, OFF_P = 112, OFF_W = 208, OFF_L = 304, OFF_STAMP = 400;
+
+struct Node {
+	uint8_t *p;
+	__device__ __forceinline__ uint32_t &expanded() const { return *reinterpret_cast<uint32_t *>(p + OFF_EXPANDED); }
+	__device__ __forceinline__ double &V() const { return *reinterpret_cast<double *>(p + OFF_V); }
+	__device__ __forceinline__ int32_t *N() const { return reinterpret_cast<int32_t *>(p + OFF_N); }
+	__device__ __forceinline__ int32_t *nb() const { return reinterpret_cast<int32_t *>(p + OFF_NB); }
+	__device__ __forceinline__ double *P() const { return reinterpret_cast<double *>(p + OFF_P); }
+	__device__ __forceinline__ double *W() const { return reinterpret_cast<double *>(p + OFF_W); }
+	__device__ __forceinline__ double *L() const { return reinterpret_cast<double *>(p + OFF_L); }
+	__device__ __forceinline__ int32_t *stamp() const { return reinterpret_cast<int32_t *>(p + OFF_STAMP); }
+};
+
+__device__ __forceinline__ Node node_of(const MctsDev &d, size_t node0, int idx)
+{
+	return Node{d.nodes + (node0 + (size_t)idx) * NODE_BYTES};
+}
 
 __device__ __forceinline__ uint32_t mcts_hash(const uint32_t s[5])
 {
@@ -96,8 +119,9 @@ __global__ void k_mcts_set_root_pv(MctsDev d, const float *probs, const float *v
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= d.T * 12) return;
 	const int t = i / 12, k = i - 12 * t;
-	d.P[((size_t)t * d.cap1 + 1) * 12 + k] = (double)probs[i];          // agents.py:472
-	if (k == 0) d.V[(size_t)t * d.cap1 + 1] = (double)values[t];        // agents.py:473
+	const Node root = node_of(d, (size_t)t * d.cap1, 1);
+	root.P()[k] = (double)probs[i];                                     // agents.py:472
+	if (k == 0) root.V() = (double)values[t];                           // agents.py:473
 }
 
 __global__ void k_mcts_gather_roots(MctsDev d, uint32_t *out)
@@ -161,8 +185,8 @@ void k_mcts_expand(MctsDev d)
 		for (int j = 0; j < 5; j++) d.children[cbase * 5 + j] = s[j];
 		d.child_idx[cbase] = idx;
 		d.child_new[cbase] = is_new ? 1 : 0;
-		d.neighbors[(node0 + leaf) * 12 + lane] = idx;                     // agents.py:534
-		d.neighbors[(node0 + idx) * 12 + (lane ^ 1)] = leaf;               // agents.py:535
+		node_of(d, node0, leaf).nb()[lane] = idx;                          // agents.py:534
+		node_of(d, node0, idx).nb()[lane ^ 1] = leaf;                      // agents.py:535
 	}
 	const unsigned long long solvedmask = __ballot(active && is_solved5(s));   // agents.py:540-543: first solved child
 	if (solvedmask != 0ull && lane == __ffsll((long long)solvedmask) - 1) {
@@ -171,7 +195,7 @@ void k_mcts_expand(MctsDev d)
 		d.solve_leaf[t] = idx;
 	}
 	if (lane == 0) {
-		d.leaves[node0 + leaf] = 0;                                        // agents.py:536
+		node_of(d, node0, leaf).expanded() = 1u;                           // leaves[leaf] = False, agents.py:536
 		d.n_states[t] = n + __popcll(newmask);
 	}
 }
@@ -195,11 +219,12 @@ void k_mcts_backup_select(MctsDev d, const float *probs, const float *values)
 	const float vf = active ? values[cbase] : 0.0f;
 	const double v = (double)vf;
 	if (is_new) {
-		d.V[node0 + idx] = v;                                              // agents.py:557
+		const Node child = node_of(d, node0, idx);
+		child.V() = v;                                                     // agents.py:557
 		#pragma unroll
 		for (int k = 0; k < 12; k++) {
-			d.P[(node0 + idx) * 12 + k] = (double)probs[cbase * 12 + k];   // agents.py:556
-			d.W[(node0 + idx) * 12 + k] = v;                               // agents.py:561
+			child.P()[k] = (double)probs[cbase * 12 + k];                  // agents.py:556
+			child.W()[k] = v;                                              // agents.py:561
 		}
 	}
 	float bestf = is_new ? vf : -INFINITY;                                 // v.max() over the NEW children (:559)
@@ -208,16 +233,16 @@ void k_mcts_backup_select(MctsDev d, const float *probs, const float *values)
 	bestf = __shfl(bestf, 0, 64);
 	const bool has_new = __ballot(is_new) != 0ull;
 	const double best = (double)bestf;
-	if (active) d.W[(node0 + leaf) * 12 + lane] = is_new ? v : d.V[node0 + idx];     // agents.py:560
+	if (active) node_of(d, node0, leaf).W()[lane] = is_new ? v : node_of(d, node0, idx).V();     // agents.py:560
 
 	const int sim = d.sims[t] + 1;
 	for (int e = lane; e < plen - 1; e += 64) {
-		const int node = pnodes[e], act = pacts[e];
-		const size_t r = (node0 + node) * 12 + act;
-		if (has_new && best > d.W[r]) d.W[r] = best;                       // agents.py:562
-		if (atomicExch(&d.stamp[r], sim) != sim) d.N[r] += 1;              // agents.py:568 (a repeated pair counts once)
-		d.L[r] = 0.0;                                                      // agents.py:569
-		d.L[(node0 + pnodes[e + 1]) * 12 + (act ^ 1)] = 0.0;               // agents.py:570
+		const int act = pacts[e];
+		const Node nd = node_of(d, node0, pnodes[e]);
+		if (has_new && best > nd.W()[act]) nd.W()[act] = best;             // agents.py:562
+		if (atomicExch(&nd.stamp()[act], sim) != sim) nd.N()[act] += 1;    // agents.py:568 (a repeated pair counts once)
+		nd.L()[act] = 0.0;                                                 // agents.py:569
+		node_of(d, node0, pnodes[e + 1]).L()[act ^ 1] = 0.0;               // agents.py:570
 	}
 	if (lane == 0) d.sims[t] = sim;
 	if (d.solved[t]) {                                                     // agents.py:482-487
@@ -235,14 +260,15 @@ void k_mcts_backup_select(MctsDev d, const float *probs, const float *values)
 	// that column, so there is no second dependent round trip for the read-modify-write.
 	int cur = 1, len = 1, owed_lane = -1;
 	for (;;) {
-		const size_t r = (node0 + cur) * 12 + lane;
-		const uint8_t leaf = d.leaves[node0 + cur];
-		const int nA = active ? d.N[r] : 0;
-		const double pA = active ? d.P[r] : 0.0, wA = active ? d.W[r] : 0.0;
-		double lval = active ? d.L[r] : 0.0;
-		const int nb = active ? d.neighbors[r] : 0;
-		if (lane == owed_lane) { lval += d.nu; d.L[r] = lval; }            // agents.py:591
-		if (leaf) break;
+		const Node nd = node_of(d, node0, cur);                            // one 512-byte record: four adjacent lines
+		const int col = active ? lane : 0;
+		const uint32_t expanded = nd.expanded();
+		const int nA = active ? nd.N()[col] : 0;
+		const double pA = active ? nd.P()[col] : 0.0, wA = active ? nd.W()[col] : 0.0;
+		double lval = active ? nd.L()[col] : 0.0;
+		const int nb = active ? nd.nb()[col] : 0;
+		if (lane == owed_lane) { lval += d.nu; nd.L()[col] = lval; }       // agents.py:591
+		if (!expanded) break;
 		int sumN = nA;
 		#pragma unroll
 		for (int m = 8; m > 0; m >>= 1) sumN += __shfl_xor(sumN, m, 16);
@@ -265,7 +291,7 @@ void k_mcts_backup_select(MctsDev d, const float *probs, const float *values)
 		}
 		best_a = __shfl(best_a, 0, 64);
 		const int next = __shfl(nb, best_a, 64);
-		if (lane == best_a) d.L[r] = lval + d.nu;                          // agents.py:589
+		if (lane == best_a) nd.L()[col] = lval + d.nu;                         // agents.py:589
 		owed_lane = best_a ^ 1;
 		if (lane == 0) {
 			pacts[len - 1] = (uint8_t)best_a;
@@ -329,8 +355,7 @@ int rk_mcts_create(rk_mcts_t **out, int n_trees, size_t capacity_per_tree, size_
 	const size_t T = (size_t)n_trees, rows = T * d.cap1;
 	int e = RK_OK;
 	#define A(ptr, cnt) if (!e) e = mcts_alloc(h, &d.ptr, (cnt))
-	A(states, rows * 5); A(neighbors, rows * 12); A(leaves, rows);
-	A(P, rows * 12); A(V, rows); A(W, rows * 12); A(L, rows * 12); A(N, rows * 12); A(stamp, rows * 12);
+	A(states, rows * 5); A(nodes, (rows + 1) * NODE_BYTES);
 	A(table, T * (size_t)ts);
 	A(path_nodes, T * max_path); A(path_actions, T * max_path);
 	A(path_len, T); A(n_states, T); A(max_states, T); A(sims, T); A(solve_action, T); A(solve_leaf, T); A(error, T);
@@ -365,14 +390,8 @@ int rk_mcts_reset(rk_mcts_t *h, const int8_t *h_start_states, const long long *h
 		if (m > (long long)h->capacity) m = (long long)h->capacity;       // never index past the pool
 		ms[t] = (int32_t)(m < 0 ? 0 : m);
 	}
-	RK_HIP(hipMemsetAsync(d.neighbors, 0, rows * 12 * sizeof(int32_t), st));      // agents.py:441
-	RK_HIP(hipMemsetAsync(d.leaves, 1, rows, st));                                 // agents.py:442
-	RK_HIP(hipMemsetAsync(d.P, 0, rows * 12 * sizeof(double), st));
-	RK_HIP(hipMemsetAsync(d.V, 0, rows * sizeof(double), st));
-	RK_HIP(hipMemsetAsync(d.W, 0, rows * 12 * sizeof(double), st));               // agents.py:446
-	RK_HIP(hipMemsetAsync(d.L, 0, rows * 12 * sizeof(double), st));               // agents.py:447
-	RK_HIP(hipMemsetAsync(d.N, 0, rows * 12 * sizeof(int32_t), st));              // agents.py:445
-	RK_HIP(hipMemsetAsync(d.stamp, 0, rows * 12 * sizeof(int32_t), st));
+	// neighbors, P, V, N, W, L zero and every node a leaf (expanded = 0)                      agents.py:441-447
+	RK_HIP(hipMemsetAsync(d.nodes, 0, rows * NODE_BYTES, st));
 	RK_HIP(hipMemsetAsync(d.table, 0, T * ((size_t)d.tmask + 1) * sizeof(uint32_t), st));
 	RK_HIP(hipMemsetAsync(d.child_new, 0, T * 12, st));
 	RK_HIP(hipMemsetAsync(d.child_idx, 0, T * 12 * sizeof(int32_t), st));
@@ -459,19 +478,28 @@ int rk_mcts_export(rk_mcts_t *h, int tree, size_t first, size_t count, int8_t *h
 	if (count == 0) return RK_OK;
 	hipStream_t st = (hipStream_t)stream;
 	const size_t r0 = (size_t)tree * d.cap1 + first;
-	std::vector<int32_t> nb, nn;
 	if (h_states) RK_HIP(hipMemcpyAsync(h_states, d.states + r0 * 5, count * STATE_BYTES, hipMemcpyDeviceToHost, st));
-	if (h_leaves) RK_HIP(hipMemcpyAsync(h_leaves, d.leaves + r0, count, hipMemcpyDeviceToHost, st));
-	if (h_P) RK_HIP(hipMemcpyAsync(h_P, d.P + r0 * 12, count * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
-	if (h_V) RK_HIP(hipMemcpyAsync(h_V, d.V + r0, count * sizeof(double), hipMemcpyDeviceToHost, st));
-	if (h_W) RK_HIP(hipMemcpyAsync(h_W, d.W + r0 * 12, count * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
-	if (h_L) RK_HIP(hipMemcpyAsync(h_L, d.L + r0 * 12, count * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
-	if (h_neighbors) { nb.resize(count * 12); RK_HIP(hipMemcpyAsync(nb.data(), d.neighbors + r0 * 12, count * 12 * 4, hipMemcpyDeviceToHost, st)); }
-	if (h_N) { nn.resize(count * 12); RK_HIP(hipMemcpyAsync(nn.data(), d.N + r0 * 12, count * 12 * 4, hipMemcpyDeviceToHost, st)); }
+	std::vector<uint8_t> rec;
+	const bool want_nodes = h_neighbors || h_leaves || h_P || h_V || h_N || h_W || h_L;
+	if (want_nodes) {
+		rec.resize(count * NODE_BYTES);
+		RK_HIP(hipMemcpyAsync(rec.data(), d.nodes + r0 * NODE_BYTES, count * NODE_BYTES, hipMemcpyDeviceToHost, st));
+	}
 	RK_HIP(hipStreamSynchronize(st));
-	for (size_t i = 0; i < count * 12; i++) {
-		if (h_neighbors) h_neighbors[i] = nb[i];
-		if (h_N) h_N[i] = nn[i];
+	for (size_t i = 0; want_nodes && i < count; i++) {                 // unpack the records into the reference's arrays
+		const uint8_t *p = rec.data() + i * NODE_BYTES;
+		uint32_t expanded;
+		memcpy(&expanded, p + OFF_EXPANDED, 4);
+		if (h_leaves) h_leaves[i] = expanded ? 0 : 1;
+		if (h_V) memcpy(h_V + i, p + OFF_V, 8);
+		if (h_P) memcpy(h_P + i * 12, p + OFF_P, 96);
+		if (h_W) memcpy(h_W + i * 12, p + OFF_W, 96);
+		if (h_L) memcpy(h_L + i * 12, p + OFF_L, 96);
+		for (int k = 0; k < 12; k++) {
+			int32_t v;
+			if (h_neighbors) { memcpy(&v, p + OFF_NB + 4 * k, 4); h_neighbors[i * 12 + k] = v; }
+			if (h_N) { memcpy(&v, p + OFF_N + 4 * k, 4); h_N[i * 12 + k] = v; }
+		}
 	}
 	return RK_OK;
 }

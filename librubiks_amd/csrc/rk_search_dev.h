@@ -13,7 +13,6 @@ struct Rec { uint64_t key; uint64_t idx; };
 constexpr uint32_t TENT = 0x80000000u;          // hash slot holds a batch position, not yet an index
 constexpr uint32_t NO_MARK = 0xFFFFFFFFu;
 
-enum { CTR_NEW = 0, CTR_WON = 1, CTR_SOLVED_IDX = 2, CTR_COUNT = 4 };
 
 __device__ __forceinline__ bool rec_less(const Rec &a, const Rec &b)
 {
@@ -87,6 +86,41 @@ __device__ __forceinline__ int block_rank(bool pred, int *s_wave /* [16] */, int
 	}
 	*total = tot;
 	return before + in_wave;
+}
+
+// ---- order-preserving compaction across workgroups in ONE launch: chained scan with tickets --------------------------
+// Every workgroup draws a ticket (so that "predecessor" means "started earlier": no deadlock whatever the dispatch
+// order), computes its local total, waits for its predecessor's inclusive prefix and publishes its own.  A prefix word
+// is {epoch : 32 | value : 32} written with ONE 64-bit agent-scope store and polled with agent-scope loads; the epoch
+// makes words of earlier launches invisible, so nothing has to be cleared except the ticket counter (the engine's
+// end-of-iteration kernel does that).  The word carries its payload itself, so no fence is needed
+// (MI355X_MICROARCH.md: a naturally aligned 8-byte granule written by one store).
+__device__ __forceinline__ int scan_ticket(int32_t *ticket_ctr, int *s_ticket)
+{
+	if (threadIdx.x == 0) *s_ticket = atomicAdd(ticket_ctr, 1);
+	__syncthreads();
+	return *s_ticket;
+}
+
+// exclusive prefix of `total` over tickets 0..b-1; publishes the inclusive prefix of ticket b.  Call from ALL threads
+// of the workgroup (it contains barriers); s_base is one int of LDS.
+__device__ __forceinline__ int scan_chain(unsigned long long *words, int b, int total, uint32_t epoch, int *s_base)
+{
+	if (threadIdx.x == 0) {
+		int base = 0;
+		if (b > 0) {
+			unsigned long long w;
+			do {
+				w = __hip_atomic_load(&words[b - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if ((uint32_t)(w >> 32) != epoch) __builtin_amdgcn_s_sleep(1);
+			} while ((uint32_t)(w >> 32) != epoch);
+			base = (int)(uint32_t)w;
+		}
+		__hip_atomic_store(&words[b], ((unsigned long long)epoch << 32) | (uint32_t)(base + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		*s_base = base;
+	}
+	__syncthreads();
+	return *s_base;
 }
 
 __device__ __forceinline__ int lower_bound_rec(const Rec *a, int n, const Rec &x)

@@ -41,6 +41,11 @@ struct alignas(16) Tables {
 	uint8_t perm686[N_ACTIONS][S686_SLOTS];
 	int8_t  solved[STATE_BYTES + 12];   // padded to 32 bytes
 	int8_t  solved686[S686_BYTES];
+	// 6x8x6 gather tables, ready to be copied to LDS with 16-byte loads: a state is 144 ushorts (48 slots x 3);
+	// src686[a][u] = source ushort of output ushort u under action a = perm686[a][u/3]*3 + u%3
+	alignas(16) uint8_t src686[N_ACTIONS][144];
+	// near686[a][slot] = colour shown by `slot` in the state whose child `a` is solved (= move a^1 applied to solved)
+	alignas(16) uint8_t near686[N_ACTIONS][S686_SLOTS];
 };
 
 constexpr Tables make_tables()
@@ -84,6 +89,10 @@ constexpr Tables make_tables()
 				p[8 * NEIGHBOUR[f][k] + STRIP[k][s]] = (uint8_t)(8 * NEIGHBOUR[f][(k + 3) & 3] + STRIP[(k + 3) & 3][s]);
 		for (int s = 0; s < S686_SLOTS; s++) q[p[s]] = (uint8_t)s;
 		for (int pos = 0; pos < 8; pos++) t.solved686[(8 * f + pos) * 6 + f] = 1;
+	}
+	for (int a = 0; a < N_ACTIONS; a++) {
+		for (int u = 0; u < 144; u++) t.src686[a][u] = (uint8_t)(t.perm686[a][u / 3] * 3 + u % 3);
+		for (int slot = 0; slot < S686_SLOTS; slot++) t.near686[a][slot] = (uint8_t)(t.perm686[a ^ 1][slot] >> 3);
 	}
 	return t;
 }

@@ -65,6 +65,11 @@ class DeepAgent(Agent):
 		super().__init__()
 		self.net = net
 
+	@classmethod
+	def from_saved(cls, loc: str, use_best: bool, loader=None):
+		"""agents.py:72-76."""
+		return cls(_load_net(loc, use_best, loader))
+
 
 class RandomSearch(Agent):
 	"""Random walk (agents.py:82-89)."""
@@ -126,6 +131,10 @@ class PolicySearch(DeepAgent):
 		action = int(np.random.choice(cube.action_dim, p=policy)) if self.sample_policy else int(policy.argmax())
 		state = cube.rotate(state, *cube.action_space[action])
 		return action, state, cube.is_solved(state)
+
+	@classmethod
+	def from_saved(cls, loc: str, use_best: bool, sample_policy=False, loader=None):
+		return cls(_load_net(loc, use_best, loader), sample_policy)
 
 	def __str__(self):
 		return f"{'Sampled' if self.sample_policy else 'Greedy'} policy"
@@ -192,11 +201,27 @@ class EGVM(DeepAgent):
 		flat = visited.reshape(self.workers * self.depth, 20)
 		return paths, flat.cpu().numpy(), cube.device.as_oh(flat), (-1, -1)
 
+	@classmethod
+	def from_saved(cls, loc: str, use_best: bool, epsilon: float, workers: int, depth: int, loader=None):
+		return cls(_load_net(loc, use_best, loader), epsilon=epsilon, workers=workers, depth=depth)
+
 	def __str__(self):
 		return f"EGVM (e={self.epsilon}, w={self.workers}, d={self.depth})"
 
 
 _OH_CODES = {torch.float32: _ffi.OH_F32, torch.float16: _ffi.OH_F16, torch.bfloat16: _ffi.OH_BF16}
+
+
+def _load_net(loc: str, use_best: bool, loader=None):
+	"""The value/policy net of a saved model folder (reference: DeepAgent.from_saved, agents.py:72-75)."""
+	if loader is not None:
+		return loader(loc, use_best)
+	try:
+		from librubiks.model import Model          # the reference package, when installed beside this one
+	except ImportError as e:
+		raise ImportError("from_saved needs the reference's librubiks.model.Model (or pass loader=callable(loc, use_best) -> net); "
+		                  "librubiks_amd replaces the cube and search engines, not the network") from e
+	return Model.load(loc, load_best=use_best).to(gpu)
 
 
 def _oh_dtype(net) -> torch.dtype:
@@ -220,28 +245,42 @@ def _value_f32(out) -> torch.Tensor:
 	return out.detach().to(device=gpu, dtype=torch.float32).reshape(-1).contiguous()
 
 
+class CapacityExhausted(RuntimeWarning):
+	"""A search that was limited only by time stopped because its node pool was full (the reference grows its arrays)."""
+
+
 class AStar(DeepAgent):
 	"""
 	Batch weighted A* (agents.py:171-413): expands the `expansions` cheapest open nodes per iteration,
 	cost = lambda_ * G + (-value).  Same results as the reference (index numbering, G, parents, action_queue)
 	whenever the net returns the same values.
 
+	One iteration is `rk_astar_step_expand` -> net forward on the fixed (12 N, 480) one-hot batch -> `rk_astar_step_commit`:
+	five small launches around the net, no host synchronisation; the host polls the engine's status every `poll`
+	iterations (steps after the search ended are no-ops on the device).  `use_hipgraph=True` captures the iteration
+	once (the net must be capturable) and replays it.
+
 	`capacity` bounds the number of stored states when a search is limited only by time (the reference grows its
-	arrays without bound); with `max_states` given, exactly that budget is used.
+	arrays without bound): the pool doubles (a new engine, the search restarts from the root) until `max_capacity`;
+	a search that still fills the pool warns with `CapacityExhausted` and sets `self.capacity_exhausted`.
 	"""
 	default_capacity = 4_000_000
+	max_capacity = 64_000_000
 
-	def __init__(self, net, lambda_: float, expansions: int, capacity: int = None):
+	def __init__(self, net, lambda_: float, expansions: int, capacity: int = None, poll: int = 4, use_hipgraph: bool = False):
 		super().__init__(net)
 		self.lambda_ = lambda_
 		self.expansions = int(expansions)
 		self.capacity = capacity
+		self.poll = max(1, int(poll))
+		self.use_hipgraph = use_hipgraph
 		self._h = None
 		self._h_cap = 0
 		self._n = 0
 		self._root = None
 		self._cache = None
 		self.iterations = 0
+		self.capacity_exhausted = False
 		self.record_pops = False      # debugging aid: keep the popped indices of every iteration in self.pops
 		self.pops = []
 
@@ -274,7 +313,15 @@ class AStar(DeepAgent):
 		self._root = None
 		self.iterations = 0
 		self.pops = []
+		self.capacity_exhausted = False
 		return time_limit, max_states
+
+	def _iteration(self, h, oh, code):
+		lib = _ffi.lib()
+		_ffi.check(lib.rk_astar_step_expand(h, oh.data_ptr(), code, _ffi.stream_ptr()))
+		values = _value_f32(self.net(oh, policy=False, value=True))
+		self._keep = values                # the commit kernels read it after this call returns
+		_ffi.check(lib.rk_astar_step_commit(h, values.data_ptr(), _ffi.stream_ptr()))
 
 	@no_grad
 	def search(self, state: np.ndarray, time_limit: float = None, max_states: int = None) -> bool:
@@ -284,40 +331,67 @@ class AStar(DeepAgent):
 		state = np.ascontiguousarray(state, dtype=np.int8)
 		if cube.is_solved(state):
 			return True
-		cap = int(min(max_states, self.capacity or self.default_capacity))
-		cap = max(cap, 12 * self.expansions + 2)
-		h = self._engine(cap)
-		lib, st = _ffi.lib(), _ffi.stream_ptr()
-		_ffi.check(lib.rk_astar_reset(h, state.ctypes.data, float(self.lambda_), st))
-		self._root, self._n = state.copy(), 1
+		K = 12 * self.expansions
+		cap = max(int(min(max_states, self.capacity or self.default_capacity)), K + 2)
+		lib = _ffi.lib()
 		oh_dtype = _oh_dtype(self.net)
-		oh = torch.empty((12 * self.expansions, 480), dtype=oh_dtype, device=gpu)
-		info = (C.c_longlong * 5)()
-		budget = min(max_states, cap)
-		while time.perf_counter() - t0 < time_limit and self._n + self.expansions * cube.action_dim <= budget:
-			if lib.rk_astar_open_size(h) == 0:
-				break
-			if self.record_pops:
-				head = np.zeros(self.expansions, np.int64)
-				got = lib.rk_astar_export_open(h, None, head.ctypes.data, self.expansions, st)
-				self.pops.append(head[:got].copy())
-			_ffi.check(lib.rk_astar_expand(h, self.expansions, info, st))
-			n_new, won, solved_idx, self._n = int(info[1]), bool(info[2]), int(info[3]), int(info[4])
-			self.iterations += 1
-			if won:
-				path = (C.c_longlong * 4096)()
-				n = lib.rk_astar_path(h, solved_idx, path, 4096, st)
-				if n < 0:
-					_ffi.check(int(n))
-				self.action_queue = deque(int(a) for a in path[:n])
-				return True
-			values = None
-			if n_new:
-				_ffi.check(lib.rk_astar_new_states_oh(h, oh.data_ptr(), _OH_CODES[oh_dtype], st))
-				values = _value_f32(self.net(oh[:n_new], policy=False, value=True))
-				assert values.numel() == n_new
-			_ffi.check(lib.rk_astar_commit(h, values.data_ptr() if values is not None else None, _ffi.stream_ptr()))
-		return False
+		oh = torch.zeros((K, 480), dtype=oh_dtype, device=gpu)
+		code = _OH_CODES[oh_dtype]
+		status = (C.c_longlong * 8)()
+		while True:
+			h = self._engine(cap)
+			cap = self._h_cap
+			_ffi.check(lib.rk_astar_reset(h, state.ctypes.data, float(self.lambda_), _ffi.stream_ptr()))
+			_ffi.check(lib.rk_astar_set_budget(h, int(min(max_states, cap)), _ffi.stream_ptr()))
+			self._root, self._n, self._cache = state.copy(), 1, None
+			self.iterations, self.pops = 0, []
+			graph = None
+			if self.use_hipgraph and not self.record_pops:
+				side = torch.cuda.Stream()
+				side.wait_stream(torch.cuda.current_stream())
+				with torch.cuda.stream(side):
+					self._iteration(h, oh, code)                   # a real iteration; also warms the allocator
+				torch.cuda.current_stream().wait_stream(side)
+				graph = torch.cuda.CUDAGraph()
+				with torch.cuda.graph(graph):
+					self._iteration(h, oh, code)
+			poll = 1 if self.record_pops else self.poll
+			while True:
+				for _ in range(poll):
+					if self.record_pops:
+						head = np.zeros(self.expansions, np.int64)
+						got = lib.rk_astar_next_pops(h, head.ctypes.data, self.expansions, _ffi.stream_ptr())
+						if got > 0:
+							self.pops.append(head[:got].copy())
+					if graph is not None:
+						graph.replay()
+					else:
+						self._iteration(h, oh, code)
+				_ffi.check(lib.rk_astar_status(h, status, _ffi.stream_ptr()))
+				done, won, self._n, self.iterations, solved_idx, err = (int(status[i]) for i in (0, 1, 2, 3, 5, 6))
+				if err:
+					raise _ffi.RubiksHipError(f"A* engine error code {err}")
+				if won:
+					path = (C.c_longlong * 4096)()
+					n = lib.rk_astar_path(h, solved_idx, path, 4096, _ffi.stream_ptr())
+					if n < 0:
+						_ffi.check(int(n))
+					self.action_queue = deque(int(a) for a in path[:n])
+					return True
+				if done or time.perf_counter() - t0 >= time_limit:
+					break
+			# out of budget, out of time, or nothing left to expand
+			pool_full = done and self._n + K > cap and lib.rk_astar_open_size(h) > 0
+			if not (pool_full and max_states > cap and time.perf_counter() - t0 < time_limit):
+				return False
+			# the pool, not the caller's budget, ended the search: grow it like the reference's increase_stack_size
+			# (agents.py:396-402) -- here by restarting in an engine twice the size -- or say so
+			if cap >= self.max_capacity:
+				self.capacity_exhausted = True
+				import warnings
+				warnings.warn(f"{self}: node pool of {cap} states is full with time left; raise max_capacity", CapacityExhausted)
+				return False
+			cap = min(2 * cap, self.max_capacity)
 
 	# -- inspection (what the reference's tests look at: tests/test_agents.py:96-145) --------------------------
 	def _export(self):
@@ -378,8 +452,11 @@ class AStar(DeepAgent):
 		return self.lambda_ * self.G[indeces] + H
 
 	@classmethod
-	def from_saved(cls, loc: str, use_best: bool, lambda_: float, expansions: int):
-		raise NotImplementedError("model loading belongs to the reference's librubiks.model; pass a loaded net to AStar(...)")
+	def from_saved(cls, loc: str, use_best: bool, lambda_: float, expansions: int, loader=None):
+		"""agents.py:405-407.  The net itself is the reference's `librubiks.model.Model` (out of this package's scope):
+		it is loaded with `loader(loc, use_best)` if given, else with the reference's `Model.load` when that package is
+		importable next to this one (the drop-in situation)."""
+		return cls(_load_net(loc, use_best, loader), lambda_=lambda_, expansions=expansions)
 
 	def __len__(self) -> int:
 		return self._n
@@ -542,6 +619,7 @@ class MCTS(DeepAgent):
 	P, V, N, W, L, indices` for inspection (tests/test_agents.py:49-94).
 	"""
 	default_capacity = 200_000
+	max_capacity = 25_000_000           # 461 B per node: 11.5 GB
 
 	def __init__(self, net, c: float, search_graph: bool, capacity: int = None, use_hipgraph: bool = False):
 		super().__init__(net)
@@ -561,14 +639,29 @@ class MCTS(DeepAgent):
 
 	@no_grad
 	def search(self, state: np.ndarray, time_limit: float = None, max_states: int = None) -> bool:
+		t0 = time.perf_counter()
 		time_limit, max_states = self.reset(time_limit, max_states)
+		self.capacity_exhausted = False
 		cap = int(min(max_states, self.capacity or self.default_capacity))
-		if self._batch is None or self._batch.capacity != cap or self._batch.c != float(self.c):
-			self._batch = MCTSBatch(self.net, self.c, 1, capacity=cap, nu=self.nu)
-		self._batch.net = self.net
-		solved = bool(self._batch.search(np.asarray(state)[None], time_limit=time_limit, max_states=cap, poll=8,
-		                                 use_graph=self.use_hipgraph)[0])
-		self._n = int(self._batch.status[0, 2])
+		while True:
+			if self._batch is None or self._batch.capacity != cap or self._batch.c != float(self.c):
+				self._batch = MCTSBatch(self.net, self.c, 1, capacity=cap, nu=self.nu)
+			self._batch.net = self.net
+			left = time_limit - (time.perf_counter() - t0)
+			solved = bool(self._batch.search(np.asarray(state)[None], time_limit=max(left, 1e-3), max_states=cap, poll=8,
+			                                 use_graph=self.use_hipgraph)[0])
+			self._n = int(self._batch.status[0, 2])
+			# a search limited only by time that filled its pool: the reference grows its arrays (agents.py:496-503);
+			# here the tree restarts in a pool twice the size, or the caller is told
+			pool_full = not solved and self._n + 12 > cap and max_states > cap and time.perf_counter() - t0 < time_limit
+			if not pool_full:
+				break
+			if cap >= self.max_capacity:
+				self.capacity_exhausted = True
+				import warnings
+				warnings.warn(f"{self}: node pool of {cap} states is full with time left; raise max_capacity", CapacityExhausted)
+				break
+			cap = min(2 * cap, self.max_capacity)
 		self.action_queue = self._batch.action_queue_of(0)
 		if solved and self.search_graph and len(self.action_queue):
 			solve_leaf = self.index_of_solved()
@@ -639,6 +732,11 @@ class MCTS(DeepAgent):
 	def indices(self) -> dict:
 		st = self.states
 		return {st[i].tobytes(): i for i in range(1, self._n + 1)}
+
+	@classmethod
+	def from_saved(cls, loc: str, use_best: bool, c: float, search_graph: bool, loader=None):
+		"""agents.py:635-639."""
+		return cls(_load_net(loc, use_best, loader), c=c, search_graph=search_graph)
 
 	def __str__(self):
 		return ("BFS" if self.search_graph else "Naive") + f" MCTS (c={self.c})"

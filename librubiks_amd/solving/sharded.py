@@ -3,26 +3,33 @@ Hash-sharded batch weighted A* across the GPUs of one node (BASELINE config 5). 
 which is single-process; the per-rank semantics are those of `AStar` (reference: librubiks/solving/agents.py:171-413).
 
 One process per GPU.  Every rank owns the states whose `rk_shard_owner(state, world)` is its rank: its own node pool,
-hash table and sorted open queue (engine `rk_astar_*` in sharded mode).  One iteration, all ranks in lock-step:
+hash table and open queue (engine `rk_astar_*` in sharded mode).  One iteration, all ranks in lock-step, is TWO
+collectives on fixed-size device buffers and no host synchronisation (the host polls the stop decision every `poll`
+iterations; steps after the decision are no-ops on the device):
 
-  1. all-gather of the N cheapest open costs of every rank (+ pool sizes) -> every rank computes the same global
-     top-N by (cost, rank, position) and knows how many of its own head entries are in it;
-  2. `rk_astar_shard_pop`: expand those, bucket the 12 n children by owner as 32-byte records
-     {state, parent index, g, action, parent rank};
-  3. frontier exchange: counts, then records, `all_to_all_single` -- RCCL over xGMI with the "nccl" backend.  An
-     all-to-all sends a different slice to each peer, so all 7 xGMI links of a GPU carry traffic at once; at N = 700
-     a rank ships ~270 KB per iteration, i.e. the exchange is latency-, not bandwidth-bound (SURVEY.md section 5);
-  4. `rk_astar_shard_insert`: membership, first-occurrence de-duplication in arrival order, append, goal test,
-     relaxation case 1 on the owner;
-  5. value net on the new states of this rank, `rk_astar_shard_push` into the local open queue;
-  6. relaxation case 2 (a seen child offers its parent a shortcut): 16-byte offers travel back to the parent's owner
-     in a second, small all-to-all, `rk_astar_shard_apply_shortcuts`;
-  7. all-gather of {won, solved index}: the rank that inserted the solved state reports it; the action queue is
-     rebuilt by walking (rank, index) parent references with one small broadcast per hop.
+  1. all-gather of 8 + N doubles per rank, written by the engine at the end of the previous iteration: pool size, win
+     flag, solved index, error flag, elapsed time of rank 0, and the rank's N cheapest open costs;
+  2. `rk_astar_shard_select`: every rank derives the same stop decision (won / state budget / a rank's pool could
+     overflow / time / error / nothing open) and the same global top-N by (cost, rank, position), expands its share and
+     buckets the 12 n children by owner as 32-byte records {state, parent index, g, action, parent rank};
+  3. frontier exchange: ONE `all_to_all_single` with equal splits -- per peer a block of {header with the record and
+     offer counts, <= 12 N records, <= 12 N shortcut offers}.  RCCL over xGMI with the "nccl" backend: an all-to-all
+     sends a different block to each peer, so all 7 xGMI links of a GPU carry traffic at once.  The blocks are padded to
+     their upper bound (12 N * 48 B per peer: 0.4 MB at N = 700), which is what removes the count exchange and every
+     host round trip; at these sizes the exchange is latency-, not bandwidth-bound (SURVEY.md section 5);
+  4. `rk_astar_shard_insert`: first the shortcut offers that arrived (relaxation case 2 of the PREVIOUS iteration, on
+     the parents' owner), then membership, first-occurrence de-duplication in arrival order, append, goal test,
+     relaxation case 1, one-hot of the new states;
+  5. value net on the fixed (world * 12 N, 480) batch, `rk_astar_shard_push`: cost, push into the local queue, this
+     iteration's shortcut offers into the send blocks (they ride on the next all-to-all, so relaxation case 2 costs no
+     collective of its own), next candidates, next all-gather contribution.
 
-With `world == 1` (no process group needed) the result equals `AStar` bit for bit -- that is how the sharded code
-path is pinned to the reference on a single GPU.  With the "gloo" backend the buffers are staged through the host,
-which lets several ranks share one GPU in tests; with "nccl" they stay on the device.
+The action queue is rebuilt by walking (rank, index) parent references with one small broadcast per hop.
+
+With `world == 1` (no process group needed; the send buffer is the receive buffer) the result equals `AStar` bit for
+bit -- that is how the sharded code path is pinned to the reference on a single GPU.  With the "gloo" backend the
+buffers are staged through the host, which lets several ranks share one GPU in tests; with "nccl" they stay on the
+device.
 """
 from __future__ import annotations
 
@@ -37,8 +44,7 @@ import torch.distributed as dist
 from librubiks_amd import gpu, no_grad, _ffi, cube
 from librubiks_amd.solving.agents import DeepAgent, _value_f32, _oh_dtype, _OH_CODES
 
-REC_BYTES = 32          # child record
-OFFER_BYTES = 16        # shortcut offer
+STOP_REASONS = {0: "running", 1: "won", 2: "budget", 3: "capacity", 4: "time", 5: "nothing open", 6: "engine error"}
 
 
 class Transport:
@@ -52,59 +58,52 @@ class Transport:
 		self.backend = dist.get_backend(group) if self.active else "local"
 		self.on_device = self.backend == "nccl"
 		# world == 1 normally short-circuits every collective; `force_collectives` runs them anyway, which is how the
-		# nccl (RCCL) code path -- device tensors, variable-size all_to_all_single -- is exercised on a one-GPU box
+		# nccl (RCCL) code path -- device tensors, all_gather_into_tensor, all_to_all_single -- is exercised on a one-GPU box
 		self.shortcut = self.world == 1 and not (force_collectives and self.active)
+		self.collectives = 0
 
-	def _dev(self):
-		return gpu if self.on_device else torch.device("cpu")
-
-	def all_gather_vec(self, vec: np.ndarray) -> np.ndarray:
-		"""(world, len(vec)) array of every rank's float64 vector."""
+	def all_gather(self, mine: torch.Tensor) -> torch.Tensor:
+		"""(world, len(mine)) device tensor of every rank's vector."""
 		if self.shortcut:
-			return vec[None].copy()
-		mine = torch.from_numpy(np.ascontiguousarray(vec, dtype=np.float64)).to(self._dev())
+			return mine.view(1, -1)
+		self.collectives += 1
 		if self.on_device:
-			out = torch.empty((self.world, len(vec)), dtype=torch.float64, device=gpu)
+			out = torch.empty((self.world, mine.numel()), dtype=mine.dtype, device=mine.device)
 			dist.all_gather_into_tensor(out, mine, group=self.group)
-			return out.cpu().numpy()
-		parts = [torch.empty_like(mine) for _ in range(self.world)]
-		dist.all_gather(parts, mine, group=self.group)
-		return torch.stack(parts).numpy()
+			return out
+		host = mine.cpu()
+		parts = [torch.empty_like(host) for _ in range(self.world)]
+		dist.all_gather(parts, host, group=self.group)
+		return torch.stack(parts).to(mine.device)
 
-	def exchange_counts(self, send_counts: np.ndarray) -> np.ndarray:
+	def all_to_all(self, send: torch.Tensor, recv: torch.Tensor) -> torch.Tensor:
+		"""send, recv: (world, block) uint8 device tensors; row p of `send` goes to rank p, row q of `recv` comes from rank q."""
 		if self.shortcut:
-			return send_counts.copy()
-		s = torch.from_numpy(np.ascontiguousarray(send_counts, dtype=np.int64)).to(self._dev())
-		r = torch.empty_like(s)
-		dist.all_to_all_single(r, s, group=self.group)
-		return r.cpu().numpy()
-
-	def exchange_records(self, send: torch.Tensor, send_counts: np.ndarray, recv_counts: np.ndarray) -> torch.Tensor:
-		"""send: (n, width) uint8 on the GPU grouped by destination; returns (m, width) uint8 on the GPU grouped by source."""
-		if self.shortcut:
-			return send[:int(send_counts[0])]
-		width = send.shape[1]
-		n_out, n_in = int(send_counts.sum()), int(recv_counts.sum())
-		src = send[:n_out]
-		if not self.on_device:
-			src = src.cpu()
-		dst = torch.empty((n_in, width), dtype=torch.uint8, device=src.device)
-		dist.all_to_all_single(dst, src.contiguous(), [int(x) for x in recv_counts], [int(x) for x in send_counts], group=self.group)
-		return dst if self.on_device else dst.to(gpu)
+			return send
+		self.collectives += 1
+		if self.on_device:
+			dist.all_to_all_single(recv, send, group=self.group)
+			return recv
+		src = send.cpu()
+		dst = torch.empty_like(src)
+		dist.all_to_all_single(dst, src, group=self.group)
+		recv.copy_(dst)
+		return recv
 
 	def broadcast_vec(self, vec: np.ndarray, src: int) -> np.ndarray:
 		if self.shortcut:
 			return vec
-		t = torch.from_numpy(np.ascontiguousarray(vec, dtype=np.int64)).to(self._dev())
+		t = torch.from_numpy(np.ascontiguousarray(vec, dtype=np.int64)).to(gpu if self.on_device else "cpu")
 		dist.broadcast(t, src=dist.get_global_rank(self.group, src) if self.group is not None else src, group=self.group)
 		return t.cpu().numpy()
 
 
 def select_pops(heads: np.ndarray, n: int) -> np.ndarray:
 	"""
-	heads: (world, n) float64, row r = the n cheapest open costs of rank r in ascending order, padded with +inf.
+	Host statement of the selection rule the device kernel `k_shard_decide` implements (used by the tests as its spec):
+	heads is (world, n) float64, row r = the n cheapest open costs of rank r in ascending order, padded with +inf.
 	Returns how many head entries each rank pops so that together they are the n globally cheapest by
-	(cost, rank, position).  Deterministic and identical on every rank.
+	(cost, rank, position).
 	"""
 	world = heads.shape[0]
 	cost = heads.ravel()
@@ -119,13 +118,18 @@ def select_pops(heads: np.ndarray, n: int) -> np.ndarray:
 class ShardedAStar(DeepAgent):
 	"""Collective agent: every rank constructs it and calls `search` with the same arguments."""
 
-	def __init__(self, net, lambda_: float, expansions: int, capacity: int = 2_000_000, group=None, force_collectives: bool = False):
+	def __init__(self, net, lambda_: float, expansions: int, capacity: int = 2_000_000, group=None, force_collectives: bool = False,
+	             poll: int = 1, profile: bool = False):
 		super().__init__(net)
 		self.lambda_, self.expansions, self.capacity = lambda_, int(expansions), int(capacity)
 		self.tp = Transport(group, force_collectives)
+		self.poll = max(1, int(poll))
+		self.profile = profile                 # record device-time per phase (HIP events); read `self.phase_ms` afterwards
+		self.phase_ms = {}
 		self._h = None
 		self.iterations = 0
 		self.total_states = 0
+		self.stop_reason = "running"
 		self._n = 0
 
 	def _engine(self):
@@ -148,72 +152,79 @@ class ShardedAStar(DeepAgent):
 		_ffi.require_gpu()
 		t0 = time.perf_counter()
 		time_limit, max_states = self.reset(time_limit, max_states)
-		self.iterations = 0
+		self.iterations, self.stop_reason = 0, "running"
 		state = np.ascontiguousarray(state, dtype=np.int8)
 		if cube.is_solved(state):
+			self.stop_reason = "won"
 			return True
 		lib, tp, N = _ffi.lib(), self.tp, self.expansions
 		h = self._engine()
 		st = _ffi.stream_ptr
-		_ffi.check(lib.rk_astar_shard_reset(h, state.ctypes.data, float(self.lambda_), st()))
+		block, glen = int(lib.rk_astar_shard_block_bytes(h)), int(lib.rk_astar_shard_gather_len(h))
+		send = torch.zeros((tp.world, block), dtype=torch.uint8, device=gpu)
+		recv = send if tp.shortcut else torch.zeros_like(send)
+		mine = torch.zeros(glen, dtype=torch.float64, device=gpu)
+		_ffi.check(lib.rk_astar_shard_bind(h, mine.data_ptr()))
+		_ffi.check(lib.rk_astar_shard_reset(h, state.ctypes.data, float(self.lambda_), send.data_ptr(), st()))
 		root_owner = lib.rk_shard_owner(state.ctypes.data, tp.world)
-		k_out, k_in = 12 * N, 12 * N * tp.world
-		send = torch.empty((k_out, REC_BYTES), dtype=torch.uint8, device=gpu)
-		offers_out = torch.empty((k_in, OFFER_BYTES), dtype=torch.uint8, device=gpu)
 		oh_dtype = _oh_dtype(self.net)
-		oh = torch.empty((min(k_in, self.capacity), 480), dtype=oh_dtype, device=gpu)
-		send_counts = np.zeros(tp.world, np.int64)
-		offer_counts = np.zeros(tp.world, np.int64)
-		info = np.zeros(5, np.int64)
-		heads = np.empty(N + 2, np.float64)
-		self._n = int(lib.rk_astar_size(h))
+		oh = torch.zeros((12 * N * tp.world, 480), dtype=oh_dtype, device=gpu)
+		code = _OH_CODES[oh_dtype]
+		decision = (C.c_longlong * 8)()
+		marks = []                                                       # per iteration: events between the phases
 
+		def mark(row):
+			if self.profile:
+				e = torch.cuda.Event(enable_timing=True)
+				e.record()
+				row.append(e)
+
+		stop, it = 0, 0
 		while True:
-			# 1. global selection (also carries pool sizes and the clock of rank 0)
-			heads[:] = np.inf
-			got = lib.rk_astar_export_open(h, heads[2:].ctypes.data, None, N, st())
-			if got < 0:
-				_ffi.check(int(got))
-			heads[0] = self._n
-			heads[1] = time.perf_counter() - t0
-			allh = tp.all_gather_vec(heads)
-			self.total_states = int(allh[:, 0].sum())
-			if allh[0, 1] >= time_limit or self.total_states + N * 12 * tp.world > max_states:
-				return False
-			pops = select_pops(allh[:, 2:], N)
-			if pops.sum() == 0:
-				return False
-			# 2. expand and bucket
-			_ffi.check(lib.rk_astar_shard_pop(h, int(pops[tp.rank]), send.data_ptr(), send_counts.ctypes.data, st()))
-			# 3. frontier exchange
-			recv_counts = tp.exchange_counts(send_counts)
-			recv = tp.exchange_records(send, send_counts, recv_counts)
-			n_recv = int(recv_counts.sum())
-			if n_recv > k_in:
-				raise _ffi.RubiksHipError(f"rank {tp.rank} received {n_recv} records, scratch holds {k_in}")
-			# 4. insert on the owner
-			_ffi.check(lib.rk_astar_shard_insert(h, recv.data_ptr() if n_recv else None, n_recv, offers_out.data_ptr(),
-			                                     offer_counts.ctypes.data, info.ctypes.data, st()))
-			n_new, won, solved_idx, self._n = int(info[1]), int(info[2]), int(info[3]), int(info[4])
-			self.iterations += 1
-			# 7a. has anybody inserted the solved state?
-			flags = tp.all_gather_vec(np.array([won, solved_idx], dtype=np.float64))
-			winners = np.flatnonzero(flags[:, 0])
-			if len(winners):
-				self._walk(int(winners[0]), int(flags[winners[0], 1]), root_owner)
-				self.total_states = int(tp.all_gather_vec(np.array([self._n], dtype=np.float64)).sum())
-				return True
-			# 5. value net on this rank's new states, push
-			values = None
-			if n_new:
-				_ffi.check(lib.rk_astar_new_states_oh(h, oh.data_ptr(), _OH_CODES[oh_dtype], st()))
-				values = _value_f32(self.net(oh[:n_new], policy=False, value=True))
-			_ffi.check(lib.rk_astar_shard_push(h, values.data_ptr() if values is not None else None, st()))
-			# 6. shortcut offers back to the parents' owners
-			offers_in_counts = tp.exchange_counts(offer_counts)
-			offers = tp.exchange_records(offers_out, offer_counts, offers_in_counts)
-			n_off = int(offers_in_counts.sum())
-			_ffi.check(lib.rk_astar_shard_apply_shortcuts(h, offers.data_ptr() if n_off else None, n_off, st()))
+			row = []
+			mark(row)
+			mine[5:6].fill_(time.perf_counter() - t0)                    # rank 0's clock decides for everybody
+			gathered = tp.all_gather(mine)                               # collective 1: heads + status
+			mark(row)
+			_ffi.check(lib.rk_astar_shard_select(h, gathered.data_ptr(), float(time_limit), float(max_states), send.data_ptr(), st()))
+			it += 1
+			if it % self.poll == 0:
+				_ffi.check(lib.rk_astar_shard_decision(h, decision, st()))   # the only host synchronisation
+				stop = int(decision[0])
+				if stop:
+					break
+			mark(row)
+			got = tp.all_to_all(send, recv)                              # collective 2: records (+ last iteration's offers)
+			mark(row)
+			_ffi.check(lib.rk_astar_shard_insert(h, got.data_ptr(), send.data_ptr(), oh.data_ptr(), code, st()))
+			mark(row)
+			values = _value_f32(self.net(oh, policy=False, value=True))
+			self._keep = (values, gathered)
+			mark(row)
+			_ffi.check(lib.rk_astar_shard_push(h, values.data_ptr(), got.data_ptr(), send.data_ptr(), st()))
+			mark(row)
+			if self.profile and len(marks) < 4096:
+				marks.append(row)
+		self.stop_reason = STOP_REASONS.get(stop, str(stop))
+		self.total_states, self.iterations, self._n = int(decision[3]), int(decision[5]), int(decision[6])
+		if self.profile and marks:
+			torch.cuda.synchronize()
+			names = ("all_gather", "select+expand", "all_to_all", "insert", "net", "push")
+			tot = np.zeros(len(names))
+			for row in marks:
+				tot += [row[i].elapsed_time(row[i + 1]) for i in range(len(names))]
+			self.phase_ms = {n: float(t / len(marks)) for n, t in zip(names, tot)}
+			self.phase_ms["iterations_timed"] = len(marks)
+		if stop == 6:
+			raise _ffi.RubiksHipError(f"rank {tp.rank}: a rank reported an engine error; every rank stops together")
+		if stop == 1:
+			self._walk(int(decision[1]), int(decision[2]), root_owner)
+			return True
+		# no win: the shortcut offers of the last iteration are still in the send blocks; deliver and apply them
+		got = tp.all_to_all(send, recv)
+		_ffi.check(lib.rk_astar_shard_flush(h, got.data_ptr(), st()))
+		_ffi.check(lib.rk_astar_shard_clear_send(h, send.data_ptr(), 1, 1, st()))
+		return False
 
 	def _walk(self, rank: int, idx: int, root_owner: int):
 		"""Action queue from (rank, idx) back to the root; one 3-int broadcast per hop (agents.py:244-251)."""

@@ -30,6 +30,8 @@ class SolveService:
 	def __init__(self, net, max_states: int = 2_000_000):
 		self.max_states = max_states
 		self.agents = [                                          # order = agentIdx of the frontend (api.py:29-37)
+			# time-limited searches start with pools of `max_states` / 200 000 nodes and grow them (doubling) while
+			# time is left; a search that hits the agents' max_capacity reports it (agent.capacity_exhausted)
 			("A*", AStar(net, **ASTAR_PARAMS, capacity=max_states)),
 			("MCTS", MCTS(net, **MCTS_PARAMS, search_graph=True, capacity=min(max_states, 200_000))),
 			("Greedy policy", PolicySearch(net)),
@@ -55,7 +57,10 @@ class SolveService:
 			raise ValueError("state must be 20 cubie codes in 0..23")
 		agent = self.agents[idx][1]
 		found = agent.search(state, float(request["timeLimit"]))
-		return {"solution": bool(found), "actions": [int(a) for a in agent.action_queue], "exploredStates": int(len(agent))}
+		out = {"solution": bool(found), "actions": [int(a) for a in agent.action_queue], "exploredStates": int(len(agent))}
+		if getattr(agent, "capacity_exhausted", False):           # not part of the reference's contract: extra key, only when it happened
+			out["capacityExhausted"] = True
+		return out
 
 	def solve_json(self, body) -> str:
 		if isinstance(body, (bytes, bytearray)):

@@ -139,7 +139,7 @@ def test_repr686_golden(golden):
 	assert (s == ref).all()
 
 
-@pytest.mark.parametrize("n", [1, 3, 4, 5, 257, 4099])
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 7, 257, 4099])
 def test_repr686_fanout_flags_one_launch(n):
 	"""6x8x6 fan-out with the goal test fused into the same launch: children, flags, count and first index against the
 	oracle, with parents one move from solved, solved parents and slots that are NOT one-hot (must never read as solved)."""
@@ -152,7 +152,7 @@ def test_repr686_fanout_flags_one_launch(n):
 	if n > 2:
 		p[0] = orc.SOLVED686                                         # a solved parent has no solved child
 		p[n - 1] = orc.rotate686(orc.SOLVED686, 2, 1)
-	if n > 4:
+	if n > 6:
 		junk = orc.rotate686(orc.SOLVED686, 1, 1).copy()
 		junk[3, 5] = [1, 0, 0, 1, 0, 0]                              # two ones in a slot
 		p[1] = junk
@@ -162,7 +162,7 @@ def test_repr686_fanout_flags_one_launch(n):
 		p[2] = junk2
 	ref_ch = np.stack([orc.rotate686(s, a // 2, 1 - a % 2) for s in p for a in range(12)])
 	ref_fl = orc.multi_is_solved686(ref_ch)
-	assert ref_fl.sum() == (1 if n <= 2 else 2)
+	assert ref_fl.sum() >= (1 if n <= 2 else 2)                      # the planted ones (a random walk may add its own)
 	stats = torch.tensor([0, _ffi.INT64_MAX], dtype=torch.int64, device="cuda")
 	ch, fl = cube.device.expand12(dev(p), stats=stats)
 	assert (ch.cpu().numpy() == ref_ch).all() and (fl.cpu().numpy().astype(bool) == ref_fl).all()

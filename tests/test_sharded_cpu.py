@@ -1,7 +1,7 @@
 """
-The N > 1 path on CPU (gloo, world_size 2 and 3): the collectives of the hash-sharded search (counts / variable-size
-record all-to-all / all-gather / broadcast), the global top-N selection every rank must agree on, and the weak-scaling
-aggregation of bench.py.  No kernels run here; the GPU side is covered by tests/test_sharded_gpu.py.
+The N > 1 path on CPU (gloo, world_size 2 and 3): the two collectives of the hash-sharded search (fixed-size all-gather,
+equal-split all-to-all of {header, padded payload} blocks) and the path-walk broadcast, the global top-N selection rule
+every rank must agree on, and the weak-scaling aggregation of bench.py.  No kernels run here; the GPU side is covered by tests/test_sharded_gpu.py.
 """
 import os
 import socket
@@ -27,37 +27,34 @@ def _worker(rank, world, port, out_dir):
 	dist.init_process_group("gloo", rank=rank, world_size=world)
 	try:
 		tp = Transport()
-		assert (tp.world, tp.rank, tp.backend, tp.on_device) == (world, rank, "gloo", False)
-		# all-gather: every rank sees every rank's vector, in rank order
-		allv = tp.all_gather_vec(np.array([rank, 10.0 * rank + 0.5]))
+		assert (tp.world, tp.rank, tp.backend, tp.on_device, tp.shortcut) == (world, rank, "gloo", False, False)
+		# collective 1, all-gather of a fixed-size vector: every rank sees every rank's vector, in rank order
+		allv = tp.all_gather(torch.tensor([rank, 10.0 * rank + 0.5], dtype=torch.float64))
 		assert allv.tolist() == [[r, 10.0 * r + 0.5] for r in range(world)]
-		# counts: rank r sends (r + 1) * (d + 1) records to rank d
-		send_counts = np.array([(rank + 1) * (d + 1) for d in range(world)], dtype=np.int64)
-		recv_counts = tp.exchange_counts(send_counts)
-		assert recv_counts.tolist() == [(s + 1) * (rank + 1) for s in range(world)]
-		# records: byte 0 = sender, byte 1 = destination, bytes 2.. = running number; grouped by destination
-		rows = []
+		# collective 2, all-to-all of equal fixed-size blocks {header = counts, padded payload}: rank r sends (r + 1) * (d + 1)
+		# records to rank d; byte 0 = sender, byte 1 = destination, byte 2 = running number
+		block = 32 + 40 * 4
+		send = torch.zeros((world, block), dtype=torch.uint8)
 		for d in range(world):
-			for k in range(send_counts[d]):
-				rows.append([rank, d, k] + [7] * 29)
-		send = torch.tensor(rows, dtype=torch.uint8)
-		# (Transport moves the result to the GPU only when there is one; patch the device for the CPU test)
-		import librubiks_amd.solving.sharded as sh
-		sh.gpu = torch.device("cpu")
-		recv = tp.exchange_records(send, send_counts, recv_counts).numpy()
-		want = [[s, rank, k] for s in range(world) for k in range((s + 1) * (rank + 1))]
-		assert recv[:, :3].tolist() == want and (recv[:, 3:] == 7).all()
-		# empty exchange
-		z = np.zeros(world, np.int64)
-		assert tp.exchange_records(torch.zeros((0, 16), dtype=torch.uint8), z, tp.exchange_counts(z)).shape == (0, 16)
-		# broadcast from the last rank
+			cnt = (rank + 1) * (d + 1)
+			send[d, 0] = cnt
+			for k in range(cnt):
+				send[d, 32 + 4 * k: 32 + 4 * k + 3] = torch.tensor([rank, d, k], dtype=torch.uint8)
+		recv = tp.all_to_all(send, torch.zeros_like(send))
+		for src in range(world):
+			cnt = int(recv[src, 0])
+			assert cnt == (src + 1) * (rank + 1)
+			rows = recv[src, 32: 32 + 4 * cnt].view(cnt, 4)[:, :3].tolist()
+			assert rows == [[src, rank, k] for k in range(cnt)]
+		assert tp.collectives == 2
+		# broadcast from the last rank (the cross-rank path walk)
 		got = tp.broadcast_vec(np.array([rank, 5, 6], dtype=np.int64), world - 1)
 		assert got.tolist() == [world - 1, 5, 6]
-		# the global selection is the same on every rank
+		# the selection rule gives the same answer on every rank from the gathered heads
 		rng = np.random.RandomState(3)
 		heads = np.sort(rng.randint(0, 6, (world, 8)).astype(np.float64), axis=1)
 		heads[0, 5:] = np.inf
-		pops = select_pops(tp.all_gather_vec(heads[rank]), 8)
+		pops = select_pops(tp.all_gather(torch.from_numpy(heads[rank])).numpy(), 8)
 		np.save(os.path.join(out_dir, f"pops{rank}.npy"), pops)
 		# bench.py's aggregation: MAX of the ranks' elapsed times
 		import bench

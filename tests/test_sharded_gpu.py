@@ -51,6 +51,113 @@ def test_world1_equals_oracle(seed, depth, lam, n, budget):
 	assert list(agent.action_queue) == list(ref.action_queue)
 
 
+def _simulate_ranks(world, start, lam, N, budget, capacity):
+	"""
+	All `world` ranks of a sharded search in ONE process on one GPU: one engine per rank, the two collectives done by hand
+	(all-gather = stack the contributions, all-to-all = transpose the send blocks).  Checks on the way that every rank takes
+	the same stop decision and that the device's global top-N selection equals the host statement of the rule.
+	"""
+	import ctypes as C
+	from librubiks_amd.solving.sharded import select_pops
+	lib, st = _ffi.lib(), _ffi.stream_ptr
+	hs, sends, mines = [], [], []
+	for r in range(world):
+		h = C.c_void_p()
+		_ffi.check(lib.rk_astar_create_sharded(C.byref(h), capacity, N, r, world))
+		send = torch.zeros((world, int(lib.rk_astar_shard_block_bytes(h))), dtype=torch.uint8, device="cuda")
+		mine = torch.zeros(int(lib.rk_astar_shard_gather_len(h)), dtype=torch.float64, device="cuda")
+		_ffi.check(lib.rk_astar_shard_bind(h, mine.data_ptr()))
+		_ffi.check(lib.rk_astar_shard_reset(h, start.ctypes.data, lam, send.data_ptr(), st()))
+		hs.append(h); sends.append(send); mines.append(mine)
+	oh = torch.zeros((12 * N * world, 480), device="cuda")
+	net = StubNet()
+	dec = (C.c_longlong * 8)()
+	iters = 0
+	while True:
+		gathered = torch.stack(mines).contiguous()
+		decisions = []
+		for r in range(world):
+			_ffi.check(lib.rk_astar_shard_select(hs[r], gathered.data_ptr(), 1e10, float(budget), sends[r].data_ptr(), st()))
+			_ffi.check(lib.rk_astar_shard_decision(hs[r], dec, st()))
+			decisions.append(list(dec))
+		stop = decisions[0][0]
+		assert all(d[:4] == decisions[0][:4] for d in decisions)          # same stop, winner and total everywhere
+		if stop:
+			break
+		want = select_pops(gathered[:, 8:].cpu().numpy(), N)
+		assert [d[4] for d in decisions] == want.tolist(), (iters, [d[4] for d in decisions], want)
+		recvs = [torch.stack([sends[src][r] for src in range(world)]).contiguous() for r in range(world)]
+		for r in range(world):
+			_ffi.check(lib.rk_astar_shard_insert(hs[r], recvs[r].data_ptr(), sends[r].data_ptr(), oh.data_ptr(), _ffi.OH_F32, st()))
+			values = net(oh, policy=False, value=True).reshape(-1).contiguous()
+			_ffi.check(lib.rk_astar_shard_push(hs[r], values.data_ptr(), recvs[r].data_ptr(), sends[r].data_ptr(), st()))
+			torch.cuda.synchronize()
+		iters += 1
+		assert iters < 100_000
+	queue = None
+	if stop == 1:
+		rank, idx = decisions[0][1], decisions[0][2]
+		root_owner = lib.rk_shard_owner(start.ctypes.data, world)
+		hop, queue = (C.c_longlong * 3)(), []
+		while not (rank == root_owner and idx == 1):
+			_ffi.check(lib.rk_astar_shard_parent(hs[rank], idx, hop, st()))
+			queue.insert(0, int(hop[2]))
+			rank, idx = int(hop[0]), int(hop[1])
+			assert len(queue) < 1000
+	else:
+		recvs = [torch.stack([sends[src][r] for src in range(world)]).contiguous() for r in range(world)]
+		for r in range(world):
+			_ffi.check(lib.rk_astar_shard_flush(hs[r], recvs[r].data_ptr(), st()))
+	shards = []
+	for r in range(world):
+		n = decisions[r][6]
+		states, G = np.zeros((n, 20), np.int8), np.zeros(n)
+		if n:
+			_ffi.check(lib.rk_astar_export(hs[r], 1, n, states.ctypes.data, G.ctypes.data, None, None, st()))
+		shards.append((states, G))
+		lib.rk_astar_destroy(hs[r])
+	return stop, queue, shards, decisions[0][3], iters
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_ranks_simulated_in_one_process(world):
+	lib = _ffi.lib()
+	for seed, depth, lam, N, budget in [(7, 6, 0.5, 10, 30_000), (19, 7, 0.1, 300, 60_000), (405, 8, 0.5, 30, 40_000)]:
+		np.random.seed(seed)
+		start, _, _ = orc.scramble(depth, True)
+		stop, queue, shards, total, iters = _simulate_ranks(world, start, lam, N, budget, capacity=budget)
+		stop2, queue2, shards2, total2, iters2 = _simulate_ranks(world, start, lam, N, budget, capacity=budget)
+		assert (stop, queue, total, iters) == (stop2, queue2, total2, iters2)          # deterministic
+		assert all((a[0] == b[0]).all() and (a[1] == b[1]).all() for a, b in zip(shards, shards2))
+		if stop == 1:
+			s = start
+			for a in queue:
+				s = orc.rotate(s, a // 2, 1 - a % 2)
+			assert orc.is_solved(s)
+		else:
+			assert stop == 2 and total + 12 * N * world > budget
+		seen = set()
+		for r, (states, G) in enumerate(shards):
+			owners = np.array([lib.rk_shard_owner(np.ascontiguousarray(x).ctypes.data, world) for x in states[:: max(1, len(states) // 300)]])
+			assert (owners == r).all()
+			keys = {x.tobytes() for x in states}
+			assert len(keys) == len(states) and not (keys & seen)
+			seen |= keys
+		assert len(seen) == total and start.tobytes() in seen
+
+
+def test_pool_capacity_stops_every_rank_together():
+	"""A budget larger than what the per-rank pools hold must end the search on all ranks at once (no rank left in a
+	collective): stop reason 3, decided from the all-gathered pool sizes."""
+	np.random.seed(42)
+	start, _, _ = orc.scramble(14, True)
+	stop, queue, shards, total, iters = _simulate_ranks(3, start, 0.2, 100, budget=10_000_000, capacity=9_000)
+	assert stop == 3 and queue is None and iters > 1
+	assert max(len(s[0]) for s in shards) + 12 * 100 * 3 > 9_000 and all(len(s[0]) <= 9_000 for s in shards)
+	agent = ShardedAStar(StubNet(), 0.2, 100, capacity=9_000)                 # the agent reports it too (world = 1)
+	assert agent.search(start, None, 10_000_000) is False and agent.stop_reason == "capacity"
+
+
 def _free_port():
 	with socket.socket() as s:
 		s.bind(("127.0.0.1", 0))
@@ -123,6 +230,29 @@ def test_multi_rank_on_one_gpu(world, tmp_path):
 		assert total == int(first[0]["total"]) and start.tobytes() in seen
 		assert total <= budget
 	assert n_solved >= 3
+
+
+def _rank_capacity(rank, world, port, out_dir):
+	import torch.distributed as dist
+	os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+	dist.init_process_group("gloo", rank=rank, world_size=world)
+	try:
+		torch.cuda.set_device(0)
+		np.random.seed(42)
+		start, _, _ = orc.scramble(14, True)
+		agent = ShardedAStar(StubNet(), 0.2, 100, capacity=9_000, poll=2)
+		solved = agent.search(start, None, 10_000_000)                        # budget far beyond world * capacity
+		np.savez(os.path.join(out_dir, f"cap_r{rank}.npz"), solved=solved, reason=agent.stop_reason, n=len(agent), iters=agent.iterations)
+	finally:
+		dist.destroy_process_group()
+
+
+def test_multi_rank_capacity_stop_gloo(tmp_path):
+	"""with capacity < budget no rank may run into ECAPACITY while its peers wait in a collective."""
+	mp.spawn(_rank_capacity, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+	z = [np.load(tmp_path / f"cap_r{r}.npz") for r in range(2)]
+	assert all(str(x["reason"]) == "capacity" and not bool(x["solved"]) for x in z)
+	assert int(z[0]["iters"]) == int(z[1]["iters"]) > 1 and all(int(x["n"]) <= 9_000 for x in z)
 
 
 def _nccl_world1(rank, port, out_path, case):
