@@ -12,10 +12,9 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from benchmarks.nets import FcSmall  # noqa: E402
+from benchmarks.nets import FastStub, FcSmall  # noqa: E402
 from librubiks_amd import cube  # noqa: E402
 from librubiks_amd.solving.agents import AStar  # noqa: E402
-from oracle.search_oracle import StubNet  # noqa: E402   (the exact stub heuristic; a net stand-in, not the checker)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--expansions", type=int, default=100)
@@ -24,7 +23,7 @@ ap.add_argument("--graph", type=int, default=0)
 ap.add_argument("--max-states", type=int, default=200_000)
 ap.add_argument("--depth", type=int, default=16)
 a = ap.parse_args()
-net = StubNet() if a.net == "stub" else (FcSmall().cuda().eval().to(torch.bfloat16) if a.net == "bf16" else FcSmall().cuda().eval())
+net = FastStub() if a.net == "stub" else (FcSmall().cuda().eval().to(torch.bfloat16) if a.net == "bf16" else FcSmall().cuda().eval())
 agent = AStar(net, 0.2, a.expansions, poll=16, use_hipgraph=bool(a.graph))
 np.random.seed(3)
 state, _, _ = cube.scramble(a.depth, True)

@@ -14,13 +14,12 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from benchmarks.nets import FcSmall  # noqa: E402
+from benchmarks.nets import FastStub, FcSmall  # noqa: E402
 from librubiks_amd import cube  # noqa: E402
 from librubiks_amd.solving.agents import AStar  # noqa: E402
-from oracle.search_oracle import StubNet  # noqa: E402   (the exact stub heuristic of the traces; a net, not the checker)
 
 net = FcSmall().cuda().eval()
-for name, nn in (("stub", StubNet()), ("fc_small fp32", net), ("fc_small bf16", FcSmall().cuda().eval().to(torch.bfloat16))):
+for name, nn in (("stub", FastStub()), ("fc_small fp32", net), ("fc_small bf16", FcSmall().cuda().eval().to(torch.bfloat16))):
 	for N in (10, 27, 100, 700):
 		for graph in (False, True):
 			agent = AStar(nn, 0.2, N, poll=16, use_hipgraph=graph)

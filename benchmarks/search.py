@@ -113,6 +113,8 @@ def bench_astar_batch(args):
 
 def bench_mcts(args):
 	net = FcSmall().cuda().eval()
+	if args.bf16:
+		net = net.to(torch.bfloat16)          # bf16 one-hot straight from the engine; P, V come back as float32 -> float64 statistics
 	T = args.trees
 	starts = []
 	for g in range(T):
@@ -128,7 +130,7 @@ def bench_mcts(args):
 	torch.cuda.synchronize()
 	dt = time.perf_counter() - t0
 	st = agent.status
-	row = {"bench": "mcts", "config": f"{T} trees x {args.sims} sims, depth-{args.depth} scrambles, c={args.c}, fc_small random init fp32, "
+	row = {"bench": "mcts", "config": f"{T} trees x {args.sims} sims, depth-{args.depth} scrambles, c={args.c}, fc_small random init {'bf16' if args.bf16 else 'fp32'}, "
 	       f"hipGraph={'on' if args.graph else 'off'}", "seconds": dt, "tree_sims": int(st[:, 3].sum()), "tree_sims_per_s": float(st[:, 3].sum()) / dt,
 	       "steps": agent.simulations, "ms_per_step": dt / agent.simulations * 1e3, "solved": int(solved.sum()), "states": int(st[:, 2].sum()),
 	       "states_per_s": float(st[:, 2].sum()) / dt, "max_path_len": int(st[:, 4].max())}

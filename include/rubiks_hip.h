@@ -18,7 +18,10 @@
  *   - A 20-byte state is int8[20]: 8 corner codes slot*3+ori then 12 edge codes slot*2+ori
  *     (cube.py:58-65).  State arrays are dense row-major (n, 20); their base must be 4-byte
  *     aligned (always true for rows of a 256-B aligned allocation).
- *   - An action index a in [0,12) means face a/2, direction 1-(a%2) (cube.py:33-34).
+ *   - An action index a in [0,12) means face a/2, direction 1-(a%2) (cube.py:33-34).  PRECONDITION of the
+ *     device-pointer entries: every action code is < 12.  A larger code is treated as action 0 (the kernels never
+ *     index past the move table) and the result for that row is meaningless; the *_host entries check and fail
+ *     with RK_EINVAL, as the reference's table indexing would raise.
  *   - repr: RK_REPR_2024 = 20-byte cubie codes, RK_REPR_686 = int8 (6,8,6) one-hot, 288 bytes
  *     (cube.py:67-71).
  */
@@ -44,6 +47,10 @@ extern "C" {
 #define RK_OH_F32  0
 #define RK_OH_F16  1
 #define RK_OH_BF16 2
+#define RK_OH_STATES 3   /* engines only: hand the net the 20-byte states themselves (first layer fused, rk_ohl_*) */
+
+#define RK_OHL_GATHER 0  /* exact float32 gather-sum through an LDS-resident weight slice */
+#define RK_OHL_MFMA   1  /* bf16 MFMA with the one-hot operand synthesised in registers */
 
 /* ---- library ------------------------------------------------------------------------------ */
 int         rk_version(void);
@@ -114,6 +121,18 @@ int rk_apply_sequences(int repr, const uint8_t *d_actions, int depth, int games,
  * (n, 480) [2024] or (n, 288) [686] elements of out_dtype (RK_OH_*); d_out 16-byte aligned. */
 int rk_as_oh(int repr, const int8_t *d_states, void *d_out, int out_dtype, size_t n, void *stream);
 
+/* Fused one-hot -> first Linear of the net (cube.py:265-277 + model.py:127,150): y = as_oh(states) @ W^T + b without the
+ * one-hot ever reaching HBM.  rk_ohl_create copies nn.Linear(480, H)'s weight (H, 480) row-major and bias (H), both
+ * float32 or both bfloat16 (w_dtype = RK_OH_F32 / RK_OH_BF16; bias may be NULL), into the layouts the two routes use;
+ * H must be a multiple of 64.  rk_ohl_forward: d_out (n, H) row-major, 16-byte aligned.
+ *   RK_OHL_GATHER  y = ((b + w_0) + w_1) + ... + w_19 with float32 adds in that order (w_i = row 24 i + state[i] of W^T):
+ *                  exact and reproducible; out_dtype RK_OH_F32 or RK_OH_BF16 (rounded to nearest even at the end)
+ *   RK_OHL_MFMA    bf16 weights, float32 accumulation on the matrix cores, out_dtype RK_OH_BF16 */
+typedef struct rk_ohl rk_ohl_t;
+int rk_ohl_create(rk_ohl_t **out, const void *d_weight, int w_dtype, const void *d_bias, int H, void *stream);
+int rk_ohl_destroy(rk_ohl_t *h);
+int rk_ohl_forward(rk_ohl_t *h, const int8_t *d_states, void *d_out, int out_dtype, size_t n, int route, void *stream);
+
 /* as_correct (cube.py:371-380): 686 one-hot int8 (n,288) -> float32 (n,48) of +1/-1. */
 int rk_as_correct686(const int8_t *d_states, float *d_out, size_t n, void *stream);
 
@@ -131,7 +150,8 @@ int rk_as_correct686(const int8_t *d_states, float *d_out, size_t n, void *strea
  *                          fan-out (:277-282), membership + first-occurrence de-duplication in parent-major batch order
  *                          (np.unique semantics, :286-295), append the unseen states with G / parent / action
  *                          (:299-313), goal test of the new states (:321-323), and the one-hot rows of the new states
- *                          (:379) into d_onehot (12 N, 480) -- rows past the number of new states are left untouched
+ *                          (:379) into d_onehot (12 N, 480) -- rows past the number of new states are left untouched;
+ *                          out_dtype RK_OH_STATES writes the (12 N, 20) int8 states instead (first layer fused)
  *   rk_astar_step_commit : d_values (12 N) from the net; cost = lambda*G + (-value) in float64 (:383), push (:316-317),
  *                          relaxation of the already-seen children (:326-329, 333-367; skipped once won, as the
  *                          reference returns before relaxing), bookkeeping and the next pop list

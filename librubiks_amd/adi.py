@@ -20,7 +20,7 @@ from librubiks_amd import gpu, no_grad, _ffi, cube
 
 @no_grad
 def adi_traindata(net, rollout_games: int, rollout_depth: int, alpha: float, reward_method: str = "lapanfix",
-                  ff_batches: int = 1):
+                  ff_batches: int = 1, fused_first_layer: bool = False):
 	assert reward_method in ("paper", "lapanfix", "schultzfix", "reward0")
 	_ffi.require_gpu()
 	net.eval()
@@ -41,11 +41,19 @@ def adi_traindata(net, rollout_games: int, rollout_depth: int, alpha: float, rew
 	# value of every child, in slices so that the one-hot batch stays bounded                      train.py:301-303
 	values = torch.empty(12 * n, dtype=torch.float32, device=gpu)
 	step = -(-12 * n // max(1, ff_batches))
-	buf = torch.empty((min(step, 12 * n), 480), dtype=torch.float32, device=gpu)
-	for lo in range(0, 12 * n, step):
-		hi = min(lo + step, 12 * n)
-		cube.device.as_oh(substates[lo:hi], out=buf[:hi - lo])
-		values[lo:hi] = net(buf[:hi - lo], policy=False, value=True).reshape(-1).float()
+	if fused_first_layer:
+		# the net's first Linear reads the 2.7 M children's 20-byte states directly: the (12 n, 480) one-hot never exists
+		from librubiks_amd.oh_linear import fuse_first_linear
+		from_states = fuse_first_linear(net)
+		for lo in range(0, 12 * n, step):
+			hi = min(lo + step, 12 * n)
+			values[lo:hi] = from_states(substates[lo:hi], policy=False, value=True).reshape(-1).float()
+	else:
+		buf = torch.empty((min(step, 12 * n), 480), dtype=torch.float32, device=gpu)
+		for lo in range(0, 12 * n, step):
+			hi = min(lo + step, 12 * n)
+			cube.device.as_oh(substates[lo:hi], out=buf[:hi - lo])
+			values[lo:hi] = net(buf[:hi - lo], policy=False, value=True).reshape(-1).float()
 	values = (values + rewards).reshape(-1, 12)                                                   # train.py:313-314
 	policy_targets = torch.argmax(values, dim=1)
 	value_targets = values[torch.arange(n, device=gpu), policy_targets]

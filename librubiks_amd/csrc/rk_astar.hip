@@ -64,7 +64,9 @@ enum {
 enum { ERR_NONE = 0, ERR_CAPACITY = 1, ERR_CHAIN = 2 };
 
 constexpr int QL = 12;                          // maximal number of queue levels
-constexpr int SORT_CHUNK = 2048;                // records sorted per workgroup in LDS (32 KB)
+constexpr int SORT_CHUNK = 2048;                // records sorted per workgroup in LDS (32 KB) when K > 2048
+constexpr int SMALL_CHUNK = 256;                // ... and when K <= 2048: up to eight 256-record runs, sorted by eight workgroups
+constexpr int MAX_NEW_RUNS = SORT_CHUNK / SMALL_CHUNK;
 enum { Q_HEAD = 0, Q_LEN = 1, Q_CUR = 2, Q_TAKE = 3 };
 
 struct QueueDev {
@@ -76,7 +78,7 @@ struct QueueDev {
 
 struct AstarDev {
 	uint32_t mask, cap1;
-	int N, K, Kpad;                             // expansions, 12 N, K rounded up to SORT_CHUNK
+	int N, K, Kpad, chunk;                      // expansions, 12 N, K rounded up to the sort chunk, sort chunk (256 or 2048)
 	int world, rank, KI;                        // sharded: ranks, this rank, incoming child slots = world * K
 	double lambda;
 	uint32_t *states; int32_t *G, *parents; uint8_t *pact, *prank; uint32_t *table, *mark;
@@ -98,16 +100,18 @@ __device__ __forceinline__ int32_t *qmeta(const QueueDev &q, int which) { return
 struct MergePlan {
 	int t;                       // target level (-1: nothing to merge)
 	int n_runs;
-	const Rec *run[QL + 1];
-	int len[QL + 1];
+	const Rec *run[QL + MAX_NEW_RUNS];
+	int len[QL + MAX_NEW_RUNS];
+	int n_new_runs;              // the first n_new_runs runs are the sorted chunks of the new records
 	int total;
 	Rec *dst;
 };
 
 // meta = pointer to [4][QL] ints (global or LDS copy).  live range of level j after the pending pop: [head+take, len)
-__device__ __forceinline__ void make_plan(const QueueDev &q, const int32_t *meta, const Rec *newrun, int n_new, MergePlan &p)
+// new_chunk: the new records are sorted runs of this length (SMALL_CHUNK), or one run (0)
+__device__ __forceinline__ void make_plan(const QueueDev &q, const int32_t *meta, const Rec *newrun, int n_new, int new_chunk, MergePlan &p)
 {
-	p.t = -1; p.n_runs = 0; p.total = 0; p.dst = nullptr;
+	p.t = -1; p.n_runs = 0; p.total = 0; p.dst = nullptr; p.n_new_runs = 0;
 	if (n_new <= 0) return;
 	int sum = n_new, t = 0;
 	for (; t < q.levels; t++) {
@@ -116,7 +120,16 @@ __device__ __forceinline__ void make_plan(const QueueDev &q, const int32_t *meta
 	}
 	if (t >= q.levels) t = q.levels - 1;       // cannot happen: the top level holds the whole pool
 	p.t = t;
-	p.run[0] = newrun; p.len[0] = n_new; p.n_runs = 1;
+	if (new_chunk > 0) {
+		for (int at = 0; at < n_new; at += new_chunk) {
+			p.run[p.n_runs] = newrun + at;
+			p.len[p.n_runs] = n_new - at < new_chunk ? n_new - at : new_chunk;
+			p.n_runs++;
+		}
+	} else {
+		p.run[0] = newrun; p.len[0] = n_new; p.n_runs = 1;
+	}
+	p.n_new_runs = p.n_runs;
 	for (int j = 0; j <= t; j++) {
 		const int start = meta[Q_HEAD * QL + j] + meta[Q_TAKE * QL + j];
 		const int live = meta[Q_LEN * QL + j] - start;
@@ -156,23 +169,35 @@ __global__ void k_astar_root(AstarDev d, const uint32_t *root, int insert)
 }
 
 // The pop list of the next iteration: the n_cand = min(N, |open|) globally smallest records in ascending order.
-// `meta` is the committed queue state (LDS copy); candidates are the first N live records of every level.
-__device__ __forceinline__ void pop_select(const AstarDev &d, const int32_t *meta, int n_cand, int n_exp)
+// `meta` is the committed queue state (LDS copy); candidates are the first N live records of every level.  When they
+// fit (levels * N <= POP_LDS records) the heads are staged in LDS first, so that the binary searches -- a dozen dependent
+// reads per candidate -- stay on the CU; `s_heads` may be null (then everything is read from global memory).
+constexpr int POP_LDS = 6144;                   // 96 KB of 16-byte records
+
+__device__ __forceinline__ void pop_select(const AstarDev &d, const int32_t *meta, int n_cand, int n_exp, Rec *s_heads)
 {
 	const QueueDev &q = d.q;
+	const bool staged = s_heads != nullptr && q.levels * n_exp <= POP_LDS;
+	if (staged) {
+		for (int cand = threadIdx.x; cand < q.levels * n_exp; cand += blockDim.x) {
+			const int j = cand / n_exp, i = cand - j * n_exp;
+			const int head = meta[Q_HEAD * QL + j];
+			if (i < meta[Q_LEN * QL + j] - head) s_heads[cand] = q.buf[j][meta[Q_CUR * QL + j]][head + i];
+		}
+		__syncthreads();
+	}
 	for (int cand = threadIdx.x; cand < q.levels * n_exp; cand += blockDim.x) {
 		const int j = cand / n_exp, i = cand - j * n_exp;
 		const int head = meta[Q_HEAD * QL + j], live = meta[Q_LEN * QL + j] - head;
 		if (i >= live) continue;
-		const Rec *run = q.buf[j][meta[Q_CUR * QL + j]] + head;
-		const Rec x = run[i];
+		const Rec x = staged ? s_heads[cand] : q.buf[j][meta[Q_CUR * QL + j]][head + i];
 		int rank = i;
 		for (int j2 = 0; j2 < q.levels; j2++) {
 			if (j2 == j) continue;
 			const int h2 = meta[Q_HEAD * QL + j2];
 			int m = meta[Q_LEN * QL + j2] - h2;
 			m = m < n_exp ? m : n_exp;
-			if (m > 0) rank += lower_bound_rec(q.buf[j2][meta[Q_CUR * QL + j2]] + h2, m, x);
+			if (m > 0) rank += lower_bound_rec(staged ? s_heads + j2 * n_exp : q.buf[j2][meta[Q_CUR * QL + j2]] + h2, m, x);
 		}
 		if (rank < n_cand) {
 			d.exp_idx[rank] = (int32_t)x.idx;
@@ -244,14 +269,25 @@ void k_expand_lookup(AstarDev d)
 	lookup_elect(d, s, c, [&](int c2, uint32_t o[5]) { child_of(d, s_act, c2, o); });
 }
 
-// one-hot rows [row0, row0 + n) of `out` from n states held in LDS (5 dwords each); the whole workgroup cooperates
+// The net's input rows for the new states of this iteration, (n_new, 480) one-hot or (n_new, 20) raw states, written by a
+// grid as wide as the batch (fused into the append kernel it was the longest kernel of the iteration: a handful of
+// workgroups writing 2 MB).  Rows past n_new are left untouched.  ELEM_BYTES = 0: no encoding at all, the rows are the
+// 20-byte states themselves (for a net whose first layer reads states: rk_ohl_forward, librubiks_amd/oh_linear.py).
 template <int ELEM_BYTES>
-__device__ __forceinline__ void oh_rows_from_lds(const uint32_t *s_states, int n, u32x4 *out, size_t row0, uint32_t one_bits)
+__global__ __launch_bounds__(256)
+void k_new_rows(AstarDev d, u32x4 *out, uint32_t one_bits)
 {
-	constexpr int E = 16 / ELEM_BYTES, CPR = 480 / E, CPC = 24 / E;
-	const uint8_t *bytes = reinterpret_cast<const uint8_t *>(s_states);
-	u32x4 *dst = out + row0 * CPR;
-	for (int q = threadIdx.x; q < n * CPR; q += blockDim.x) {
+	const int n_new = d.ctr[C_NNEW];
+	const uint32_t *pool = d.states + ((size_t)d.ctr[C_NBEFORE] + 1) * 5;
+	if (ELEM_BYTES == 0) {
+		uint32_t *dst = reinterpret_cast<uint32_t *>(out);
+		for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n_new * 5; q += gridDim.x * blockDim.x) dst[q] = pool[q];
+		return;
+	}
+	constexpr int EB = ELEM_BYTES == 0 ? 4 : ELEM_BYTES;
+	constexpr int E = 16 / EB, CPR = 480 / E, CPC = 24 / E;
+	const uint8_t *bytes = reinterpret_cast<const uint8_t *>(pool);
+	for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n_new * CPR; q += gridDim.x * blockDim.x) {
 		const int r = q / CPR, g = q - r * CPR;
 		const int cubie = g / CPC, base = (g - cubie * CPC) * E;
 		const int rel = (int)bytes[r * STATE_BYTES + cubie] - base;
@@ -264,7 +300,7 @@ __device__ __forceinline__ void oh_rows_from_lds(const uint32_t *s_states, int n
 			val.x = (rel >> 1) == 0 ? one : 0u; val.y = (rel >> 1) == 1 ? one : 0u;
 			val.z = (rel >> 1) == 2 ? one : 0u; val.w = (rel >> 1) == 3 ? one : 0u;
 		}
-		dst[q] = val;
+		out[q] = val;
 	}
 }
 
@@ -297,19 +333,18 @@ void k_shard_lookup(AstarDev d, const uint8_t *recv)
 	lookup_elect(d, s, c, [&](int c2, uint32_t o[5]) { load5(shard_rec(recv, d.K, c2), o); });
 }
 
-// flags + order-preserving compaction (chained scan) + append + goal test + relaxation case 1 (read half) + one-hot.
+// flags + order-preserving compaction (tickets + look-back) + append + goal test + relaxation case 1 (read half).
 // SHARDED = false: child c belongs to popped node c/12, action c%12.   SHARDED = true: child slots of the receive buffer.
-template <bool SHARDED, int OH_BYTES>
-__global__ __launch_bounds__(SCAN_BLOCK)
-void k_append(AstarDev d, const uint8_t *recv, u32x4 *onehot, uint32_t one_bits)
+template <bool SHARDED>
+__global__ __launch_bounds__(ASCAN)
+void k_append(AstarDev d, const uint8_t *recv)
 {
-	__shared__ int s_wave[16];
+	__shared__ int s_wave[4];
 	__shared__ int s_ticket, s_base;
-	__shared__ uint32_t s_new[SCAN_BLOCK * 5];
 	const int b = scan_ticket(&d.ctr[C_TICKET0], &s_ticket);
 	const int K = SHARDED ? d.KI : 12 * d.ctr[C_NPOP];
 	const bool live = !d.ctr[C_DONE] || !SHARDED;                       // (single mode: K is 0 once done)
-	const int c = b * SCAN_BLOCK + threadIdx.x;
+	const int c = b * ASCAN + threadIdx.x;
 	const bool valid = live && c < K && (!SHARDED || shard_valid(recv, d.K, c));
 	int fu = 0, fs = 0;
 	int32_t sidx = 0;
@@ -320,9 +355,9 @@ void k_append(AstarDev d, const uint8_t *recv, u32x4 *onehot, uint32_t one_bits)
 	}
 	if (c < (SHARDED ? d.KI : d.K)) d.flags[c] = (uint8_t)(fu | (fs << 1));
 	int total;
-	const int r = block_rank(fu != 0, s_wave, &total);
+	const int r = block_rank256(fu != 0, s_wave, &total);
 	const uint32_t epoch = (uint32_t)d.ctr[C_EPOCH] + 1u;
-	const int base = scan_chain(d.chain0, b, total, epoch, &s_base);
+	const int base = scan_lookback(d.chain0, b, total, epoch, &s_base);
 	const uint32_t n_before = (uint32_t)d.ctr[C_NBEFORE];
 	if (b == (int)gridDim.x - 1 && threadIdx.x == 0) {                  // the last ticket holds the grand total
 		d.ctr[C_NNEW] = base + total;
@@ -347,7 +382,7 @@ void k_append(AstarDev d, const uint8_t *recv, u32x4 *onehot, uint32_t one_bits)
 			uint32_t s[5];
 			load5(cs, s);
 			#pragma unroll
-			for (int j = 0; j < 5; j++) { d.states[(size_t)idx * 5 + j] = s[j]; s_new[r * 5 + j] = s[j]; }
+			for (int j = 0; j < 5; j++) d.states[(size_t)idx * 5 + j] = s[j];
 			d.G[idx] = g;
 			d.parents[idx] = p;
 			d.pact[idx] = act;
@@ -362,27 +397,29 @@ void k_append(AstarDev d, const uint8_t *recv, u32x4 *onehot, uint32_t one_bits)
 		}
 		d.newway[c] = nw;
 	}
-	if (onehot != nullptr) {
-		__syncthreads();
-		oh_rows_from_lds<OH_BYTES>(s_new, total, onehot, (size_t)base, one_bits);
-	}
 }
 
 // cost = lambda * G + (-value), float64, no fused multiply-add (agents.py:380-383); bitonic sort of one chunk in LDS;
 // write half of relaxation case 1 (agents.py:357-359).  Padding records carry distinct maximal keys.
-template <bool SHARDED>
-__global__ __launch_bounds__(1024)
+// CHUNK = 256 (128 threads; K <= 2048: the new records become up to eight sorted runs on eight CUs in parallel, which the
+// queue insert merges directly) or 2048 (1024 threads, followed by the merge passes).
+template <bool SHARDED, int CHUNK>
+__global__ __launch_bounds__(CHUNK / 2)
 void k_records_sort(AstarDev d, const float *values, const uint8_t *recv)
 {
-	__shared__ Rec s[SORT_CHUNK];
+	__shared__ Rec s[CHUNK];
+	constexpr int T = CHUNK / 2;
 	const int tid = threadIdx.x;
 	const int n_new = d.ctr[C_NNEW];
 	const uint32_t n_before = (uint32_t)d.ctr[C_NBEFORE];
-	const int base = blockIdx.x * SORT_CHUNK;
+	const int base = blockIdx.x * CHUNK;
 	if (base < n_new) {                                                 // uniform for the workgroup
+		const int cnt = n_new - base < CHUNK ? n_new - base : CHUNK;
+		int P = 64;                                                     // sort only the power of two that holds the chunk's records
+		while (P < cnt) P <<= 1;
 		#pragma unroll
 		for (int h = 0; h < 2; h++) {
-			const int j = base + tid + h * 1024;
+			const int j = base + tid + h * T;
 			Rec x = Rec{~0ull, 0xFFFFFFFF00000000ull + (uint64_t)j};
 			if (j < n_new) {
 				const uint32_t idx = n_before + 1u + (uint32_t)j;
@@ -390,25 +427,27 @@ void k_records_sort(AstarDev d, const float *values, const uint8_t *recv)
 				const double lg = d.lambda * (double)d.G[idx];
 				x = Rec{sortable_key(lg + hv), (uint64_t)idx};
 			}
-			s[tid + h * 1024] = x;
+			s[tid + h * T] = x;
 		}
 		__syncthreads();
-		for (int k = 2; k <= SORT_CHUNK; k <<= 1)
+		for (int k = 2; k <= P; k <<= 1)
 			for (int j = k >> 1; j > 0; j >>= 1) {
-				const int i = 2 * tid - (tid & (j - 1));
-				const int l = i + j;
-				const bool up = (i & k) == 0;
-				const Rec a = s[i], b2 = s[l];
-				if (rec_less(b2, a) == up) { s[i] = b2; s[l] = a; }
+				if (tid < (P >> 1)) {
+					const int i = 2 * tid - (tid & (j - 1));
+					const int l = i + j;
+					const bool up = (i & k) == 0;
+					const Rec a = s[i], b2 = s[l];
+					if (rec_less(b2, a) == up) { s[i] = b2; s[l] = a; }
+				}
 				__syncthreads();
 			}
-		d.rec0[base + tid] = s[tid];
-		d.rec0[base + tid + 1024] = s[tid + 1024];
+		d.rec0[base + tid] = s[tid];                                    // (records past P are padding and already in place)
+		d.rec0[base + tid + T] = s[tid + T];
 	}
 	// relaxation case 1, write half: first-seen children that found a shorter way to an old node
 	if (d.ctr[C_WON]) return;                                           // the reference returns before relaxing (agents.py:321-323)
 	const int K = SHARDED ? d.KI : 12 * d.ctr[C_NPOP];
-	for (int c = blockIdx.x * 1024 + tid; c < K; c += gridDim.x * 1024) {
+	for (int c = blockIdx.x * T + tid; c < K; c += gridDim.x * T) {
 		if (!(d.flags[c] & 2) || !d.newway[c]) continue;
 		const int32_t t = d.seen[c];
 		d.G[t] = d.val1[c];
@@ -429,7 +468,7 @@ __global__ void k_merge_pass(AstarDev d, int L, int from)
 {
 	const int e = blockIdx.x * blockDim.x + threadIdx.x;
 	const int n_new = d.ctr[C_NNEW];
-	if (e >= d.Kpad || n_new <= SORT_CHUNK) return;                     // a single chunk is already sorted
+	if (e >= d.Kpad || n_new <= SORT_CHUNK) return;                     // a single chunk is already sorted (only launched when K > 2048)
 	const int used = ((n_new + SORT_CHUNK - 1) / SORT_CHUNK) * SORT_CHUNK;
 	const Rec *src = from ? d.rec1 : d.rec0;
 	Rec *dst = from ? d.rec0 : d.rec1;
@@ -444,26 +483,65 @@ __global__ void k_merge_pass(AstarDev d, int L, int from)
 
 // push (agents.py:316-317): multi-way rank merge of the sorted new records with queue levels 0..t into level t's
 // other buffer; read half of relaxation case 2 (agents.py:362), which also clears the marks this batch set.
+// Every record finds its output slot as its own offset plus one binary search per other run.  With K <= 2048 the new
+// records are up to eight 256-record runs: each workgroup stages them in LDS first (32 KB), so those searches -- most of
+// them -- never leave the CU.
 template <bool SHARDED>
 __global__ __launch_bounds__(256)
 void k_queue_insert(AstarDev d, int new_in_rec1)
 {
 	__shared__ MergePlan s_plan;
+	__shared__ Rec s_newrecs[SORT_CHUNK];
+	const bool small = d.chunk == SMALL_CHUNK;
 	if (threadIdx.x == 0) {
 		const int n_new = d.ctr[C_NNEW];
-		// with more than one chunk the merge passes ping-pong; a single chunk stays in rec0
-		make_plan(d.q, d.q.meta, (n_new > SORT_CHUNK && new_in_rec1) ? d.rec1 : d.rec0, n_new, s_plan);
+		// with more than one 2048-chunk the merge passes ping-pong; otherwise the sorted run(s) are in rec0
+		make_plan(d.q, d.q.meta, (!small && n_new > SORT_CHUNK && new_in_rec1) ? d.rec1 : d.rec0, n_new, small ? SMALL_CHUNK : 0, s_plan);
 	}
 	__syncthreads();
+	if (small && s_plan.total > 0) {
+		const int n_new = d.ctr[C_NNEW];
+		for (int i = threadIdx.x; i < n_new; i += blockDim.x) s_newrecs[i] = d.rec0[i];
+		__syncthreads();
+		if ((int)threadIdx.x < s_plan.n_new_runs) s_plan.run[threadIdx.x] = s_newrecs + threadIdx.x * SMALL_CHUNK;
+		__syncthreads();
+	}
 	const MergePlan &p = s_plan;
+	// Long runs that stay in global memory (the queue levels) get a coarse index in LDS: every `step`-th record, at most
+	// SAMPLES per run, so that a binary search spends its first steps on the CU and only log2(step) of them in memory.
+	constexpr int SAMPLES = 256, SAMPLED_RUNS = 3;
+	__shared__ Rec s_samples[SAMPLED_RUNS][SAMPLES];
+	__shared__ int s_step[SAMPLED_RUNS], s_nsamp[SAMPLED_RUNS];
+	const int first_global = small ? p.n_new_runs : 0;
+	if (p.total > 0) {
+		for (int k = 0; k < SAMPLED_RUNS; k++) {
+			const int r = first_global + k;
+			if (r >= p.n_runs) break;
+			const int len = p.len[r], step = (len + SAMPLES - 1) / SAMPLES;
+			const int ns = step > 1 ? (len + step - 1) / step : 0;             // short runs are searched directly
+			if ((int)threadIdx.x < ns) s_samples[k][threadIdx.x] = p.run[r][(size_t)threadIdx.x * step];
+			if (threadIdx.x == 0) { s_step[k] = step; s_nsamp[k] = ns; }
+		}
+		__syncthreads();
+	}
 	const int stride = gridDim.x * blockDim.x;
 	for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < p.total; e += stride) {
 		int r = 0, off = e;
 		while (off >= p.len[r]) { off -= p.len[r]; r++; }
 		const Rec x = p.run[r][off];
 		int pos = off;
-		for (int r2 = 0; r2 < p.n_runs; r2++)
-			if (r2 != r) pos += lower_bound_rec(p.run[r2], p.len[r2], x);
+		for (int r2 = 0; r2 < p.n_runs; r2++) {
+			if (r2 == r) continue;
+			const int k = r2 - first_global;
+			if (k >= 0 && k < SAMPLED_RUNS && s_nsamp[k] > 0) {
+				const int sp = lower_bound_rec(s_samples[k], s_nsamp[k], x);   // first sample >= x
+				const int lo = sp > 0 ? (sp - 1) * s_step[k] : 0;
+				const int hi = sp < s_nsamp[k] ? sp * s_step[k] : p.len[r2];
+				pos += lo + lower_bound_rec(p.run[r2] + lo, hi - lo, x);
+			} else {
+				pos += lower_bound_rec(p.run[r2], p.len[r2], x);
+			}
+		}
 		p.dst[pos] = x;
 	}
 	if (SHARDED) return;                                                // sharded: case 2 travels as offers (k_shard_offers)
@@ -491,11 +569,17 @@ template <bool SHARDED>
 __global__ __launch_bounds__(1024)
 void k_end(AstarDev d, int new_in_rec1, int count_iteration)
 {
-	__shared__ int32_t s_meta[4 * QL];
+	__shared__ int32_t s_meta[4 * QL], s_old[4 * QL], s_ctr[C_COUNT];
 	__shared__ int s_ncand, s_nexp;
+	__shared__ Rec s_heads[POP_LDS];
 	const int tid = threadIdx.x;
-	const int n_pop = d.ctr[C_NPOP];
-	if (!SHARDED && !d.ctr[C_WON]) {
+	// counters and queue state come in with two parallel loads and go back the same way: the bookkeeping thread below
+	// works on LDS only (as dependent global round trips it cost more than every other kernel of the iteration)
+	if (tid < C_COUNT) s_ctr[tid] = d.ctr[tid];
+	else if (tid >= 64 && tid < 64 + 4 * QL) s_old[tid - 64] = d.q.meta[tid - 64];
+	__syncthreads();
+	const int n_pop = s_ctr[C_NPOP];
+	if (!SHARDED && !s_ctr[C_WON]) {
 		for (int i = tid; i < n_pop; i += blockDim.x) {
 			const int32_t p = d.exp_idx[i];
 			for (int a = 0; a < 12; a++) {
@@ -509,12 +593,13 @@ void k_end(AstarDev d, int new_in_rec1, int count_iteration)
 		}
 	}
 	if (tid == 0) {
-		const int n_new = d.ctr[C_NNEW];
+		const int n_new = s_ctr[C_NNEW];
 		MergePlan p;
-		make_plan(d.q, d.q.meta, (n_new > SORT_CHUNK && new_in_rec1) ? d.rec1 : d.rec0, n_new, p);
+		const bool small = d.chunk == SMALL_CHUNK;
+		make_plan(d.q, s_old, (!small && n_new > SORT_CHUNK && new_in_rec1) ? d.rec1 : d.rec0, n_new, small ? SMALL_CHUNK : 0, p);
 		int open = 0;
 		for (int j = 0; j < d.q.levels; j++) {
-			int head = d.q.meta[Q_HEAD * QL + j] + d.q.meta[Q_TAKE * QL + j], len = d.q.meta[Q_LEN * QL + j], cur = d.q.meta[Q_CUR * QL + j];
+			int head = s_old[Q_HEAD * QL + j] + s_old[Q_TAKE * QL + j], len = s_old[Q_LEN * QL + j], cur = s_old[Q_CUR * QL + j];
 			if (j < p.t) { head = 0; len = 0; }
 			else if (j == p.t) { head = 0; len = p.total; cur ^= 1; }
 			if (head >= len) { head = 0; len = 0; }
@@ -522,35 +607,37 @@ void k_end(AstarDev d, int new_in_rec1, int count_iteration)
 			open += len - head;
 		}
 		for (int j = d.q.levels; j < QL; j++) { s_meta[Q_HEAD * QL + j] = 0; s_meta[Q_LEN * QL + j] = 0; s_meta[Q_CUR * QL + j] = 0; s_meta[Q_TAKE * QL + j] = 0; }
-		for (int i = 0; i < 4 * QL; i++) d.q.meta[i] = s_meta[i];
-		const bool ran = SHARDED ? d.ctr[C_DONE] == 0 : n_pop > 0;
-		if (ran && count_iteration) d.ctr[C_ITERS] += 1;
-		d.ctr[C_EPOCH] += 1;                                             // chained-scan words of this launch sequence expire
-		const int n_states = d.ctr[C_NSTATES];
-		d.ctr[C_NBEFORE] = n_states;
-		d.ctr[C_OPEN] = open;
-		d.ctr[C_NNEW] = 0;
-		d.ctr[C_NIN] = 0;
-		d.ctr[C_TICKET0] = 0; d.ctr[C_TICKET1] = 0; d.ctr[C_TICKET2] = 0;
-		const int n_exp = d.ctr[C_NEXP];
-		int done = d.ctr[C_DONE];
-		if (d.ctr[C_WON]) done = 1;
-		if (!SHARDED && (n_states + 12 * n_exp > d.ctr[C_BUDGET] || open == 0)) done = 1;      // loop guard, agents.py:236
-		d.ctr[C_DONE] = done;
+		const bool ran = SHARDED ? s_ctr[C_DONE] == 0 : n_pop > 0;
+		if (ran && count_iteration) s_ctr[C_ITERS] += 1;
+		s_ctr[C_EPOCH] += 1;                                             // chained-scan words of this launch sequence expire
+		const int n_states = s_ctr[C_NSTATES];
+		s_ctr[C_NBEFORE] = n_states;
+		s_ctr[C_OPEN] = open;
+		s_ctr[C_NNEW] = 0;
+		s_ctr[C_NIN] = 0;
+		s_ctr[C_TICKET0] = 0; s_ctr[C_TICKET1] = 0; s_ctr[C_TICKET2] = 0;
+		const int n_exp = s_ctr[C_NEXP];
+		int done = s_ctr[C_DONE];
+		if (s_ctr[C_WON]) done = 1;
+		if (!SHARDED && (n_states + 12 * n_exp > s_ctr[C_BUDGET] || open == 0)) done = 1;      // loop guard, agents.py:236
+		s_ctr[C_DONE] = done;
 		const int n_cand = open < n_exp ? open : n_exp;
-		d.ctr[C_NCAND] = n_cand;
-		if (!SHARDED) d.ctr[C_NPOP] = done ? 0 : n_cand;
-		else d.ctr[C_NPOP] = 0;                                          // decided after the all-gather (k_shard_decide)
+		s_ctr[C_NCAND] = n_cand;
+		if (!SHARDED) s_ctr[C_NPOP] = done ? 0 : n_cand;
+		else s_ctr[C_NPOP] = 0;                                          // decided after the all-gather (k_shard_decide)
 		s_ncand = n_cand; s_nexp = n_exp;
 	}
 	__syncthreads();
-	pop_select(d, s_meta, s_ncand, s_nexp);
+	if (tid < C_COUNT) d.ctr[tid] = s_ctr[tid];
+	else if (tid >= 64 && tid < 64 + 4 * QL) d.q.meta[tid - 64] = s_meta[tid - 64];
+	__syncthreads();
+	pop_select(d, s_meta, s_ncand, s_nexp, s_heads);
 	if (SHARDED) {
 		// this rank's contribution to the all-gather: pool size, win flag, solved index, error, then the candidate costs
 		__syncthreads();
 		double *g = d.gather_in;
 		if (tid == 0) {
-			g[0] = (double)d.ctr[C_NSTATES]; g[1] = (double)d.ctr[C_WON]; g[2] = (double)d.ctr[C_SOLVED]; g[3] = (double)d.ctr[C_ERROR];
+			g[0] = (double)s_ctr[C_NSTATES]; g[1] = (double)s_ctr[C_WON]; g[2] = (double)s_ctr[C_SOLVED]; g[3] = (double)s_ctr[C_ERROR];
 			g[4] = (double)s_ncand; g[6] = 0.0; g[7] = 0.0;              // g[5] = elapsed seconds, written by the host of rank 0
 		}
 		for (int i = tid; i < d.N; i += blockDim.x) g[8 + i] = i < s_ncand ? key_to_double(d.cand_key[i]) : INFINITY;
@@ -576,7 +663,7 @@ void k_pop_select_only(AstarDev d, int n_exp)
 		s_ncand = n_cand;
 	}
 	__syncthreads();
-	pop_select(d, s_meta, s_ncand, n_exp);
+	pop_select(d, s_meta, s_ncand, n_exp, nullptr);
 }
 
 __global__ void k_set_budget(AstarDev d, int budget)
@@ -705,16 +792,16 @@ void k_shard_decide(AstarDev d, const double *gathered, double time_limit, doubl
 }
 
 // expand this rank's share and bucket the child records by owner, stable, in one launch
-__global__ __launch_bounds__(SCAN_BLOCK)
+__global__ __launch_bounds__(ASCAN)
 void k_shard_expand(AstarDev d, uint8_t *send)
 {
 	__shared__ u32x4 s_act[36];
-	__shared__ int s_wave[16];
+	__shared__ int s_wave[4];
 	__shared__ int s_ticket, s_base;
 	stage_action_tables(s_act, threadIdx.x);
 	const int b = scan_ticket(&d.ctr[C_TICKET1], &s_ticket);
 	const int n_pop = d.ctr[C_NPOP], K = 12 * n_pop;
-	const int c = b * SCAN_BLOCK + threadIdx.x;
+	const int c = b * ASCAN + threadIdx.x;
 	const bool valid = c < K;
 	uint32_t s[5] = {0, 0, 0, 0, 0}, meta6 = 0, p = 0, owner = 0xFFFFFFFFu;
 	if (valid) {
@@ -731,8 +818,8 @@ void k_shard_expand(AstarDev d, uint8_t *send)
 	const uint32_t epoch = (uint32_t)d.ctr[C_EPOCH] + 1u;
 	for (int w = 0; w < d.world; w++) {                                  // world <= 8 on a node: one ballot round per owner
 		int total;
-		const int r = block_rank(owner == (uint32_t)w, s_wave, &total);
-		const int base = scan_chain(d.chain1 + (size_t)w * gridDim.x, b, total, epoch, &s_base);
+		const int r = block_rank256(owner == (uint32_t)w, s_wave, &total);
+		const int base = scan_lookback(d.chain1 + (size_t)w * gridDim.x, b, total, epoch, &s_base);
 		uint8_t *blk = send + (size_t)w * shard_block_bytes(d.K);
 		if (owner == (uint32_t)w) {
 			u32x4 *dst = reinterpret_cast<u32x4 *>(blk + 32 + (size_t)(base + r) * 32);
@@ -779,13 +866,13 @@ __global__ void k_shard_offers_in(AstarDev d, const uint8_t *recv, int phase)
 
 // receiver side of relaxation case 2: build the offers of this iteration's first-seen children, bucketed by the rank
 // that owns the parent (stable), into the offer areas of the send blocks; also clears the marks this batch set.
-__global__ __launch_bounds__(SCAN_BLOCK)
+__global__ __launch_bounds__(ASCAN)
 void k_shard_offers(AstarDev d, const uint8_t *recv, uint8_t *send)
 {
-	__shared__ int s_wave[16];
+	__shared__ int s_wave[4];
 	__shared__ int s_ticket, s_base;
 	const int b = scan_ticket(&d.ctr[C_TICKET2], &s_ticket);
-	const int c = b * SCAN_BLOCK + threadIdx.x;
+	const int c = b * ASCAN + threadIdx.x;
 	const bool live = !d.ctr[C_DONE] && !d.ctr[C_WON];
 	uint32_t dst_rank = 0xFFFFFFFFu;
 	u32x4 rec = {0u, 0u, 0u, 0u};
@@ -803,8 +890,8 @@ void k_shard_offers(AstarDev d, const uint8_t *recv, uint8_t *send)
 	const uint32_t epoch = (uint32_t)d.ctr[C_EPOCH] + 1u;
 	for (int w = 0; w < d.world; w++) {
 		int total;
-		const int r = block_rank(dst_rank == (uint32_t)w, s_wave, &total);
-		const int base = scan_chain(d.chain2 + (size_t)w * gridDim.x, b, total, epoch, &s_base);
+		const int r = block_rank256(dst_rank == (uint32_t)w, s_wave, &total);
+		const int base = scan_lookback(d.chain2 + (size_t)w * gridDim.x, b, total, epoch, &s_base);
 		uint8_t *blk = send + (size_t)w * shard_block_bytes(d.K);
 		if (dst_rank == (uint32_t)w)
 			*reinterpret_cast<u32x4 *>(blk + 32 + (size_t)d.K * 32 + (size_t)(base + r) * 16) = rec;
@@ -867,12 +954,15 @@ template <bool SHARDED>
 void launch_append(rk_astar *h, const uint8_t *recv, void *d_onehot, int out_dtype, hipStream_t st)
 {
 	const AstarDev &d = h->d;
-	const unsigned nb = blocks(SHARDED ? (size_t)d.KI : (size_t)d.K, SCAN_BLOCK);
-	if (d_onehot != nullptr && out_dtype == RK_OH_F32)
-		hipLaunchKernelGGL((k_append<SHARDED, 4>), dim3(nb), dim3(SCAN_BLOCK), 0, st, d, recv, (u32x4 *)d_onehot, 0x3F800000u);
-	else
-		hipLaunchKernelGGL((k_append<SHARDED, 2>), dim3(nb), dim3(SCAN_BLOCK), 0, st, d, recv, (u32x4 *)d_onehot,
-		                   out_dtype == RK_OH_F16 ? 0x3C00u : 0x3F80u);
+	const size_t kin = SHARDED ? (size_t)d.KI : (size_t)d.K;
+	hipLaunchKernelGGL((k_append<SHARDED>), dim3(blocks(kin, ASCAN)), dim3(ASCAN), 0, st, d, recv);
+	if (d_onehot == nullptr) return;
+	// about one 16-byte store per thread: the grid covers the largest possible batch
+	const size_t chunks = kin * (out_dtype == RK_OH_F32 ? 120 : out_dtype == RK_OH_STATES ? 2 : 60);
+	const unsigned grid = std::min<unsigned>(blocks(chunks), 8192u);
+	if (out_dtype == RK_OH_F32) hipLaunchKernelGGL((k_new_rows<4>), dim3(grid), dim3(256), 0, st, d, (u32x4 *)d_onehot, 0x3F800000u);
+	else if (out_dtype == RK_OH_STATES) hipLaunchKernelGGL((k_new_rows<0>), dim3(grid), dim3(256), 0, st, d, (u32x4 *)d_onehot, 0u);
+	else hipLaunchKernelGGL((k_new_rows<2>), dim3(grid), dim3(256), 0, st, d, (u32x4 *)d_onehot, out_dtype == RK_OH_F16 ? 0x3C00u : 0x3F80u);
 }
 
 // records + sort + merge passes + queue insert + end of iteration; returns through the launches only
@@ -880,12 +970,15 @@ template <bool SHARDED>
 int launch_commit(rk_astar *h, const float *d_values, const uint8_t *recv, hipStream_t st)
 {
 	const AstarDev &d = h->d;
-	const int n_chunks = d.Kpad / SORT_CHUNK;
-	hipLaunchKernelGGL((k_records_sort<SHARDED>), dim3(n_chunks), dim3(1024), 0, st, d, d_values, recv);
 	int from = 0;
-	for (int L = SORT_CHUNK; L < d.Kpad; L <<= 1) {
-		hipLaunchKernelGGL(k_merge_pass, dim3(blocks(d.Kpad)), dim3(256), 0, st, d, L, from);
-		from ^= 1;
+	if (d.chunk == SMALL_CHUNK) {
+		hipLaunchKernelGGL((k_records_sort<SHARDED, SMALL_CHUNK>), dim3(d.Kpad / SMALL_CHUNK), dim3(SMALL_CHUNK / 2), 0, st, d, d_values, recv);
+	} else {
+		hipLaunchKernelGGL((k_records_sort<SHARDED, SORT_CHUNK>), dim3(d.Kpad / SORT_CHUNK), dim3(SORT_CHUNK / 2), 0, st, d, d_values, recv);
+		for (int L = SORT_CHUNK; L < d.Kpad; L <<= 1) {
+			hipLaunchKernelGGL(k_merge_pass, dim3(blocks(d.Kpad)), dim3(256), 0, st, d, L, from);
+			from ^= 1;
+		}
 	}
 	// when the new records fit one chunk the passes are no-ops and the sorted run is in rec0
 	const unsigned grid = std::min<unsigned>(1024u, std::max<unsigned>(blocks((size_t)d.Kpad * 4), 8u));
@@ -912,7 +1005,8 @@ static int astar_create_impl(rk_astar_t **out, size_t capacity, int max_expansio
 	d.N = max_expansions; d.K = 12 * max_expansions;
 	d.KI = d.K * world;                                   // a rank can receive every rank's children
 	const int kin = world == 1 ? d.K : d.KI;
-	d.Kpad = ((kin + SORT_CHUNK - 1) / SORT_CHUNK) * SORT_CHUNK;
+	d.chunk = kin <= SORT_CHUNK ? SMALL_CHUNK : SORT_CHUNK;
+	d.Kpad = ((kin + d.chunk - 1) / d.chunk) * d.chunk;
 	d.cap1 = (uint32_t)(capacity + 1);
 	uint64_t t = 1024;
 	while (t < 2 * (uint64_t)capacity + 2) t <<= 1;
@@ -926,7 +1020,7 @@ static int astar_create_impl(rk_astar_t **out, size_t capacity, int max_expansio
 	A(children, (size_t)d.K * 5 + 64); A(solved, (size_t)d.K + 64);
 	A(seen, KS); A(child_slot, KS); A(flags, KS); A(rank_local, 16); A(newway, KS); A(shortcut, KS); A(val1, KS); A(val2, KS);
 	A(rec0, (size_t)d.Kpad + 16); A(rec1, (size_t)d.Kpad + 16);
-	const size_t n_scan_blocks = (KS + SCAN_BLOCK - 1) / SCAN_BLOCK + 1;
+	const size_t n_scan_blocks = (KS + ASCAN - 1) / ASCAN + 1;
 	A(chain0, n_scan_blocks); A(chain1, n_scan_blocks * (size_t)world); A(chain2, n_scan_blocks * (size_t)world);
 	A(hit, KS); A(gather_in, (size_t)d.N + 16);
 	#undef A
@@ -982,7 +1076,7 @@ static int astar_reset_impl(rk_astar_t *h, const int8_t *h_start_state, double l
 	RK_HIP(hipMemsetAsync(d.table, 0, ((size_t)d.mask + 1) * sizeof(uint32_t), st));
 	RK_HIP(hipMemsetAsync(d.mark, 0xFF, (h->cap + 1) * sizeof(uint32_t), st));
 	// chained-scan epochs restart with the iteration counter: forget the words of the previous search
-	const size_t n_scan_blocks = ((size_t)(d.world == 1 ? d.K : d.KI) + 64 + SCAN_BLOCK - 1) / SCAN_BLOCK + 1;
+	const size_t n_scan_blocks = ((size_t)(d.world == 1 ? d.K : d.KI) + 64 + ASCAN - 1) / ASCAN + 1;
 	RK_HIP(hipMemsetAsync(d.chain0, 0, n_scan_blocks * sizeof(unsigned long long), st));
 	RK_HIP(hipMemsetAsync(d.chain1, 0, n_scan_blocks * d.world * sizeof(unsigned long long), st));
 	RK_HIP(hipMemsetAsync(d.chain2, 0, n_scan_blocks * d.world * sizeof(unsigned long long), st));
@@ -1019,7 +1113,7 @@ int rk_astar_step_expand(rk_astar_t *h, void *d_onehot, int out_dtype, void *str
 	if (h->d.world != 1) return fail(RK_ESTATE, "rk_astar_step_expand: sharded engines use rk_astar_shard_*");
 	if (h->pending) return fail(RK_ESTATE, "rk_astar_step_expand: previous iteration not committed");
 	if (d_onehot && (reinterpret_cast<uintptr_t>(d_onehot) & 15)) return fail(RK_EINVAL, "rk_astar_step_expand: one-hot buffer must be 16-byte aligned");
-	if (out_dtype < RK_OH_F32 || out_dtype > RK_OH_BF16) return fail(RK_EINVAL, "rk_astar_step_expand: unknown dtype %d", out_dtype);
+	if (out_dtype < RK_OH_F32 || out_dtype > RK_OH_STATES) return fail(RK_EINVAL, "rk_astar_step_expand: unknown dtype %d", out_dtype);
 	hipStream_t st = (hipStream_t)stream;
 	const AstarDev &d = h->d;
 	hipLaunchKernelGGL(k_expand_lookup, dim3(blocks((size_t)12 * h->n_exp)), dim3(256), 0, st, d);
@@ -1260,7 +1354,7 @@ int rk_astar_shard_select(rk_astar_t *h, const void *d_gathered, double time_lim
 	hipStream_t st = (hipStream_t)stream;
 	const AstarDev &d = h->d;
 	hipLaunchKernelGGL(k_shard_decide, dim3(1), dim3(1024), 0, st, d, (const double *)d_gathered, time_limit, max_states, h->decision);
-	hipLaunchKernelGGL(k_shard_expand, dim3(blocks((size_t)d.K, SCAN_BLOCK)), dim3(SCAN_BLOCK), 0, st, d, (uint8_t *)d_send);
+	hipLaunchKernelGGL(k_shard_expand, dim3(blocks((size_t)d.K, ASCAN)), dim3(ASCAN), 0, st, d, (uint8_t *)d_send);
 	RK_HIP(hipGetLastError());
 	return RK_OK;
 }
@@ -1300,7 +1394,7 @@ int rk_astar_shard_push(rk_astar_t *h, const float *d_values, const void *d_recv
 	hipStream_t st = (hipStream_t)stream;
 	const AstarDev &d = h->d;
 	const int from = launch_commit<true>(h, d_values, (const uint8_t *)d_recv, st);
-	hipLaunchKernelGGL(k_shard_offers, dim3(blocks((size_t)d.KI, SCAN_BLOCK)), dim3(SCAN_BLOCK), 0, st, d, (const uint8_t *)d_recv, (uint8_t *)d_send);
+	hipLaunchKernelGGL(k_shard_offers, dim3(blocks((size_t)d.KI, ASCAN)), dim3(ASCAN), 0, st, d, (const uint8_t *)d_recv, (uint8_t *)d_send);
 	hipLaunchKernelGGL((k_end<true>), dim3(1), dim3(1024), 0, st, d, from, 1);
 	RK_HIP(hipGetLastError());
 	h->pending = false;

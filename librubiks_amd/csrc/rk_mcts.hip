@@ -239,8 +239,13 @@ void k_mcts_backup_select(MctsDev d, const float *probs, const float *values)
 	for (int e = lane; e < plen - 1; e += 64) {
 		const int act = pacts[e];
 		const Node nd = node_of(d, node0, pnodes[e]);
-		if (has_new && best > nd.W()[act]) nd.W()[act] = best;             // agents.py:562
-		if (atomicExch(&nd.stamp()[act], sim) != sim) nd.N()[act] += 1;    // agents.py:568 (a repeated pair counts once)
+		// the three reads of the record travel together (one round trip instead of three dependent ones); a pair that
+		// occurs twice on the path has its second exchange return `sim`, so its stale read of N is never written back
+		const double w = nd.W()[act];
+		const int cnt = nd.N()[act];
+		const int last = atomicExch(&nd.stamp()[act], sim);
+		if (has_new && best > w) nd.W()[act] = best;                       // agents.py:562
+		if (last != sim) nd.N()[act] = cnt + 1;                            // agents.py:568 (a repeated pair counts once)
 		nd.L()[act] = 0.0;                                                 // agents.py:569
 		node_of(d, node0, pnodes[e + 1]).L()[act ^ 1] = 0.0;               // agents.py:570
 	}

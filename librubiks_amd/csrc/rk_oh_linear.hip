@@ -1,0 +1,279 @@
+// Fused one-hot -> first Linear layer of the value/policy net.
+//
+// The reference one-hot encodes every state into 480 floats (cube.py:265-277: oh[n, 24 i + state[n, i]] = 1) and feeds
+// them to nn.Linear(480, H) (model.py:127 / :150, H = 4096 for fc_small): y = oh @ W^T + b.  A one-hot row has exactly 20
+// ones, so  y[n, :] = b + sum_i W^T[24 i + state[n, i], :]  -- the 1 920-byte (f32) or 960-byte (bf16) row never has to
+// exist in HBM.  Two routes, both reading the 20-byte states directly:
+//
+//   GATHER (exact f32)  a workgroup keeps a 64-column slice of W^T (480 x 64 f32 = 120 KB) in LDS and sums, for every
+//                       row, its 20 weight rows in the fixed order  ((b + w_0) + w_1) + ... + w_19  with plain f32 adds.
+//                       16 lanes x 16 B cover a 256-byte LDS row, so one ds_read_b128 wave-instruction serves four
+//                       batch rows conflict-free at the full 256 B/clk.  LDS-read bound: 20 x 256 B per (row, 64 columns).
+//   MFMA (bf16)         y = A B with v_mfma_f32_32x32x16_bf16 where the A operand (the one-hot tile) is SYNTHESISED IN
+//                       REGISTERS: lane (r, h) of a wave needs A[row r][k = 16 s + 8 h .. +7], eight consecutive one-hot
+//                       columns, which lie inside one cubie's 24 columns (8 | 24) -- so the fragment is "1.0 at position
+//                       state[row][cubie] - offset if that is in 0..7, else zeros": a byte extract and three compares.
+//                       Nothing of A touches LDS or HBM.  B = a 64-column tile of W (bf16, 64 x 480, 61 KB) stays in LDS
+//                       for all the rows a workgroup handles (row stride 976 B: 244 dwords = 52 mod 64, so the 16 lanes of
+//                       a ds_read_b128 group hit 16 different bank quads); accumulators start at the bias; the epilogue
+//                       rounds to bf16 (nearest even) and goes through LDS so that a wave stores whole 128-byte rows.
+//
+// Which one is faster where is measured by benchmarks/oh_linear.py (profiles/r02_oh_linear.json).
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <vector>
+
+#include "../../include/rubiks_hip.h"
+#include "rk_device.h"
+#include "rk_error.h"
+
+namespace rk {
+
+constexpr int OHL_K = 480;
+constexpr int OHL_TN = 64;                   // output columns per workgroup (both routes)
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t f32_to_bf16_rne(float x)
+{
+	uint32_t u = __builtin_bit_cast(uint32_t, x);
+	u += 0x7FFFu + ((u >> 16) & 1u);
+	return u >> 16;
+}
+
+// weight preparation: W (H, 480) in f32 or bf16 -> W^T (480, H) f32 and W (H, 480) bf16
+__global__ void k_ohl_prepare(const void *w, int w_is_bf16, int H, float *wt_f32, uint16_t *w_bf16)
+{
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= (size_t)H * OHL_K) return;
+	const size_t h = i / OHL_K, k = i - h * OHL_K;
+	float v;
+	if (w_is_bf16) v = __builtin_bit_cast(float, (uint32_t)reinterpret_cast<const uint16_t *>(w)[i] << 16);
+	else v = reinterpret_cast<const float *>(w)[i];
+	wt_f32[k * (size_t)H + h] = v;
+	w_bf16[i] = (uint16_t)f32_to_bf16_rne(v);
+}
+
+__global__ void k_ohl_bias(const void *b, int b_is_bf16, int H, float *out)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= H) return;
+	out[i] = b == nullptr ? 0.0f
+	       : b_is_bf16 ? __builtin_bit_cast(float, (uint32_t)reinterpret_cast<const uint16_t *>(b)[i] << 16)
+	                   : reinterpret_cast<const float *>(b)[i];
+}
+
+__device__ __forceinline__ uint32_t code_of(const uint32_t s5[5], int cubie)
+{
+	const uint32_t c = (s5[cubie >> 2] >> (8 * (cubie & 3))) & 0xFFu;
+	return c < 24u ? c : 23u;                 // states hold codes 0..23; never index past the weight slice
+}
+
+// ---- route GATHER ------------------------------------------------------------------------------------------------
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256)
+void k_ohl_gather(const uint32_t *__restrict__ states, const float *__restrict__ wt, const float *__restrict__ bias, void *__restrict__ out,
+                  size_t n, int H, size_t rows_per_group)
+{
+	__shared__ __attribute__((aligned(16))) float s_w[OHL_K * OHL_TN];       // 122 880 B: this workgroup's 64 columns of W^T
+	const int tid = threadIdx.x, c0 = blockIdx.x * OHL_TN;
+	for (int i = tid; i < OHL_K * (OHL_TN / 4); i += 256) {
+		const int k = i >> 4, q = i & 15;
+		reinterpret_cast<f32x4 *>(s_w)[i] = *reinterpret_cast<const f32x4 *>(wt + (size_t)k * H + c0 + 4 * q);
+	}
+	__syncthreads();
+	const int lane = tid & 63, wv = tid >> 6, sub = lane >> 4, q = lane & 15;
+	const f32x4 b = *reinterpret_cast<const f32x4 *>(bias + c0 + 4 * q);
+	const size_t r_begin = (size_t)blockIdx.y * rows_per_group;
+	const size_t r_end = r_begin + rows_per_group < n ? r_begin + rows_per_group : n;
+	uint32_t nxt[5] = {0u, 0u, 0u, 0u, 0u};
+	{
+		const size_t r = r_begin + (size_t)(wv * 4 + sub);
+		if (r < r_end) {
+			#pragma unroll
+			for (int j = 0; j < 5; j++) nxt[j] = states[r * 5 + j];
+		}
+	}
+	for (size_t r = r_begin + (size_t)(wv * 4 + sub); r < r_end; r += 16) {
+		uint32_t s5[5];
+		#pragma unroll
+		for (int j = 0; j < 5; j++) s5[j] = nxt[j];
+		if (r + 16 < r_end) {                                                // next row's states while this row is summed
+			#pragma unroll
+			for (int j = 0; j < 5; j++) nxt[j] = states[(r + 16) * 5 + j];
+		}
+		f32x4 acc = b;
+		#pragma unroll
+		for (int i = 0; i < 20; i++) {                                       // fixed order: ((b + w_0) + w_1) + ...
+			const f32x4 w = reinterpret_cast<const f32x4 *>(s_w)[(24 * i + (int)code_of(s5, i)) * 16 + q];
+			acc.x += w.x; acc.y += w.y; acc.z += w.z; acc.w += w.w;
+		}
+		if (OUT_BF16) {
+			u32x2 v;
+			v.x = f32_to_bf16_rne(acc.x) | (f32_to_bf16_rne(acc.y) << 16);
+			v.y = f32_to_bf16_rne(acc.z) | (f32_to_bf16_rne(acc.w) << 16);
+			*reinterpret_cast<u32x2 *>(reinterpret_cast<uint16_t *>(out) + r * (size_t)H + c0 + 4 * q) = v;
+		} else {
+			*reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(out) + r * (size_t)H + c0 + 4 * q) = acc;
+		}
+	}
+}
+
+// ---- route MFMA --------------------------------------------------------------------------------------------------
+constexpr int OHL_WROW = 976;                // bytes per LDS row of the W tile (480 bf16 + 16 B pad)
+constexpr int OHL_DROW = 144;                // bytes per LDS row of a wave's output staging (64 bf16 + 16 B pad)
+
+__global__ __launch_bounds__(256, 2)
+void k_ohl_mfma(const uint32_t *__restrict__ states, const uint16_t *__restrict__ wb, const float *__restrict__ bias, uint16_t *__restrict__ out,
+                size_t n, int H, size_t rows_per_group)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t s_w[OHL_TN * OHL_WROW];      // 62 464 B
+	__shared__ __attribute__((aligned(16))) uint8_t s_d[4][32 * OHL_DROW];       // 18 432 B
+	const int tid = threadIdx.x, c0 = blockIdx.x * OHL_TN;
+	for (int i = tid; i < OHL_TN * 60; i += 256) {
+		const int row = i / 60, ch = i - row * 60;
+		*reinterpret_cast<u32x4 *>(s_w + row * OHL_WROW + ch * 16) = *reinterpret_cast<const u32x4 *>(wb + (size_t)(c0 + row) * OHL_K + ch * 8);
+	}
+	__syncthreads();
+	const int lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
+	const float bias0 = bias[c0 + r], bias1 = bias[c0 + 32 + r];
+	const uint8_t *wrow0 = s_w + r * OHL_WROW + 16 * h, *wrow1 = s_w + (32 + r) * OHL_WROW + 16 * h;
+	uint8_t *stage = s_d[wv];
+	const size_t r_begin = (size_t)blockIdx.y * rows_per_group;
+	const size_t r_end = r_begin + rows_per_group < n ? r_begin + rows_per_group : n;
+	// the states of the NEXT row tile are requested before the current one is multiplied: with two waves per SIMD nothing
+	// else would hide the load latency (about twice the tile's MFMA time)
+	uint32_t nxt[5] = {0u, 0u, 0u, 0u, 0u};
+	{
+		const size_t m0 = r_begin + (size_t)wv * 32;
+		if (m0 < r_end) {
+			const size_t row = m0 + r < r_end ? m0 + r : r_end - 1;
+			#pragma unroll
+			for (int j = 0; j < 5; j++) nxt[j] = states[row * 5 + j];
+		}
+	}
+	for (size_t m0 = r_begin + (size_t)wv * 32; m0 < r_end; m0 += 128) {
+		uint32_t s5[5];
+		#pragma unroll
+		for (int j = 0; j < 5; j++) s5[j] = nxt[j];
+		if (m0 + 128 < r_end) {
+			const size_t row = m0 + 128 + r < r_end ? m0 + 128 + r : r_end - 1;     // tail rows repeat the last row (never stored)
+			#pragma unroll
+			for (int j = 0; j < 5; j++) nxt[j] = states[row * 5 + j];
+		}
+		f32x16 acc0, acc1;
+		#pragma unroll
+		for (int v = 0; v < 16; v++) { acc0[v] = bias0; acc1[v] = bias1; }
+		#pragma unroll
+		for (int ks = 0; ks < OHL_K / 16; ks++) {
+			// this lane's eight one-hot columns start at 16 ks + 8 h: inside cubie (16 ks + 8 h) / 24 at offset 0, 8 or 16
+			const int k_lo = 16 * ks, k_hi = 16 * ks + 8;
+			const int rel_lo = (int)code_of(s5, k_lo / 24) - k_lo % 24;
+			const int rel_hi = (int)code_of(s5, k_hi / 24) - k_hi % 24;
+			const int rel = h ? rel_hi : rel_lo;
+			const uint32_t one = (unsigned)rel < 8u ? 0x3F80u << (16 * (rel & 1)) : 0u;
+			const int slot = rel >> 1;
+			const u32x4 a = u32x4{slot == 0 ? one : 0u, slot == 1 ? one : 0u, slot == 2 ? one : 0u, slot == 3 ? one : 0u};
+			const u32x4 b0 = *reinterpret_cast<const u32x4 *>(wrow0 + 32 * ks);
+			const u32x4 b1 = *reinterpret_cast<const u32x4 *>(wrow1 + 32 * ks);
+			const bf16x8 A = __builtin_bit_cast(bf16x8, a);
+			acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(bf16x8, b0), acc0, 0, 0, 0);
+			acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(bf16x8, b1), acc1, 0, 0, 0);
+		}
+		// epilogue: C/D element v of lane (r, h) is row (v & 3) + 8 (v >> 2) + 4 h, column r
+		#pragma unroll
+		for (int v = 0; v < 16; v++) {
+			const int i = (v & 3) + 8 * (v >> 2) + 4 * h;
+			reinterpret_cast<uint16_t *>(stage + i * OHL_DROW)[r] = (uint16_t)f32_to_bf16_rne(acc0[v]);
+			reinterpret_cast<uint16_t *>(stage + i * OHL_DROW)[32 + r] = (uint16_t)f32_to_bf16_rne(acc1[v]);
+		}
+		wave_lds_fence();
+		#pragma unroll
+		for (int it = 0; it < 4; it++) {                                         // 32 rows x 128 B, 16 B per lane
+			const int idx = it * 64 + lane, i = idx >> 3, ch = idx & 7;
+			const u32x4 val = *reinterpret_cast<const u32x4 *>(stage + i * OHL_DROW + ch * 16);
+			if (m0 + i < r_end) *reinterpret_cast<u32x4 *>(out + (m0 + i) * (size_t)H + c0 + ch * 8) = val;
+		}
+		wave_lds_fence();
+	}
+}
+
+}  // namespace rk
+
+using namespace rk;
+
+struct rk_ohl {
+	int H = 0;
+	float *wt_f32 = nullptr, *bias = nullptr;
+	uint16_t *w_bf16 = nullptr;
+};
+
+extern "C" {
+
+int rk_ohl_create(rk_ohl_t **out, const void *d_weight, int w_dtype, const void *d_bias, int H, void *stream)
+{
+	if (!out || !d_weight) return fail(RK_EINVAL, "rk_ohl_create: null argument");
+	if (w_dtype != RK_OH_F32 && w_dtype != RK_OH_BF16) return fail(RK_EINVAL, "rk_ohl_create: weights must be float32 or bfloat16");
+	if (H < OHL_TN || H % OHL_TN != 0 || H > (1 << 20)) return fail(RK_EINVAL, "rk_ohl_create: out_features %d must be a positive multiple of %d", H, OHL_TN);
+	rk_ohl *h = new rk_ohl();
+	h->H = H;
+	hipStream_t st = (hipStream_t)stream;
+	hipError_t e = hipMalloc((void **)&h->wt_f32, (size_t)H * OHL_K * sizeof(float));
+	if (e == hipSuccess) e = hipMalloc((void **)&h->w_bf16, (size_t)H * OHL_K * sizeof(uint16_t));
+	if (e == hipSuccess) e = hipMalloc((void **)&h->bias, (size_t)H * sizeof(float));
+	if (e != hipSuccess) { rk_ohl_destroy(h); return fail(RK_EHIP, "rk_ohl_create: hipMalloc failed: %s", hipGetErrorString(e)); }
+	const size_t total = (size_t)H * OHL_K;
+	hipLaunchKernelGGL(k_ohl_prepare, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_weight, w_dtype == RK_OH_BF16 ? 1 : 0, H, h->wt_f32, h->w_bf16);
+	hipLaunchKernelGGL(k_ohl_bias, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, st, d_bias, w_dtype == RK_OH_BF16 ? 1 : 0, H, h->bias);
+	RK_HIP(hipGetLastError());
+	RK_HIP(hipStreamSynchronize(st));              // the caller's weight tensor may go away
+	*out = h;
+	return RK_OK;
+}
+
+int rk_ohl_destroy(rk_ohl_t *h)
+{
+	if (!h) return RK_OK;
+	(void)hipFree(h->wt_f32); (void)hipFree(h->w_bf16); (void)hipFree(h->bias);
+	delete h;
+	return RK_OK;
+}
+
+int rk_ohl_forward(rk_ohl_t *h, const int8_t *d_states, void *d_out, int out_dtype, size_t n, int route, void *stream)
+{
+	if (!h) return fail(RK_EINVAL, "rk_ohl_forward: null handle");
+	if (n == 0) return RK_OK;
+	if (!d_states || !d_out) return fail(RK_EINVAL, "rk_ohl_forward: null pointer");
+	if ((reinterpret_cast<uintptr_t>(d_states) & 3) || (reinterpret_cast<uintptr_t>(d_out) & 15))
+		return fail(RK_EINVAL, "rk_ohl_forward: states must be 4-byte and the output 16-byte aligned");
+	if (route != RK_OHL_GATHER && route != RK_OHL_MFMA) return fail(RK_EINVAL, "rk_ohl_forward: unknown route %d", route);
+	if (out_dtype != RK_OH_F32 && out_dtype != RK_OH_BF16) return fail(RK_EINVAL, "rk_ohl_forward: output must be float32 or bfloat16");
+	if (route == RK_OHL_MFMA && out_dtype != RK_OH_BF16) return fail(RK_EINVAL, "rk_ohl_forward: the MFMA route writes bfloat16");
+	hipStream_t st = (hipStream_t)stream;
+	const unsigned col_tiles = (unsigned)(h->H / OHL_TN);
+	// about one workgroup per CU (gather: 120 KB of LDS each) or two (MFMA): the weight slice is loaded once per workgroup
+	const size_t quantum = route == RK_OHL_MFMA ? 128 : 16;
+	size_t groups = (route == RK_OHL_MFMA ? 512u : 256u) / col_tiles;
+	if (groups < 1) groups = 1;
+	const size_t max_groups = (n + quantum - 1) / quantum;
+	if (groups > max_groups) groups = max_groups;
+	if (groups > 65535) groups = 65535;
+	size_t rows = (n + groups - 1) / groups;
+	rows = (rows + quantum - 1) / quantum * quantum;
+	groups = (n + rows - 1) / rows;
+	const dim3 grid(col_tiles, (unsigned)groups);
+	if (route == RK_OHL_GATHER) {
+		if (out_dtype == RK_OH_F32)
+			hipLaunchKernelGGL(k_ohl_gather<false>, grid, dim3(256), 0, st, (const uint32_t *)d_states, h->wt_f32, h->bias, d_out, n, h->H, rows);
+		else
+			hipLaunchKernelGGL(k_ohl_gather<true>, grid, dim3(256), 0, st, (const uint32_t *)d_states, h->wt_f32, h->bias, d_out, n, h->H, rows);
+	} else {
+		hipLaunchKernelGGL(k_ohl_mfma, grid, dim3(256), 0, st, (const uint32_t *)d_states, h->w_bf16, h->bias, (uint16_t *)d_out, n, h->H, rows);
+	}
+	RK_HIP(hipGetLastError());
+	return RK_OK;
+}
+
+}  // extern "C"

@@ -88,13 +88,36 @@ __device__ __forceinline__ int block_rank(bool pred, int *s_wave /* [16] */, int
 	return before + in_wave;
 }
 
-// ---- order-preserving compaction across workgroups in ONE launch: chained scan with tickets --------------------------
+// ---- order-preserving compaction across workgroups in ONE launch: tickets + look-back --------------------------------
 // Every workgroup draws a ticket (so that "predecessor" means "started earlier": no deadlock whatever the dispatch
-// order), computes its local total, waits for its predecessor's inclusive prefix and publishes its own.  A prefix word
-// is {epoch : 32 | value : 32} written with ONE 64-bit agent-scope store and polled with agent-scope loads; the epoch
-// makes words of earlier launches invisible, so nothing has to be cleared except the ticket counter (the engine's
-// end-of-iteration kernel does that).  The word carries its payload itself, so no fence is needed
-// (MI355X_MICROARCH.md: a naturally aligned 8-byte granule written by one store).
+// order), publishes its local total at once and then sums the totals of ALL its predecessors, 64 at a time with one wave
+// (a decoupled look-back without the prefix hand-over: nobody waits for a chain, only for words that are published
+// before any waiting starts).  A word is {epoch : 32 | total : 32} written with ONE 64-bit agent-scope store and polled
+// with agent-scope loads; the epoch makes the words of earlier launches invisible, so nothing has to be cleared except
+// the ticket counter (the engine's end-of-iteration kernel does that).  The word carries its payload itself, so no
+// fence is needed (MI355X_MICROARCH.md: a naturally aligned 8-byte granule written by one store).
+constexpr int ASCAN = 256;                        // threads (= items) per workgroup of these compactions
+
+// exclusive prefix of a 0/1 predicate inside a 256-thread workgroup; *total = number of set predicates
+__device__ __forceinline__ int block_rank256(bool pred, int *s_wave /* [4] */, int *total)
+{
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const unsigned long long b = __ballot(pred);
+	const int in_wave = __popcll(b & ((1ull << lane) - 1ull));
+	__syncthreads();                                  // s_wave may still be read from a previous call
+	if (lane == 0) s_wave[wv] = __popcll(b);
+	__syncthreads();
+	int before = 0, tot = 0;
+	#pragma unroll
+	for (int w = 0; w < 4; w++) {
+		const int v = s_wave[w];
+		before += w < wv ? v : 0;
+		tot += v;
+	}
+	*total = tot;
+	return before + in_wave;
+}
+
 __device__ __forceinline__ int scan_ticket(int32_t *ticket_ctr, int *s_ticket)
 {
 	if (threadIdx.x == 0) *s_ticket = atomicAdd(ticket_ctr, 1);
@@ -102,22 +125,29 @@ __device__ __forceinline__ int scan_ticket(int32_t *ticket_ctr, int *s_ticket)
 	return *s_ticket;
 }
 
-// exclusive prefix of `total` over tickets 0..b-1; publishes the inclusive prefix of ticket b.  Call from ALL threads
-// of the workgroup (it contains barriers); s_base is one int of LDS.
-__device__ __forceinline__ int scan_chain(unsigned long long *words, int b, int total, uint32_t epoch, int *s_base)
+// exclusive prefix of `total` over tickets 0..b-1.  Call from ALL threads of the workgroup (it contains a barrier);
+// s_base is one int of LDS.
+__device__ __forceinline__ int scan_lookback(unsigned long long *words, int b, int total, uint32_t epoch, int *s_base)
 {
-	if (threadIdx.x == 0) {
-		int base = 0;
-		if (b > 0) {
-			unsigned long long w;
-			do {
-				w = __hip_atomic_load(&words[b - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				if ((uint32_t)(w >> 32) != epoch) __builtin_amdgcn_s_sleep(1);
-			} while ((uint32_t)(w >> 32) != epoch);
-			base = (int)(uint32_t)w;
+	if (threadIdx.x == 0)
+		__hip_atomic_store(&words[b], ((unsigned long long)epoch << 32) | (uint32_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if (threadIdx.x < 64) {                           // wave 0 sums the predecessors' totals, 64 per round
+		int sum = 0;
+		for (int j0 = 0; j0 < b; j0 += 64) {
+			const int j = j0 + (int)threadIdx.x;
+			if (j < b) {
+				unsigned long long w;
+				for (;;) {
+					w = __hip_atomic_load(&words[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if ((uint32_t)(w >> 32) == epoch) break;
+					__builtin_amdgcn_s_sleep(1);
+				}
+				sum += (int)(uint32_t)w;
+			}
 		}
-		__hip_atomic_store(&words[b], ((unsigned long long)epoch << 32) | (uint32_t)(base + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		*s_base = base;
+		#pragma unroll
+		for (int m = 32; m > 0; m >>= 1) sum += __shfl_xor(sum, m, 64);
+		if (threadIdx.x == 0) *s_base = sum;
 	}
 	__syncthreads();
 	return *s_base;

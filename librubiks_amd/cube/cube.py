@@ -164,12 +164,23 @@ class device:
 	`states` are int8 (n, 20) [or (n, 6, 8, 6)], contiguous.  These are thin wrappers over the C ABI.
 	"""
 
+	#: Device-pointer entries take action codes as they are: the kernels treat a code >= 12 as action 0 so that they
+	#: never index past the move table, but the result is then meaningless (the host paths raise IndexError, as the
+	#: reference's table indexing would).  Set to True to pay one reduction + sync per call and get the IndexError.
+	check_actions = False
+
+	@staticmethod
+	def _validate(actions: torch.Tensor):
+		if device.check_actions and actions.numel() and int(actions.max()) >= 12:
+			raise IndexError(f"action code {int(actions.max())} outside 0..11")
+
 	@staticmethod
 	def multi_rotate(states: torch.Tensor, actions: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
-		"""out[i] = move actions[i] (uint8 action index) applied to states[i]   (cube.py:256-263)."""
+		"""out[i] = move actions[i] (uint8 action index, 0..11) applied to states[i]   (cube.py:256-263)."""
 		_ffi.require_gpu()
 		_check_dev(states, torch.int8, "states")
 		_check_dev(actions, torch.uint8, "actions")
+		device._validate(actions)
 		n = len(states)
 		if len(actions) != n:
 			raise ValueError(f"{n} states but {len(actions)} actions")
@@ -272,6 +283,7 @@ class device:
 		"""actions uint8 (depth, games) -> states of every game along its move sequence (cube.py:218-232)."""
 		_ffi.require_gpu()
 		_check_dev(actions, torch.uint8, "actions")
+		device._validate(actions)
 		depth, games = actions.shape
 		moves = depth - int(with_solved)
 		rows = 1 if only_last else moves + int(with_solved)

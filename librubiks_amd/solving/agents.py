@@ -267,8 +267,15 @@ class AStar(DeepAgent):
 	default_capacity = 4_000_000
 	max_capacity = 64_000_000
 
-	def __init__(self, net, lambda_: float, expansions: int, capacity: int = None, poll: int = 4, use_hipgraph: bool = False):
+	def __init__(self, net, lambda_: float, expansions: int, capacity: int = None, poll: int = 4, use_hipgraph: bool = False,
+	             fused_first_layer: bool = False):
 		super().__init__(net)
+		# fused_first_layer: the engine hands the net the new nodes' 20-byte states and the net's first Linear(480, H)
+		# reads them directly (librubiks_amd.oh_linear) -- no one-hot batch exists at all
+		self._from_states = None
+		if fused_first_layer:
+			from librubiks_amd.oh_linear import fuse_first_linear
+			self._from_states = fuse_first_linear(net)
 		self.lambda_ = lambda_
 		self.expansions = int(expansions)
 		self.capacity = capacity
@@ -319,7 +326,7 @@ class AStar(DeepAgent):
 	def _iteration(self, h, oh, code):
 		lib = _ffi.lib()
 		_ffi.check(lib.rk_astar_step_expand(h, oh.data_ptr(), code, _ffi.stream_ptr()))
-		values = _value_f32(self.net(oh, policy=False, value=True))
+		values = _value_f32((self._from_states or self.net)(oh, policy=False, value=True))
 		self._keep = values                # the commit kernels read it after this call returns
 		_ffi.check(lib.rk_astar_step_commit(h, values.data_ptr(), _ffi.stream_ptr()))
 
@@ -334,9 +341,12 @@ class AStar(DeepAgent):
 		K = 12 * self.expansions
 		cap = max(int(min(max_states, self.capacity or self.default_capacity)), K + 2)
 		lib = _ffi.lib()
-		oh_dtype = _oh_dtype(self.net)
-		oh = torch.zeros((K, 480), dtype=oh_dtype, device=gpu)
-		code = _OH_CODES[oh_dtype]
+		if self._from_states is not None:
+			oh, code = torch.from_numpy(cube.repeat_state(cube.get_solved(), K)).to(gpu), _ffi.OH_STATES      # (K, 20) int8: valid codes everywhere
+		else:
+			oh_dtype = _oh_dtype(self.net)
+			oh = torch.zeros((K, 480), dtype=oh_dtype, device=gpu)
+			code = _OH_CODES[oh_dtype]
 		status = (C.c_longlong * 8)()
 		while True:
 			h = self._engine(cap)
