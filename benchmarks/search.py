@@ -44,7 +44,7 @@ def bench_astar(args):
 	rows = []
 	for timed in (False, True):
 		use = TimedNet(net) if timed else net
-		agent = AStar(use, args.lam, args.expansions)
+		agent = AStar(use, args.lam, args.expansions, fused_first_layer=bool(args.fused) and not timed)
 		tot_t = tot_states = tot_iter = solved = 0
 		for g in range(args.games):
 			np.random.seed(g)
@@ -123,7 +123,7 @@ def bench_mcts(args):
 		starts.append(s)
 	starts = np.array(starts)
 	cap = args.sims * 12 + 64
-	agent = MCTSBatch(net, args.c, T, capacity=cap, max_path=args.max_path)
+	agent = MCTSBatch(net, args.c, T, capacity=cap, max_path=args.max_path, fused_first_layer=bool(args.fused))
 	torch.cuda.synchronize()
 	t0 = time.perf_counter()
 	solved = agent.search(starts, max_states=cap, max_sims=args.sims, use_graph=bool(args.graph), poll=args.poll)
@@ -131,7 +131,7 @@ def bench_mcts(args):
 	dt = time.perf_counter() - t0
 	st = agent.status
 	row = {"bench": "mcts", "config": f"{T} trees x {args.sims} sims, depth-{args.depth} scrambles, c={args.c}, fc_small random init {'bf16' if args.bf16 else 'fp32'}, "
-	       f"hipGraph={'on' if args.graph else 'off'}", "seconds": dt, "tree_sims": int(st[:, 3].sum()), "tree_sims_per_s": float(st[:, 3].sum()) / dt,
+	       f"hipGraph={'on' if args.graph else 'off'}" + (", first layer fused (rk_ohl)" if args.fused else ""), "seconds": dt, "tree_sims": int(st[:, 3].sum()), "tree_sims_per_s": float(st[:, 3].sum()) / dt,
 	       "steps": agent.simulations, "ms_per_step": dt / agent.simulations * 1e3, "solved": int(solved.sum()), "states": int(st[:, 2].sum()),
 	       "states_per_s": float(st[:, 2].sum()) / dt, "max_path_len": int(st[:, 4].max())}
 	print(json.dumps(row), flush=True)
@@ -149,6 +149,7 @@ if __name__ == "__main__":
 	ap.add_argument("--max-states", type=int, default=150_000)
 	ap.add_argument("--lam", type=float, default=0.16)
 	ap.add_argument("--bf16", type=int, default=0)
+	ap.add_argument("--fused", type=int, default=0, help="first Linear reads the 20-byte states (rk_ohl_*), no one-hot batch")
 	ap.add_argument("--trees", type=int, default=256)
 	ap.add_argument("--sims", type=int, default=4096)
 	ap.add_argument("--c", type=float, default=0.6)

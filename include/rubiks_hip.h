@@ -157,7 +157,7 @@ int rk_as_correct686(const int8_t *d_states, float *d_out, size_t n, void *strea
  *                          reference returns before relaxing), bookkeeping and the next pop list
  *   rk_astar_status      : synchronises; h_status[8] = done, won, n_states, iterations, open-queue length, index of the
  *                          solved state, error, nodes the next iteration pops
- * Five launches per iteration (plus merge passes when 12 N > 2048), fixed shapes: an iteration can be captured in a
+ * Six launches per iteration (plus merge passes when 12 N > 2048), fixed shapes: an iteration can be captured in a
  * hipGraph.  Once `done` (won, out of budget, queue empty) further steps are no-ops.  Results are identical to the
  * reference's arrays (same index numbering, G, parents, parent_actions) whenever the value net returns the same
  * numbers.  An engine handle is not thread-safe: one host thread drives it, on one stream at a time. */
@@ -267,7 +267,8 @@ int rk_astar_shard_parent(rk_astar_t *h, long long index, long long *h_out, void
  *                         new indices in action order (:517-529), neighbor links both ways and leaf flag (:533-536),
  *                         goal test of ALL children, first solved wins (:540-543).  Leaves the 12 children of every
  *                         tree in a (T*12, 20) buffer.
- *   rk_mcts_children_oh   one-hot of that buffer, (T*12, 480): the fixed-shape net batch
+ *   rk_mcts_children_oh   one-hot of that buffer, (T*12, 480): the fixed-shape net batch (out_dtype RK_OH_STATES: the
+ *                         (T*12, 20) int8 states themselves, for a net whose first layer is fused, rk_ohl_*)
  *   rk_mcts_backup_select P, V of the new children (:556-557), W[leaf] = V[neighbors], W[new] = v, max-backup of
  *                         max(v_new) along the path (:559-562), N += 1 once per distinct (node, action) of the path,
  *                         virtual loss cleared (:567-570); then, unless the tree just solved, the next descent

@@ -18,15 +18,17 @@
 // O(log(|open| / K)) merges, so an iteration moves O(K log) queue bytes instead of re-merging all of |open|
 // (round 1 merged the whole queue, 16 B x |open|, every iteration).
 //
-// One iteration (agents.py:236-252 + 254-331) is FIVE launches around the net forward, none of which synchronises:
+// One iteration (agents.py:236-252 + 254-331) is SIX launches around the net forward, none of which synchronises:
 //   k_expand_lookup   pop list -> parents -> 12 children each (agents.py:277-282), goal flag, membership test and
 //                     in-batch first-occurrence election through the hash table (agents.py:286-295)
-//   k_append          first_unseen / first_seen flags, order-preserving compaction across workgroups (chained scan),
-//                     append with G / parent / action (agents.py:299-313), goal test of the new states (:321-323),
-//                     read half of relaxation case 1 (:354), and the one-hot rows of the new states for the net
+//   k_append          first_unseen / first_seen flags, order-preserving compaction across workgroups (tickets +
+//                     look-back), append with G / parent / action (agents.py:299-313), goal test of the new states
+//                     (:321-323), read half of relaxation case 1 (:354)
+//   k_new_rows        the net's input: one-hot rows (or, with a fused first layer, the raw states) of the new states, on a
+//                     grid as wide as the batch; write half of relaxation case 1 (:357-359)
 //   [net forward on the fixed (12 N, 480) batch -- PyTorch]
-//   k_records_sort    cost = lambda*G + (-value) in float64 (agents.py:383), bitonic sort of 2048-record chunks in LDS,
-//                     write half of relaxation case 1 (:357-359)          (+ log2(K/2048) merge passes when K > 2048)
+//   k_records_sort    cost = lambda*G + (-value) in float64 (agents.py:383); bitonic sort in LDS, one workgroup per chunk:
+//                     runs of 256 (K <= 2048) or chunks of 2048 followed by log2(K/2048) merge passes
 //   k_queue_insert    the multi-way rank merge described above (heappush, :316-317); read half of case 2 (:362)
 //   k_end             write half of case 2 (:365-367), queue bookkeeping, loop guard (:236), and the NEXT pop list
 // All shapes are fixed by N, so an iteration can be captured in a hipGraph and replayed; the host polls `ctr` now and
@@ -65,7 +67,7 @@ enum { ERR_NONE = 0, ERR_CAPACITY = 1, ERR_CHAIN = 2 };
 
 constexpr int QL = 12;                          // maximal number of queue levels
 constexpr int SORT_CHUNK = 2048;                // records sorted per workgroup in LDS (32 KB) when K > 2048
-constexpr int SMALL_CHUNK = 256;                // ... and when K <= 2048: up to eight 256-record runs, sorted by eight workgroups
+constexpr int SMALL_CHUNK = 256;                // ... and when K <= 2048: up to eight 256-record runs, sorted by eight workgroups in parallel
 constexpr int MAX_NEW_RUNS = SORT_CHUNK / SMALL_CHUNK;
 enum { Q_HEAD = 0, Q_LEN = 1, Q_CUR = 2, Q_TAKE = 3 };
 
@@ -269,14 +271,54 @@ void k_expand_lookup(AstarDev d)
 	lookup_elect(d, s, c, [&](int c2, uint32_t o[5]) { child_of(d, s_act, c2, o); });
 }
 
+// Sharded mode: incoming child slots.  The receive buffer is `world` blocks of {32-byte header, K records of 32 B,
+// K shortcut offers of 16 B}; batch position c = src * K + pos keeps arrival order (grouped by sending rank, each group
+// in the sender's order) without compaction.  Record: {state[5], parent_idx, g | action<<16 | parent_rank<<24, pad}.
+__device__ __forceinline__ size_t shard_block_bytes(int K) { return 32 + (size_t)K * 48; }
+__device__ __forceinline__ const uint32_t *shard_hdr(const uint8_t *buf, int K, int peer)
+{
+	return reinterpret_cast<const uint32_t *>(buf + (size_t)peer * shard_block_bytes(K));
+}
+__device__ __forceinline__ const uint32_t *shard_rec(const uint8_t *buf, int K, int c)
+{
+	const int peer = c / K, pos = c - peer * K;
+	return reinterpret_cast<const uint32_t *>(buf + (size_t)peer * shard_block_bytes(K) + 32 + (size_t)pos * 32);
+}
+__device__ __forceinline__ bool shard_valid(const uint8_t *buf, int K, int c)
+{
+	const int peer = c / K, pos = c - peer * K;
+	return pos < (int)shard_hdr(buf, K, peer)[0];
+}
+
 // The net's input rows for the new states of this iteration, (n_new, 480) one-hot or (n_new, 20) raw states, written by a
 // grid as wide as the batch (fused into the append kernel it was the longest kernel of the iteration: a handful of
 // workgroups writing 2 MB).  Rows past n_new are left untouched.  ELEM_BYTES = 0: no encoding at all, the rows are the
 // 20-byte states themselves (for a net whose first layer reads states: rk_ohl_forward, librubiks_amd/oh_linear.py).
-template <int ELEM_BYTES>
+template <int ELEM_BYTES, bool SHARDED>
 __global__ __launch_bounds__(256)
-void k_new_rows(AstarDev d, u32x4 *out, uint32_t one_bits)
+void k_new_rows(AstarDev d, u32x4 *out, uint32_t one_bits, const uint8_t *recv)
 {
+	// relaxation case 1, write half (agents.py:357-359): first-seen children that found a shorter way to an old node.
+	// It only needs the append kernel's results and touches old nodes, so it rides here, off the critical path after the
+	// net.  The reference returns before relaxing once it has won (agents.py:321-323).
+	if (!d.ctr[C_WON]) {
+		const int K = SHARDED ? d.KI : 12 * d.ctr[C_NPOP];
+		for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < K; c += gridDim.x * blockDim.x) {
+			if (!(d.flags[c] & 2) || !d.newway[c]) continue;
+			const int32_t t = d.seen[c];
+			d.G[t] = d.val1[c];
+			if (SHARDED) {
+				const uint32_t *r = shard_rec(recv, d.K, c);
+				d.pact[t] = (uint8_t)((r[6] >> 16) & 0xFFu);
+				d.parents[t] = (int32_t)r[5];
+				d.prank[t] = (uint8_t)(r[6] >> 24);
+			} else {
+				d.pact[t] = (uint8_t)(c % 12);
+				d.parents[t] = d.exp_idx[c / 12];
+			}
+		}
+	}
+	if (out == nullptr) return;
 	const int n_new = d.ctr[C_NNEW];
 	const uint32_t *pool = d.states + ((size_t)d.ctr[C_NBEFORE] + 1) * 5;
 	if (ELEM_BYTES == 0) {
@@ -302,25 +344,6 @@ void k_new_rows(AstarDev d, u32x4 *out, uint32_t one_bits)
 		}
 		out[q] = val;
 	}
-}
-
-// Sharded mode: incoming child slots.  The receive buffer is `world` blocks of {32-byte header, K records of 32 B,
-// K shortcut offers of 16 B}; batch position c = src * K + pos keeps arrival order (grouped by sending rank, each group
-// in the sender's order) without compaction.  Record: {state[5], parent_idx, g | action<<16 | parent_rank<<24, pad}.
-__device__ __forceinline__ size_t shard_block_bytes(int K) { return 32 + (size_t)K * 48; }
-__device__ __forceinline__ const uint32_t *shard_hdr(const uint8_t *buf, int K, int peer)
-{
-	return reinterpret_cast<const uint32_t *>(buf + (size_t)peer * shard_block_bytes(K));
-}
-__device__ __forceinline__ const uint32_t *shard_rec(const uint8_t *buf, int K, int c)
-{
-	const int peer = c / K, pos = c - peer * K;
-	return reinterpret_cast<const uint32_t *>(buf + (size_t)peer * shard_block_bytes(K) + 32 + (size_t)pos * 32);
-}
-__device__ __forceinline__ bool shard_valid(const uint8_t *buf, int K, int c)
-{
-	const int peer = c / K, pos = c - peer * K;
-	return pos < (int)shard_hdr(buf, K, peer)[0];
 }
 
 __global__ __launch_bounds__(256)
@@ -399,13 +422,40 @@ void k_append(AstarDev d, const uint8_t *recv)
 	}
 }
 
-// cost = lambda * G + (-value), float64, no fused multiply-add (agents.py:380-383); bitonic sort of one chunk in LDS;
-// write half of relaxation case 1 (agents.py:357-359).  Padding records carry distinct maximal keys.
-// CHUNK = 256 (128 threads; K <= 2048: the new records become up to eight sorted runs on eight CUs in parallel, which the
-// queue insert merges directly) or 2048 (1024 threads, followed by the merge passes).
-template <bool SHARDED, int CHUNK>
+// cost record of new state j: cost = lambda * G + (-value), float64, no fused multiply-add (agents.py:380-383).
+// Padding records carry distinct maximal keys.
+__device__ __forceinline__ Rec cost_record(const AstarDev &d, const float *values, int j, int n_new, uint32_t n_before)
+{
+	if (j >= n_new) return Rec{~0ull, 0xFFFFFFFF00000000ull + (uint64_t)j};
+	const uint32_t idx = n_before + 1u + (uint32_t)j;
+	const double hv = (double)(-values[j]);
+	const double lg = d.lambda * (double)d.G[idx];
+	return Rec{sortable_key(lg + hv), (uint64_t)idx};
+}
+
+// bitonic sort of s[0..P) (P a power of two >= 64) by T threads with thread ids tid; contains barriers (uniform P)
+template <int T>
+__device__ __forceinline__ void bitonic_lds(Rec *s, int P, int tid)
+{
+	for (int k = 2; k <= P; k <<= 1)
+		for (int j = k >> 1; j > 0; j >>= 1) {
+			for (int t = tid; t < (P >> 1); t += T) {
+				const int i = 2 * t - (t & (j - 1));
+				const int l = i + j;
+				const bool up = (i & k) == 0;
+				const Rec a = s[i], b2 = s[l];
+				if (rec_less(b2, a) == up) { s[i] = b2; s[l] = a; }
+			}
+			__syncthreads();
+		}
+}
+
+// The new records are sorted in chunks, one workgroup each: CHUNK = 2048 (K > 2048; k_merge_pass then merges the chunks)
+// or CHUNK = 256 (K <= 2048: up to eight runs sorted on eight CUs at once, which the queue insert merges directly --
+// measured against sorting inside the insert kernel, where every workgroup repeats 90 barrier steps: 9 us vs 20 us).
+template <int CHUNK>
 __global__ __launch_bounds__(CHUNK / 2)
-void k_records_sort(AstarDev d, const float *values, const uint8_t *recv)
+void k_records_sort(AstarDev d, const float *values)
 {
 	__shared__ Rec s[CHUNK];
 	constexpr int T = CHUNK / 2;
@@ -413,54 +463,16 @@ void k_records_sort(AstarDev d, const float *values, const uint8_t *recv)
 	const int n_new = d.ctr[C_NNEW];
 	const uint32_t n_before = (uint32_t)d.ctr[C_NBEFORE];
 	const int base = blockIdx.x * CHUNK;
-	if (base < n_new) {                                                 // uniform for the workgroup
-		const int cnt = n_new - base < CHUNK ? n_new - base : CHUNK;
-		int P = 64;                                                     // sort only the power of two that holds the chunk's records
-		while (P < cnt) P <<= 1;
-		#pragma unroll
-		for (int h = 0; h < 2; h++) {
-			const int j = base + tid + h * T;
-			Rec x = Rec{~0ull, 0xFFFFFFFF00000000ull + (uint64_t)j};
-			if (j < n_new) {
-				const uint32_t idx = n_before + 1u + (uint32_t)j;
-				const double hv = (double)(-values[j]);
-				const double lg = d.lambda * (double)d.G[idx];
-				x = Rec{sortable_key(lg + hv), (uint64_t)idx};
-			}
-			s[tid + h * T] = x;
-		}
-		__syncthreads();
-		for (int k = 2; k <= P; k <<= 1)
-			for (int j = k >> 1; j > 0; j >>= 1) {
-				if (tid < (P >> 1)) {
-					const int i = 2 * tid - (tid & (j - 1));
-					const int l = i + j;
-					const bool up = (i & k) == 0;
-					const Rec a = s[i], b2 = s[l];
-					if (rec_less(b2, a) == up) { s[i] = b2; s[l] = a; }
-				}
-				__syncthreads();
-			}
-		d.rec0[base + tid] = s[tid];                                    // (records past P are padding and already in place)
-		d.rec0[base + tid + T] = s[tid + T];
-	}
-	// relaxation case 1, write half: first-seen children that found a shorter way to an old node
-	if (d.ctr[C_WON]) return;                                           // the reference returns before relaxing (agents.py:321-323)
-	const int K = SHARDED ? d.KI : 12 * d.ctr[C_NPOP];
-	for (int c = blockIdx.x * T + tid; c < K; c += gridDim.x * T) {
-		if (!(d.flags[c] & 2) || !d.newway[c]) continue;
-		const int32_t t = d.seen[c];
-		d.G[t] = d.val1[c];
-		if (SHARDED) {
-			const uint32_t *r = shard_rec(recv, d.K, c);
-			d.pact[t] = (uint8_t)((r[6] >> 16) & 0xFFu);
-			d.parents[t] = (int32_t)r[5];
-			d.prank[t] = (uint8_t)(r[6] >> 24);
-		} else {
-			d.pact[t] = (uint8_t)(c % 12);
-			d.parents[t] = d.exp_idx[c / 12];
-		}
-	}
+	if (base >= n_new) return;                                          // uniform for the workgroup
+	const int cnt = n_new - base < CHUNK ? n_new - base : CHUNK;
+	int P = 64;                                                         // sort only the power of two that holds the chunk's records
+	while (P < cnt) P <<= 1;
+	s[tid] = cost_record(d, values, base + tid, n_new, n_before);
+	s[tid + T] = cost_record(d, values, base + tid + T, n_new, n_before);
+	__syncthreads();
+	bitonic_lds<T>(s, P, tid);
+	d.rec0[base + tid] = s[tid];                                        // (records past P are padding and already in place)
+	d.rec0[base + tid + T] = s[tid + T];
 }
 
 // merge neighbouring sorted runs of length L over the padded new-record array (all records distinct)
@@ -492,14 +504,18 @@ void k_queue_insert(AstarDev d, int new_in_rec1)
 {
 	__shared__ MergePlan s_plan;
 	__shared__ Rec s_newrecs[SORT_CHUNK];
+	__shared__ int32_t s_qmeta[4 * QL];
 	const bool small = d.chunk == SMALL_CHUNK;
+	if (threadIdx.x < 4 * QL) s_qmeta[threadIdx.x] = d.q.meta[threadIdx.x];     // one parallel load instead of a dependent chain
+	__syncthreads();
 	if (threadIdx.x == 0) {
 		const int n_new = d.ctr[C_NNEW];
 		// with more than one 2048-chunk the merge passes ping-pong; otherwise the sorted run(s) are in rec0
-		make_plan(d.q, d.q.meta, (!small && n_new > SORT_CHUNK && new_in_rec1) ? d.rec1 : d.rec0, n_new, small ? SMALL_CHUNK : 0, s_plan);
+		make_plan(d.q, s_qmeta, (!small && n_new > SORT_CHUNK && new_in_rec1) ? d.rec1 : d.rec0, n_new, small ? SMALL_CHUNK : 0, s_plan);
 	}
 	__syncthreads();
 	if (small && s_plan.total > 0) {
+		// K <= 2048: the sorted runs of new records (16-32 KB) are staged in LDS, so the merge searches them on the CU
 		const int n_new = d.ctr[C_NNEW];
 		for (int i = threadIdx.x; i < n_new; i += blockDim.x) s_newrecs[i] = d.rec0[i];
 		__syncthreads();
@@ -956,13 +972,15 @@ void launch_append(rk_astar *h, const uint8_t *recv, void *d_onehot, int out_dty
 	const AstarDev &d = h->d;
 	const size_t kin = SHARDED ? (size_t)d.KI : (size_t)d.K;
 	hipLaunchKernelGGL((k_append<SHARDED>), dim3(blocks(kin, ASCAN)), dim3(ASCAN), 0, st, d, recv);
-	if (d_onehot == nullptr) return;
-	// about one 16-byte store per thread: the grid covers the largest possible batch
-	const size_t chunks = kin * (out_dtype == RK_OH_F32 ? 120 : out_dtype == RK_OH_STATES ? 2 : 60);
+	// the net's input rows (about one 16-byte store per thread: the grid covers the largest possible batch) + relaxation 1
+	const size_t chunks = d_onehot == nullptr ? kin : kin * (out_dtype == RK_OH_F32 ? 120 : out_dtype == RK_OH_STATES ? 2 : 60);
 	const unsigned grid = std::min<unsigned>(blocks(chunks), 8192u);
-	if (out_dtype == RK_OH_F32) hipLaunchKernelGGL((k_new_rows<4>), dim3(grid), dim3(256), 0, st, d, (u32x4 *)d_onehot, 0x3F800000u);
-	else if (out_dtype == RK_OH_STATES) hipLaunchKernelGGL((k_new_rows<0>), dim3(grid), dim3(256), 0, st, d, (u32x4 *)d_onehot, 0u);
-	else hipLaunchKernelGGL((k_new_rows<2>), dim3(grid), dim3(256), 0, st, d, (u32x4 *)d_onehot, out_dtype == RK_OH_F16 ? 0x3C00u : 0x3F80u);
+	if (d_onehot != nullptr && out_dtype == RK_OH_F32)
+		hipLaunchKernelGGL((k_new_rows<4, SHARDED>), dim3(grid), dim3(256), 0, st, d, (u32x4 *)d_onehot, 0x3F800000u, recv);
+	else if (d_onehot != nullptr && out_dtype == RK_OH_STATES)
+		hipLaunchKernelGGL((k_new_rows<0, SHARDED>), dim3(grid), dim3(256), 0, st, d, (u32x4 *)d_onehot, 0u, recv);
+	else
+		hipLaunchKernelGGL((k_new_rows<2, SHARDED>), dim3(grid), dim3(256), 0, st, d, (u32x4 *)d_onehot, out_dtype == RK_OH_F16 ? 0x3C00u : 0x3F80u, recv);
 }
 
 // records + sort + merge passes + queue insert + end of iteration; returns through the launches only
@@ -972,18 +990,18 @@ int launch_commit(rk_astar *h, const float *d_values, const uint8_t *recv, hipSt
 	const AstarDev &d = h->d;
 	int from = 0;
 	if (d.chunk == SMALL_CHUNK) {
-		hipLaunchKernelGGL((k_records_sort<SHARDED, SMALL_CHUNK>), dim3(d.Kpad / SMALL_CHUNK), dim3(SMALL_CHUNK / 2), 0, st, d, d_values, recv);
+		hipLaunchKernelGGL((k_records_sort<SMALL_CHUNK>), dim3(d.Kpad / SMALL_CHUNK), dim3(SMALL_CHUNK / 2), 0, st, d, d_values);
 	} else {
-		hipLaunchKernelGGL((k_records_sort<SHARDED, SORT_CHUNK>), dim3(d.Kpad / SORT_CHUNK), dim3(SORT_CHUNK / 2), 0, st, d, d_values, recv);
+		hipLaunchKernelGGL((k_records_sort<SORT_CHUNK>), dim3(d.Kpad / SORT_CHUNK), dim3(SORT_CHUNK / 2), 0, st, d, d_values);
 		for (int L = SORT_CHUNK; L < d.Kpad; L <<= 1) {
 			hipLaunchKernelGGL(k_merge_pass, dim3(blocks(d.Kpad)), dim3(256), 0, st, d, L, from);
 			from ^= 1;
 		}
 	}
-	// when the new records fit one chunk the passes are no-ops and the sorted run is in rec0
 	const unsigned grid = std::min<unsigned>(1024u, std::max<unsigned>(blocks((size_t)d.Kpad * 4), 8u));
 	hipLaunchKernelGGL((k_queue_insert<SHARDED>), dim3(grid), dim3(256), 0, st, d, from);
 	if (!SHARDED) hipLaunchKernelGGL((k_end<false>), dim3(1), dim3(1024), 0, st, d, from, 1);
+	(void)recv;
 	return from;
 }
 

@@ -348,6 +348,22 @@ __global__ void kb_end(BatchDev d, int merge_width)
 	if (c[B_WON]) c[B_DONE] = 1;
 }
 
+// action indices from the root to node `index` of search s, walked on the device (agents.py:244-251)
+__global__ void kb_walk(BatchDev d, int s, int index, int32_t *out /* [0] = length or -1, then actions root -> node */, int max_len)
+{
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	const size_t base = (size_t)s * d.cap1;
+	int len = 0, i = index;
+	while (i != 1 && len <= (int)d.cap1) { i = d.parents[base + i]; len++; if (i < 1 || (uint32_t)i >= d.cap1) { out[0] = -1; return; } }
+	if (i != 1) { out[0] = -1; return; }
+	out[0] = len;
+	i = index;
+	for (int k = len - 1; k >= 0; k--) {
+		if (k < max_len) out[1 + k] = d.pact[base + i];
+		i = d.parents[base + i];
+	}
+}
+
 }  // namespace rk
 
 using namespace rk;
@@ -358,6 +374,7 @@ struct rk_astarb {
 	std::vector<void *> allocs;
 	uint32_t *starts = nullptr;
 	int32_t *budgets = nullptr;
+	int32_t *walk = nullptr;      // path walk result: length, then actions
 	int merge_bound = 0;          // launch width of the queue merge: an upper bound of any search's queue length
 	bool ready = false, pending = false;
 };
@@ -375,6 +392,8 @@ int b_alloc(rk_astarb *h, T **p, size_t count)
 }
 
 inline unsigned nblk(size_t n, unsigned per = 256) { return (unsigned)((n + per - 1) / per); }
+
+constexpr int WALK_MAX = 1 << 16;
 
 }  // namespace
 
@@ -409,6 +428,7 @@ int rk_astarb_create(rk_astarb_t **out, int n_searches, size_t capacity_per_sear
 	#undef A
 	if (!e) e = b_alloc(h, &h->starts, S * 5);
 	if (!e) e = b_alloc(h, &h->budgets, S);
+	if (!e) e = b_alloc(h, &h->walk, (size_t)WALK_MAX + 8);
 	if (e) { rk_astarb_destroy(h); return e; }
 	*out = h;
 	return RK_OK;
@@ -554,22 +574,20 @@ long long rk_astarb_path(rk_astarb_t *h, int search, long long index, long long 
 	if (search < 0 || search >= d.S) return fail(RK_EINVAL, "rk_astarb_path: search %d out of range", search);
 	if (index < 1 || (size_t)index >= d.cap1) return fail(RK_EINVAL, "rk_astarb_path: index %lld out of range", index);
 	hipStream_t st = (hipStream_t)stream;
-	const size_t n = (size_t)d.cap1, r0 = (size_t)search * d.cap1;
-	std::vector<int32_t> p(n);
-	std::vector<uint8_t> a(n);
-	RK_HIP(hipMemcpyAsync(p.data(), d.parents + r0, n * 4, hipMemcpyDeviceToHost, st));
-	RK_HIP(hipMemcpyAsync(a.data(), d.pact + r0, n, hipMemcpyDeviceToHost, st));
+	hipLaunchKernelGGL(kb_walk, dim3(1), dim3(64), 0, st, d, search, (int)index, h->walk, WALK_MAX);
+	RK_HIP(hipGetLastError());
+	int32_t len = 0;
+	RK_HIP(hipMemcpyAsync(&len, h->walk, sizeof len, hipMemcpyDeviceToHost, st));
 	RK_HIP(hipStreamSynchronize(st));
-	std::vector<long long> rev;
-	long long i = index;
-	while (i != 1) {
-		if (rev.size() > n) return fail(RK_ESTATE, "rk_astarb_path: parent chain does not reach the root");
-		rev.push_back(a[(size_t)i]);
-		i = p[(size_t)i];
-		if (i < 1 || (size_t)i >= n) return fail(RK_ESTATE, "rk_astarb_path: broken parent chain");
+	if (len < 0) return fail(RK_ESTATE, "rk_astarb_path: broken parent chain");
+	size_t n = (size_t)len < max_len ? (size_t)len : max_len;
+	if (n > (size_t)WALK_MAX) n = WALK_MAX;
+	std::vector<int32_t> acts(n);
+	if (n) {
+		RK_HIP(hipMemcpyAsync(acts.data(), h->walk + 1, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+		RK_HIP(hipStreamSynchronize(st));
 	}
-	const size_t len = rev.size();
-	for (size_t k = 0; k < len && k < max_len; k++) h_actions[k] = rev[len - 1 - k];
+	for (size_t k = 0; k < n; k++) h_actions[k] = acts[k];
 	return (long long)len;
 }
 

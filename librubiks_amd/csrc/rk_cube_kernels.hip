@@ -884,8 +884,8 @@ void launch_expand12_variant(int variant, const int8_t *parents, int8_t *childre
 void launch_expand12(const int8_t *parents, int8_t *children, uint8_t *solved, long long *stats, size_t n, hipStream_t st)
 {
 	const size_t n_tiles = (n + EXP_ROUND - 1) / EXP_ROUND;
-	const bool persistent = n_tiles > (size_t)(2 * EXP_GRID_PERSISTENT * EXP_WAVES);
-	const unsigned grid = persistent ? (unsigned)EXP_GRID_PERSISTENT : grid_for(n_tiles, EXP_WAVES, 1u << 20);
+	const bool persistent = n_tiles >= (size_t)8192;                   // from about half a million parents on
+	const unsigned grid = grid_for(n_tiles, EXP_WAVES, persistent ? (unsigned)EXP_GRID_PERSISTENT : 1u << 20);
 	#define RK_GO(FLAGS, PRE) hipLaunchKernelGGL((k_expand12<FLAGS, 1, true, EXP_WAVES, PRE>), dim3(grid), dim3(EXP_WAVES * WAVE), 0, st, \
 		(const uint32_t *)parents, (u32x4 *)children, (uint32_t *)(FLAGS ? solved : nullptr), FLAGS ? stats : (long long *)nullptr, n, n_tiles)
 	if (solved != nullptr) { if (persistent) RK_GO(true, true); else RK_GO(true, false); }

@@ -81,6 +81,42 @@ __device__ __forceinline__ bool same5(const uint32_t a[5], const uint32_t *p)
 	return ((a[0] ^ p[0]) | (a[1] ^ p[1]) | (a[2] ^ p[2]) | (a[3] ^ p[3]) | (a[4] ^ p[4])) == 0;
 }
 
+// ---- 16-lane reductions on the VALU (DPP row rotations) instead of through the LDS crossbar ----------------------
+// A tree level costs one memory round trip plus this arithmetic; with __shfl_xor (ds_bpermute, ~60 cycles each, a dozen
+// dependent ones per level for the 64-bit arg-max) the arithmetic was as long as the memory latency.  row_ror:n rotates
+// inside each row of 16 lanes, so after n = 8, 4, 2, 1 every lane of a row holds the row's reduction.
+template <int N> __device__ __forceinline__ int dpp_ror_i(int v)
+{
+	return __builtin_amdgcn_update_dpp(v, v, 0x120 + N, 0xF, 0xF, false);
+}
+template <int N> __device__ __forceinline__ double dpp_ror_d(double v)
+{
+	const long long b = __double_as_longlong(v);
+	const int lo = dpp_ror_i<N>((int)(b & 0xFFFFFFFFll)), hi = dpp_ror_i<N>((int)(b >> 32));
+	return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ int row_sum_i(int v)
+{
+	v += dpp_ror_i<8>(v); v += dpp_ror_i<4>(v); v += dpp_ror_i<2>(v); v += dpp_ror_i<1>(v);
+	return v;
+}
+__device__ __forceinline__ float row_max_f(float v)
+{
+	#define RK_STEP(N) v = fmaxf(v, __int_as_float(dpp_ror_i<N>(__float_as_int(v))))
+	RK_STEP(8); RK_STEP(4); RK_STEP(2); RK_STEP(1);
+	#undef RK_STEP
+	return v;
+}
+// first arg-max (np.argmax: the smallest index among equal maxima) of (x, a) over a row
+__device__ __forceinline__ int row_argmax_first(double x, int a)
+{
+	#define RK_STEP(N) do { const double ox = dpp_ror_d<N>(x); const int oa = dpp_ror_i<N>(a); \
+		if (ox > x || (ox == x && oa < a)) { x = ox; a = oa; } } while (0)
+	RK_STEP(8); RK_STEP(4); RK_STEP(2); RK_STEP(1);
+	#undef RK_STEP
+	return a;
+}
+
 __device__ __forceinline__ void fence_wave_to_wave()
 {
 	// later loads of this wave (other lanes) must see earlier stores of this wave
@@ -228,9 +264,7 @@ void k_mcts_backup_select(MctsDev d, const float *probs, const float *values)
 		}
 	}
 	float bestf = is_new ? vf : -INFINITY;                                 // v.max() over the NEW children (:559)
-	#pragma unroll
-	for (int m = 8; m > 0; m >>= 1) bestf = fmaxf(bestf, __shfl_xor(bestf, m, 16));
-	bestf = __shfl(bestf, 0, 64);
+	bestf = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(row_max_f(bestf))));
 	const bool has_new = __ballot(is_new) != 0ull;
 	const double best = (double)bestf;
 	if (active) node_of(d, node0, leaf).W()[lane] = is_new ? v : node_of(d, node0, idx).V();     // agents.py:560
@@ -274,10 +308,7 @@ void k_mcts_backup_select(MctsDev d, const float *probs, const float *values)
 		const int nb = active ? nd.nb()[col] : 0;
 		if (lane == owed_lane) { lval += d.nu; nd.L()[col] = lval; }       // agents.py:591
 		if (!expanded) break;
-		int sumN = nA;
-		#pragma unroll
-		for (int m = 8; m > 0; m >>= 1) sumN += __shfl_xor(sumN, m, 16);
-		sumN = __shfl(sumN, 0, 64);
+		const int sumN = __builtin_amdgcn_readfirstlane(row_sum_i(nA));
 		double x = -INFINITY;
 		int best_a = lane;
 		if (active) {
@@ -288,14 +319,8 @@ void k_mcts_backup_select(MctsDev d, const float *probs, const float *values)
 			const double Q = wA - lval;
 			x = U + Q;
 		}
-		#pragma unroll
-		for (int m = 8; m > 0; m >>= 1) {                                  // first arg-max (np.argmax)
-			const double ox = __shfl_xor(x, m, 16);
-			const int oa = __shfl_xor(best_a, m, 16);
-			if (ox > x || (ox == x && oa < best_a)) { x = ox; best_a = oa; }
-		}
-		best_a = __shfl(best_a, 0, 64);
-		const int next = __shfl(nb, best_a, 64);
+		best_a = __builtin_amdgcn_readfirstlane(row_argmax_first(x, best_a));   // first arg-max (np.argmax), wave-uniform
+		const int next = __builtin_amdgcn_readlane(nb, best_a);
 		if (lane == best_a) nd.L()[col] = lval + d.nu;                         // agents.py:589
 		owed_lane = best_a ^ 1;
 		if (lane == 0) {
@@ -414,6 +439,12 @@ int rk_mcts_roots_oh(rk_mcts_t *h, void *d_out, int out_dtype, void *stream)
 {
 	if (!h || !h->ready) return fail(RK_ESTATE, "rk_mcts_roots_oh: reset the engine first");
 	MctsDev &d = h->d;
+	if (out_dtype == RK_OH_STATES) {
+		if (!d_out) return fail(RK_EINVAL, "rk_mcts_roots_oh: null output");
+		hipLaunchKernelGGL(k_mcts_gather_roots, dim3(nblocks((size_t)d.T * 5)), dim3(256), 0, (hipStream_t)stream, d, (uint32_t *)d_out);
+		RK_HIP(hipGetLastError());
+		return RK_OK;
+	}
 	hipLaunchKernelGGL(k_mcts_gather_roots, dim3(nblocks((size_t)d.T * 5)), dim3(256), 0, (hipStream_t)stream, d, d.children);
 	RK_HIP(hipGetLastError());
 	return rk_as_oh(RK_REPR_2024, (const int8_t *)d.children, d_out, out_dtype, (size_t)d.T, stream);
@@ -439,6 +470,11 @@ int rk_mcts_expand(rk_mcts_t *h, void *stream)
 int rk_mcts_children_oh(rk_mcts_t *h, void *d_out, int out_dtype, void *stream)
 {
 	if (!h || !h->ready) return fail(RK_ESTATE, "rk_mcts_children_oh: reset the engine first");
+	if (out_dtype == RK_OH_STATES) {              // a net whose first layer reads states (rk_ohl_*): hand over the (T*12, 20) int8 rows
+		if (!d_out) return fail(RK_EINVAL, "rk_mcts_children_oh: null output");
+		RK_HIP(hipMemcpyAsync(d_out, h->d.children, (size_t)h->d.T * 12 * STATE_BYTES, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+		return RK_OK;
+	}
 	return rk_as_oh(RK_REPR_2024, (const int8_t *)h->d.children, d_out, out_dtype, (size_t)h->d.T * 12, stream);
 }
 

@@ -494,8 +494,14 @@ class MCTSBatch(DeepAgent):
 	(through torch.cuda.CUDAGraph) and replays it; the host only polls every `poll` simulations.
 	"""
 
-	def __init__(self, net, c: float, n_trees: int, capacity: int = 50_000, max_path: int = None, nu: float = 100.0):
+	def __init__(self, net, c: float, n_trees: int, capacity: int = 50_000, max_path: int = None, nu: float = 100.0,
+	             fused_first_layer: bool = False):
 		super().__init__(net)
+		# fused_first_layer: the net's first Linear(480, H) reads the children's 20-byte states (librubiks_amd.oh_linear)
+		self._from_states = None
+		if fused_first_layer:
+			from librubiks_amd.oh_linear import fuse_first_linear
+			self._from_states = fuse_first_linear(net)
 		self.c, self.nu, self.n_trees = float(c), float(nu), int(n_trees)
 		self.capacity = int(capacity)
 		self.max_path = int(max_path or max(4096, 2 * self.capacity))
@@ -535,8 +541,9 @@ class MCTSBatch(DeepAgent):
 	def _step(self, oh, h):
 		lib = _ffi.lib()
 		_ffi.check(lib.rk_mcts_expand(h, _ffi.stream_ptr()))
-		_ffi.check(lib.rk_mcts_children_oh(h, oh.data_ptr(), _OH_CODES[oh.dtype], _ffi.stream_ptr()))
-		p, v = _policy_value_f32(self.net(oh))
+		fused = self._from_states is not None
+		_ffi.check(lib.rk_mcts_children_oh(h, oh.data_ptr(), _ffi.OH_STATES if fused else _OH_CODES[oh.dtype], _ffi.stream_ptr()))
+		p, v = _policy_value_f32((self._from_states if fused else self.net)(oh))
 		self._keep = (p, v)            # the kernels read these after this call returns
 		_ffi.check(lib.rk_mcts_backup_select(h, p.data_ptr(), v.data_ptr(), _ffi.stream_ptr()))
 
@@ -555,12 +562,18 @@ class MCTSBatch(DeepAgent):
 		ms = np.minimum(np.broadcast_to(np.asarray(max_states, dtype=np.int64), (self.n_trees,)), self.capacity).copy()
 		h, lib = self._engine(), _ffi.lib()
 		_ffi.check(lib.rk_mcts_reset(h, states.ctypes.data, ms.ctypes.data, self.c, self.nu, _ffi.stream_ptr()))
-		oh_dtype = _oh_dtype(self.net)
-		root_oh = torch.empty((self.n_trees, 480), dtype=oh_dtype, device=gpu)
-		_ffi.check(lib.rk_mcts_roots_oh(h, root_oh.data_ptr(), _OH_CODES[oh_dtype], _ffi.stream_ptr()))
-		p, v = _policy_value_f32(self.net(root_oh))                      # agents.py:470-473
+		if self._from_states is not None:
+			root_oh = torch.empty((self.n_trees, 20), dtype=torch.int8, device=gpu)
+			_ffi.check(lib.rk_mcts_roots_oh(h, root_oh.data_ptr(), _ffi.OH_STATES, _ffi.stream_ptr()))
+			p, v = _policy_value_f32(self._from_states(root_oh))
+			oh = torch.from_numpy(cube.repeat_state(cube.get_solved(), 12 * self.n_trees)).to(gpu)
+		else:
+			oh_dtype = _oh_dtype(self.net)
+			root_oh = torch.empty((self.n_trees, 480), dtype=oh_dtype, device=gpu)
+			_ffi.check(lib.rk_mcts_roots_oh(h, root_oh.data_ptr(), _OH_CODES[oh_dtype], _ffi.stream_ptr()))
+			p, v = _policy_value_f32(self.net(root_oh))                  # agents.py:470-473
+			oh = torch.empty((12 * self.n_trees, 480), dtype=oh_dtype, device=gpu)
 		_ffi.check(lib.rk_mcts_set_root_pv(h, p.data_ptr(), v.data_ptr(), _ffi.stream_ptr()))
-		oh = torch.empty((12 * self.n_trees, 480), dtype=oh_dtype, device=gpu)
 		self.simulations = 0
 		graph = None
 		if use_graph:

@@ -94,3 +94,29 @@ def test_fused_net_in_astar_and_adi():
 	np.random.seed(4)
 	oh2, p2, v2, w2 = adi_traindata(net, 20, 8, 0.5, "lapanfix", ff_batches=2, fused_first_layer=True)
 	assert torch.equal(oh1, oh2) and torch.allclose(v1, v2, rtol=1e-4, atol=1e-4) and (p1 == p2).float().mean() > 0.95
+
+
+def test_fused_net_in_mcts():
+	"""MCTSBatch with the first layer fused: the tree's P and V equal a fresh forward of the net (reference invariant,
+	tests/test_agents.py:84-90, atol 1e-4 because the first layer sums in another order) and the graph replay works."""
+	from benchmarks.nets import FcSmall
+	from librubiks_amd.solving.agents import MCTSBatch
+	net = FcSmall(seed=3).cuda().eval()
+	starts = []
+	for i in range(6):
+		np.random.seed(50 + i)
+		starts.append(orc.scramble(8, True)[0])
+	starts = np.array(starts)
+	agent = MCTSBatch(net, 1.0, 6, capacity=1500, fused_first_layer=True)
+	agent.search(starts, max_states=1500, max_sims=100, use_graph=True, poll=32)
+	for t in (0, 5):
+		a = agent.tree_arrays(t)
+		n = a["n"]
+		assert n > 500 and (a["states"][1] == starts[t]).all()
+		with torch.no_grad():
+			p, v = net(cube.as_oh(a["states"][1:n + 1]))
+		assert np.allclose(a["P"][1:n + 1], p.softmax(dim=1).cpu().numpy(), atol=1e-4)
+		assert np.allclose(a["V"][1:n + 1], v.reshape(-1).cpu().numpy(), atol=1e-4)
+		i, j = np.nonzero(a["neighbors"][1:n + 1])
+		moved = orc.multi_rotate(a["states"][i + 1], j // 2, 1 - j % 2)
+		assert (moved == a["states"][a["neighbors"][i + 1, j]]).all()
