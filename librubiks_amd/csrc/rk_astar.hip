@@ -939,7 +939,7 @@ struct rk_astar {
 	long long *decision = nullptr;
 	int n_exp = 0;                // expansions of the pending / next iteration (host view)
 	bool ready = false, pending = false;
-	int pending_oh = 0;
+	bool budget_explicit = false; // rk_astar_set_budget was called since the last reset
 	std::vector<void *> allocs;
 };
 
@@ -1105,6 +1105,7 @@ static int astar_reset_impl(rk_astar_t *h, const int8_t *h_start_state, double l
 	h->n_exp = d.N;
 	h->ready = true;
 	h->pending = false;
+	h->budget_explicit = false;
 	return RK_OK;
 }
 
@@ -1122,6 +1123,7 @@ int rk_astar_set_budget(rk_astar_t *h, long long max_states, void *stream)
 	if (b > (long long)h->cap) b = (long long)h->cap;
 	hipLaunchKernelGGL(k_set_budget, dim3(1), dim3(64), 0, (hipStream_t)stream, h->d, (int)b);
 	RK_HIP(hipGetLastError());
+	h->budget_explicit = true;
 	return RK_OK;
 }
 
@@ -1178,7 +1180,9 @@ int rk_astar_expand(rk_astar_t *h, int n_expand, long long *h_info, void *stream
 		h->n_exp = n_expand;
 	}
 	if (int e = read_ctr(h, c, st)) return e;
-	if ((size_t)c[C_NSTATES] + 12 * (size_t)c[C_NCAND] > h->cap)
+	// a host that never set a state budget learns about a full pool as an error; with a budget the engine's own loop
+	// guard has ended the search (done, nothing popped) before the pool can overflow
+	if (!h->budget_explicit && (size_t)c[C_NSTATES] + 12 * (size_t)c[C_NCAND] > h->cap)
 		return fail(RK_ECAPACITY, "rk_astar_expand: %d states + %d children exceed capacity %zu", c[C_NSTATES], 12 * c[C_NCAND], h->cap);
 	if (int e = rk_astar_step_expand(h, nullptr, RK_OH_F32, stream)) return e;
 	const int n_pop = c[C_NPOP];
@@ -1193,6 +1197,11 @@ int rk_astar_new_states_oh(rk_astar_t *h, void *d_out, int out_dtype, void *stre
 	int32_t c[C_COUNT];
 	if (int e = read_ctr(h, c, (hipStream_t)stream)) return e;
 	if (c[C_NNEW] == 0) return RK_OK;
+	if (out_dtype == RK_OH_STATES) {              // first layer fused: the new states themselves
+		if (!d_out) return fail(RK_EINVAL, "rk_astar_new_states_oh: null output");
+		RK_HIP(hipMemcpyAsync(d_out, h->d.states + ((size_t)c[C_NBEFORE] + 1) * 5, (size_t)c[C_NNEW] * STATE_BYTES, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+		return RK_OK;
+	}
 	return rk_as_oh(RK_REPR_2024, (const int8_t *)(h->d.states + ((size_t)c[C_NBEFORE] + 1) * 5), d_out, out_dtype, (size_t)c[C_NNEW], stream);
 }
 

@@ -241,18 +241,20 @@ __global__ __launch_bounds__(64)
 void k_mcts_backup_select(MctsDev d, const float *probs, const float *values)
 {
 	const int t = blockIdx.x, lane = threadIdx.x;
-	if (d.done[t]) return;
 	const bool active = lane < 12;
 	const size_t node0 = (size_t)t * d.cap1;
 	const size_t cbase = (size_t)t * 12 + lane;
 	const int32_t *pnodes = d.path_nodes + (size_t)t * d.max_path;
 	uint8_t *pacts = d.path_actions + (size_t)t * d.max_path;
-	const int plen = d.path_len[t];
-	const int leaf = pnodes[plen - 1];
-
+	// everything that does not depend on another load is requested before the first wait (the early exits used to put a
+	// round trip between each of these: six of them before any work)
+	const uint8_t is_done = d.done[t], tree_solved = d.solved[t];
+	const int plen = d.path_len[t], sims_before = d.sims[t];
 	const int idx = active ? d.child_idx[cbase] : 0;
 	const bool is_new = active && d.child_new[cbase] != 0;
 	const float vf = active ? values[cbase] : 0.0f;
+	if (is_done) return;
+	const int leaf = pnodes[plen - 1];
 	const double v = (double)vf;
 	if (is_new) {
 		const Node child = node_of(d, node0, idx);
@@ -269,7 +271,7 @@ void k_mcts_backup_select(MctsDev d, const float *probs, const float *values)
 	const double best = (double)bestf;
 	if (active) node_of(d, node0, leaf).W()[lane] = is_new ? v : node_of(d, node0, idx).V();     // agents.py:560
 
-	const int sim = d.sims[t] + 1;
+	const int sim = sims_before + 1;
 	for (int e = lane; e < plen - 1; e += 64) {
 		const int act = pacts[e];
 		const Node nd = node_of(d, node0, pnodes[e]);
@@ -284,7 +286,7 @@ void k_mcts_backup_select(MctsDev d, const float *probs, const float *values)
 		node_of(d, node0, pnodes[e + 1]).L()[act ^ 1] = 0.0;               // agents.py:570
 	}
 	if (lane == 0) d.sims[t] = sim;
-	if (d.solved[t]) {                                                     // agents.py:482-487
+	if (tree_solved) {                                                     // agents.py:482-487
 		if (lane == 0) {
 			pacts[plen - 1] = (uint8_t)d.solve_action[t];
 			d.done[t] = 1;

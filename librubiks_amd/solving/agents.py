@@ -255,10 +255,13 @@ class AStar(DeepAgent):
 	cost = lambda_ * G + (-value).  Same results as the reference (index numbering, G, parents, action_queue)
 	whenever the net returns the same values.
 
-	One iteration is `rk_astar_step_expand` -> net forward on the fixed (12 N, 480) one-hot batch -> `rk_astar_step_commit`:
-	five small launches around the net, no host synchronisation; the host polls the engine's status every `poll`
-	iterations (steps after the search ended are no-ops on the device).  `use_hipgraph=True` captures the iteration
-	once (the net must be capturable) and replays it.
+	Two ways to drive an iteration, chosen by the batch size K = 12 * expansions:
+	  * K < 2048 (latency regime, the reference's N = 27 ... 170): `rk_astar_step_expand` -> net forward on the fixed
+	    (K, 480) one-hot batch -> `rk_astar_step_commit`: six small launches around the net, no host synchronisation; the
+	    host polls the engine's status every few iterations (never past the state budget; steps after a win are no-ops
+	    on the device).  `use_hipgraph=True` captures the iteration once (the net must be capturable) and replays it.
+	  * K >= 2048 (the net dominates): `rk_astar_expand` synchronises once per iteration (about 30 us against
+	    milliseconds of net) so that the net runs on exactly the new states instead of the padded batch.
 
 	`capacity` bounds the number of stored states when a search is limited only by time (the reference grows its
 	arrays without bound): the pool doubles (a new engine, the search restarts from the root) until `max_capacity`;
@@ -365,8 +368,30 @@ class AStar(DeepAgent):
 				graph = torch.cuda.CUDAGraph()
 				with torch.cuda.graph(graph):
 					self._iteration(h, oh, code)
-			poll = 1 if self.record_pops else self.poll
-			while True:
+			budget = int(min(max_states, cap))
+			done = won = err = solved_idx = 0
+			exact = K >= 2048 and graph is None and not self.record_pops
+			info = (C.c_longlong * 5)()
+			while exact:
+				# one synchronisation per iteration, the net sees exactly the new states (agents.py:315, :369-383)
+				_ffi.check(lib.rk_astar_expand(h, self.expansions, info, _ffi.stream_ptr()))
+				n_pop, n_new, won, solved_idx, self._n = (int(x) for x in info)
+				if n_pop == 0:
+					done = 1
+					break
+				self.iterations += 1
+				if won:
+					break
+				values = None
+				if n_new:
+					_ffi.check(lib.rk_astar_new_states_oh(h, oh.data_ptr(), code, _ffi.stream_ptr()))
+					values = _value_f32((self._from_states or self.net)(oh[:n_new], policy=False, value=True))
+				_ffi.check(lib.rk_astar_commit(h, values.data_ptr() if values is not None else None, _ffi.stream_ptr()))
+				if time.perf_counter() - t0 >= time_limit:
+					break
+			while not exact:
+				# never run past the state budget: a search grows by at most K states per iteration
+				poll = 1 if self.record_pops else max(1, min(self.poll, (budget - self._n) // K))
 				for _ in range(poll):
 					if self.record_pops:
 						head = np.zeros(self.expansions, np.int64)
@@ -381,15 +406,15 @@ class AStar(DeepAgent):
 				done, won, self._n, self.iterations, solved_idx, err = (int(status[i]) for i in (0, 1, 2, 3, 5, 6))
 				if err:
 					raise _ffi.RubiksHipError(f"A* engine error code {err}")
-				if won:
-					path = (C.c_longlong * 4096)()
-					n = lib.rk_astar_path(h, solved_idx, path, 4096, _ffi.stream_ptr())
-					if n < 0:
-						_ffi.check(int(n))
-					self.action_queue = deque(int(a) for a in path[:n])
-					return True
-				if done or time.perf_counter() - t0 >= time_limit:
+				if won or done or time.perf_counter() - t0 >= time_limit:
 					break
+			if won:
+				path = (C.c_longlong * 4096)()
+				n = lib.rk_astar_path(h, solved_idx, path, 4096, _ffi.stream_ptr())
+				if n < 0:
+					_ffi.check(int(n))
+				self.action_queue = deque(int(a) for a in path[:n])
+				return True
 			# out of budget, out of time, or nothing left to expand
 			pool_full = done and self._n + K > cap and lib.rk_astar_open_size(h) > 0
 			if not (pool_full and max_states > cap and time.perf_counter() - t0 < time_limit):
