@@ -36,14 +36,17 @@ struct ExpandWaveLdsT {
 	uint32_t flags[EXP_ROUND * 3];             // 768 B: 12 solved bytes per parent
 };
 
-// The kernel's shape is a set of compile-time knobs; benchmarks/tune_expand.py A/Bs them (profiles/r01_tune_expand*.json).
-// Two shapes ship (launch_expand12): <ROUNDS 1, NT, 4 waves> with one tile per wave, and the same with PRELOAD on a
-// persistent grid for batches whose input no longer fits the Infinity Cache.  Shapes that were tried and dropped from the
-// code because they lost or tied: an atomic tile counter (2-5x slower), per-lane strided input loads instead of the LDS
-// transpose (3 % slower), and a "split" shape where a lane owns (parent, four children) and a wave writes only 3 840 B
-// at 32 waves/CU (45.5 us vs 44.6 us).  The geometry-only diagnostics below show why shapes stop mattering: the same
-// loads and stores WITHOUT any table look-up, transpose or LDS traffic take 44.2 us -- the kernel is bound by its
-// memory access pattern (7 % reads, three streams), which runs at ~6.1 TB/s on this chip.
+// The kernel's shape is a set of compile-time knobs; benchmarks/tune_expand.py A/Bs them (profiles/r01_tune_expand*.json,
+// profiles/r02_tune_expand.json).  Two shapes ship (launch_expand12): <ROUNDS 1, NT, 4 waves> with one tile per wave for
+// small batches, and the same with PRELOAD on a persistent grid of 3 072 workgroups from about half a million parents on --
+// with inputs that really come from HBM (round 2 measures cache-neutral) a wave that only ever sees one tile waits a full
+// memory latency for it; issuing the next tile's loads before expanding the current one takes 1 M parents from 50.0 to
+// 43.5 us.  Shapes that were tried and dropped from the code because they lost or tied: an atomic tile counter (2-5x
+// slower), per-lane strided input loads instead of the LDS transpose (3 % slower), and a "split" shape where a lane owns
+// (parent, four children) and a wave writes only 3 840 B at 32 waves/CU (45.5 us vs 44.6 us).  The geometry-only
+// diagnostics (tuning build) show why shapes stop mattering: the same loads and stores WITHOUT any table look-up,
+// transpose or LDS traffic take within 1 % of the real kernel -- it is bound by its memory access pattern (7 % reads,
+// three streams).
 // ROUNDS = rounds of 64 parents per wave tile (4 -> 256-parent tiles with 16 B/lane input loads, 1 -> 64-parent tiles);
 // NT = non-temporal output stores; NWAVES = waves per workgroup;
 // PRELOAD = software pipeline of the input: a tile's parent loads are issued one tile ahead (the first before the move

@@ -299,6 +299,8 @@ void k_mcts_backup_select(MctsDev d, const float *probs, const float *values)
 	// One round of loads per tree level: the leaf flag and the node's five rows are requested together, and the virtual
 	// loss the previous step owes this node's reverse edge (agents.py:591) is applied on arrival by the lane that owns
 	// that column, so there is no second dependent round trip for the read-modify-write.
+	// (Tried in round 2 and dropped: touching all 12 children's records as soon as `neighbors` arrives, to overlap the
+	// next level's miss with this level's f64 arithmetic -- 31.7 us against 30.6 us without it.)
 	int cur = 1, len = 1, owed_lane = -1;
 	for (;;) {
 		const Node nd = node_of(d, node0, cur);                            // one 512-byte record: four adjacent lines

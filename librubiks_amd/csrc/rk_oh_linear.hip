@@ -12,8 +12,8 @@
 //   MFMA (bf16)         y = A B with v_mfma_f32_32x32x16_bf16 where the A operand (the one-hot tile) is SYNTHESISED IN
 //                       REGISTERS: lane (r, h) of a wave needs A[row r][k = 16 s + 8 h .. +7], eight consecutive one-hot
 //                       columns, which lie inside one cubie's 24 columns (8 | 24) -- so the fragment is "1.0 at position
-//                       state[row][cubie] - offset if that is in 0..7, else zeros": a byte extract and three compares.
-//                       Nothing of A touches LDS or HBM.  B = a 64-column tile of W (bf16, 64 x 480, 61 KB) stays in LDS
+//                       state[row][cubie] - offset if that is in 0..7, else zeros": a byte extract, a subtract, a clamp and
+//                       one read of a 144-byte table of the nine possible fragments.  No one-hot tile in LDS or HBM.  B = a 64-column tile of W (bf16, 64 x 480, 61 KB) stays in LDS
 //                       for all the rows a workgroup handles (row stride 976 B: 244 dwords = 52 mod 64, so the 16 lanes of
 //                       a ds_read_b128 group hit 16 different bank quads); accumulators start at the bias; the epilogue
 //                       rounds to bf16 (nearest even) and goes through LDS so that a wave stores whole 128-byte rows.
@@ -35,6 +35,8 @@ constexpr int OHL_TN = 64;                   // output columns per workgroup (bo
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t f32_to_bf16_rne(float x)
 {
@@ -72,14 +74,17 @@ __device__ __forceinline__ uint32_t code_of(const uint32_t s5[5], int cubie)
 }
 
 // ---- route GATHER ------------------------------------------------------------------------------------------------
+constexpr int OHL_GATHER_THREADS = 512;      // 8 waves (two per SIMD, so that one wave's LDS latency hides behind the other's adds)
+constexpr int OHL_GATHER_ROWS = OHL_GATHER_THREADS / 16;
+
 template <bool OUT_BF16>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(OHL_GATHER_THREADS)
 void k_ohl_gather(const uint32_t *__restrict__ states, const float *__restrict__ wt, const float *__restrict__ bias, void *__restrict__ out,
                   size_t n, int H, size_t rows_per_group)
 {
 	__shared__ __attribute__((aligned(16))) float s_w[OHL_K * OHL_TN];       // 122 880 B: this workgroup's 64 columns of W^T
 	const int tid = threadIdx.x, c0 = blockIdx.x * OHL_TN;
-	for (int i = tid; i < OHL_K * (OHL_TN / 4); i += 256) {
+	for (int i = tid; i < OHL_K * (OHL_TN / 4); i += OHL_GATHER_THREADS) {
 		const int k = i >> 4, q = i & 15;
 		reinterpret_cast<f32x4 *>(s_w)[i] = *reinterpret_cast<const f32x4 *>(wt + (size_t)k * H + c0 + 4 * q);
 	}
@@ -96,13 +101,13 @@ void k_ohl_gather(const uint32_t *__restrict__ states, const float *__restrict__
 			for (int j = 0; j < 5; j++) nxt[j] = states[r * 5 + j];
 		}
 	}
-	for (size_t r = r_begin + (size_t)(wv * 4 + sub); r < r_end; r += 16) {
+	for (size_t r = r_begin + (size_t)(wv * 4 + sub); r < r_end; r += OHL_GATHER_ROWS) {
 		uint32_t s5[5];
 		#pragma unroll
 		for (int j = 0; j < 5; j++) s5[j] = nxt[j];
-		if (r + 16 < r_end) {                                                // next row's states while this row is summed
+		if (r + OHL_GATHER_ROWS < r_end) {                                   // next row's states while this row is summed
 			#pragma unroll
-			for (int j = 0; j < 5; j++) nxt[j] = states[(r + 16) * 5 + j];
+			for (int j = 0; j < 5; j++) nxt[j] = states[(r + OHL_GATHER_ROWS) * 5 + j];
 		}
 		f32x4 acc = b;
 		#pragma unroll
@@ -131,13 +136,21 @@ void k_ohl_mfma(const uint32_t *__restrict__ states, const uint16_t *__restrict_
 {
 	__shared__ __attribute__((aligned(16))) uint8_t s_w[OHL_TN * OHL_WROW];      // 62 464 B
 	__shared__ __attribute__((aligned(16))) uint8_t s_d[4][32 * OHL_DROW];       // 18 432 B
+	__shared__ u32x4 s_frag[9];          // A fragments: entry p < 8 = eight bf16 zeros with 1.0 at position p, entry 8 = all zeros
 	const int tid = threadIdx.x, c0 = blockIdx.x * OHL_TN;
+	if (tid < 9) {
+		const uint32_t one = 0x3F80u << (16 * (tid & 1));
+		const int slot = tid >> 1;
+		s_frag[tid] = tid < 8 ? u32x4{slot == 0 ? one : 0u, slot == 1 ? one : 0u, slot == 2 ? one : 0u, slot == 3 ? one : 0u} : u32x4{0u, 0u, 0u, 0u};
+	}
 	for (int i = tid; i < OHL_TN * 60; i += 256) {
 		const int row = i / 60, ch = i - row * 60;
 		*reinterpret_cast<u32x4 *>(s_w + row * OHL_WROW + ch * 16) = *reinterpret_cast<const u32x4 *>(wb + (size_t)(c0 + row) * OHL_K + ch * 8);
 	}
 	__syncthreads();
 	const int lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
+	// offset of this lane's eight columns inside their cubie, by k-step mod 3: (16 ks + 8 h) % 24
+	const uint32_t off3[3] = {h ? 8u : 0u, h ? 0u : 16u, h ? 16u : 8u};
 	const float bias0 = bias[c0 + r], bias1 = bias[c0 + 32 + r];
 	const uint8_t *wrow0 = s_w + r * OHL_WROW + 16 * h, *wrow1 = s_w + (32 + r) * OHL_WROW + 16 * h;
 	uint8_t *stage = s_d[wv];
@@ -168,26 +181,32 @@ void k_ohl_mfma(const uint32_t *__restrict__ states, const uint16_t *__restrict_
 		for (int v = 0; v < 16; v++) { acc0[v] = bias0; acc1[v] = bias1; }
 		#pragma unroll
 		for (int ks = 0; ks < OHL_K / 16; ks++) {
-			// this lane's eight one-hot columns start at 16 ks + 8 h: inside cubie (16 ks + 8 h) / 24 at offset 0, 8 or 16
+			// This lane's eight one-hot columns start at 16 ks + 8 h: inside cubie (16 ks + 8 h) / 24 at offset 0, 8 or 16.
+			// The fragment is "1.0 at position code - offset if that is in 0..7, else zeros": a byte extract, a subtract, a
+			// clamp and ONE 16-byte LDS read from a nine-entry table (same entry -> broadcast, different entries ->
+			// different banks).  Built from compares on the VALU it took ~20 operations per k-step and, with the bf16
+			// rounding of the epilogue done by hand, made the kernel VALU-bound (37 % of the MFMA rate).
 			const int k_lo = 16 * ks, k_hi = 16 * ks + 8;
-			const int rel_lo = (int)code_of(s5, k_lo / 24) - k_lo % 24;
-			const int rel_hi = (int)code_of(s5, k_hi / 24) - k_hi % 24;
-			const int rel = h ? rel_hi : rel_lo;
-			const uint32_t one = (unsigned)rel < 8u ? 0x3F80u << (16 * (rel & 1)) : 0u;
-			const int slot = rel >> 1;
-			const u32x4 a = u32x4{slot == 0 ? one : 0u, slot == 1 ? one : 0u, slot == 2 ? one : 0u, slot == 3 ? one : 0u};
+			const uint32_t c_lo = (s5[(k_lo / 24) >> 2] >> (8 * ((k_lo / 24) & 3))) & 0xFFu;
+			const uint32_t c_hi = (s5[(k_hi / 24) >> 2] >> (8 * ((k_hi / 24) & 3))) & 0xFFu;
+			uint32_t rel = (h ? c_hi : c_lo) - off3[ks % 3];             // wraps to a huge value when the code is below the offset
+			rel = rel < 8u ? rel : 8u;                                   // (codes >= 24 also end up at the zero entry)
+			const u32x4 a = s_frag[rel];
 			const u32x4 b0 = *reinterpret_cast<const u32x4 *>(wrow0 + 32 * ks);
 			const u32x4 b1 = *reinterpret_cast<const u32x4 *>(wrow1 + 32 * ks);
 			const bf16x8 A = __builtin_bit_cast(bf16x8, a);
 			acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(bf16x8, b0), acc0, 0, 0, 0);
 			acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(bf16x8, b1), acc1, 0, 0, 0);
 		}
-		// epilogue: C/D element v of lane (r, h) is row (v & 3) + 8 (v >> 2) + 4 h, column r
+		// epilogue: C/D element v of lane (r, h) is row (v & 3) + 8 (v >> 2) + 4 h, column r; v_cvt_pk_bf16_f32 rounds two
+		// values per instruction (nearest even), the halves go to LDS as 16-bit stores
 		#pragma unroll
 		for (int v = 0; v < 16; v++) {
 			const int i = (v & 3) + 8 * (v >> 2) + 4 * h;
-			reinterpret_cast<uint16_t *>(stage + i * OHL_DROW)[r] = (uint16_t)f32_to_bf16_rne(acc0[v]);
-			reinterpret_cast<uint16_t *>(stage + i * OHL_DROW)[32 + r] = (uint16_t)f32_to_bf16_rne(acc1[v]);
+			const f32x2 pair = {acc0[v], acc1[v]};
+			const uint32_t packed = __builtin_bit_cast(uint32_t, __builtin_convertvector(pair, bf16x2));
+			reinterpret_cast<uint16_t *>(stage + i * OHL_DROW)[r] = (uint16_t)packed;
+			reinterpret_cast<uint16_t *>(stage + i * OHL_DROW)[32 + r] = (uint16_t)(packed >> 16);
 		}
 		wave_lds_fence();
 		#pragma unroll
@@ -254,7 +273,7 @@ int rk_ohl_forward(rk_ohl_t *h, const int8_t *d_states, void *d_out, int out_dty
 	hipStream_t st = (hipStream_t)stream;
 	const unsigned col_tiles = (unsigned)(h->H / OHL_TN);
 	// about one workgroup per CU (gather: 120 KB of LDS each) or two (MFMA): the weight slice is loaded once per workgroup
-	const size_t quantum = route == RK_OHL_MFMA ? 128 : 16;
+	const size_t quantum = route == RK_OHL_MFMA ? 128 : OHL_GATHER_ROWS;
 	size_t groups = (route == RK_OHL_MFMA ? 512u : 256u) / col_tiles;
 	if (groups < 1) groups = 1;
 	const size_t max_groups = (n + quantum - 1) / quantum;
@@ -266,9 +285,9 @@ int rk_ohl_forward(rk_ohl_t *h, const int8_t *d_states, void *d_out, int out_dty
 	const dim3 grid(col_tiles, (unsigned)groups);
 	if (route == RK_OHL_GATHER) {
 		if (out_dtype == RK_OH_F32)
-			hipLaunchKernelGGL(k_ohl_gather<false>, grid, dim3(256), 0, st, (const uint32_t *)d_states, h->wt_f32, h->bias, d_out, n, h->H, rows);
+			hipLaunchKernelGGL(k_ohl_gather<false>, grid, dim3(OHL_GATHER_THREADS), 0, st, (const uint32_t *)d_states, h->wt_f32, h->bias, d_out, n, h->H, rows);
 		else
-			hipLaunchKernelGGL(k_ohl_gather<true>, grid, dim3(256), 0, st, (const uint32_t *)d_states, h->wt_f32, h->bias, d_out, n, h->H, rows);
+			hipLaunchKernelGGL(k_ohl_gather<true>, grid, dim3(OHL_GATHER_THREADS), 0, st, (const uint32_t *)d_states, h->wt_f32, h->bias, d_out, n, h->H, rows);
 	} else {
 		hipLaunchKernelGGL(k_ohl_mfma, grid, dim3(256), 0, st, (const uint32_t *)d_states, h->w_bf16, h->bias, (uint16_t *)d_out, n, h->H, rows);
 	}
