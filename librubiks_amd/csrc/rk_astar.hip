@@ -940,6 +940,7 @@ struct rk_astar {
 	int n_exp = 0;                // expansions of the pending / next iteration (host view)
 	bool ready = false, pending = false;
 	bool budget_explicit = false; // rk_astar_set_budget was called since the last reset
+	int last_n_new = 0, last_n_before = 0;    // sizes reported by the last rk_astar_expand
 	std::vector<void *> allocs;
 };
 
@@ -1179,30 +1180,32 @@ int rk_astar_expand(rk_astar_t *h, int n_expand, long long *h_info, void *stream
 		hipLaunchKernelGGL(k_pop_select_only, dim3(1), dim3(1024), 0, st, h->d, n_expand);
 		h->n_exp = n_expand;
 	}
-	if (int e = read_ctr(h, c, st)) return e;
-	// a host that never set a state budget learns about a full pool as an error; with a budget the engine's own loop
-	// guard has ended the search (done, nothing popped) before the pool can overflow
-	if (!h->budget_explicit && (size_t)c[C_NSTATES] + 12 * (size_t)c[C_NCAND] > h->cap)
-		return fail(RK_ECAPACITY, "rk_astar_expand: %d states + %d children exceed capacity %zu", c[C_NSTATES], 12 * c[C_NCAND], h->cap);
+	if (!h->budget_explicit) {
+		// a host that never set a state budget learns about a full pool as an error; with a budget the engine's own loop
+		// guard has ended the search (done, nothing popped) before the pool can overflow, and this round trip is skipped
+		if (int e = read_ctr(h, c, st)) return e;
+		if ((size_t)c[C_NSTATES] + 12 * (size_t)c[C_NCAND] > h->cap)
+			return fail(RK_ECAPACITY, "rk_astar_expand: %d states + %d children exceed capacity %zu", c[C_NSTATES], 12 * c[C_NCAND], h->cap);
+	}
 	if (int e = rk_astar_step_expand(h, nullptr, RK_OH_F32, stream)) return e;
-	const int n_pop = c[C_NPOP];
-	if (int e = read_ctr(h, c, st)) return e;
-	h_info[0] = n_pop; h_info[1] = c[C_NNEW]; h_info[2] = c[C_WON]; h_info[3] = c[C_SOLVED]; h_info[4] = c[C_NSTATES];
+	if (int e = read_ctr(h, c, st)) return e;            // the one synchronisation of the iteration (the kernels above leave NPOP alone)
+	h->last_n_new = c[C_NNEW];
+	h->last_n_before = c[C_NBEFORE];
+	h_info[0] = c[C_NPOP]; h_info[1] = c[C_NNEW]; h_info[2] = c[C_WON]; h_info[3] = c[C_SOLVED]; h_info[4] = c[C_NSTATES];
 	return RK_OK;
 }
 
 int rk_astar_new_states_oh(rk_astar_t *h, void *d_out, int out_dtype, void *stream)
 {
 	if (!h || !h->pending) return fail(RK_ESTATE, "rk_astar_new_states_oh: no pending expansion");
-	int32_t c[C_COUNT];
-	if (int e = read_ctr(h, c, (hipStream_t)stream)) return e;
-	if (c[C_NNEW] == 0) return RK_OK;
+	const size_t n_new = (size_t)h->last_n_new, first = (size_t)h->last_n_before + 1;      // as reported by rk_astar_expand
+	if (n_new == 0) return RK_OK;
 	if (out_dtype == RK_OH_STATES) {              // first layer fused: the new states themselves
 		if (!d_out) return fail(RK_EINVAL, "rk_astar_new_states_oh: null output");
-		RK_HIP(hipMemcpyAsync(d_out, h->d.states + ((size_t)c[C_NBEFORE] + 1) * 5, (size_t)c[C_NNEW] * STATE_BYTES, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+		RK_HIP(hipMemcpyAsync(d_out, h->d.states + first * 5, n_new * STATE_BYTES, hipMemcpyDeviceToDevice, (hipStream_t)stream));
 		return RK_OK;
 	}
-	return rk_as_oh(RK_REPR_2024, (const int8_t *)(h->d.states + ((size_t)c[C_NBEFORE] + 1) * 5), d_out, out_dtype, (size_t)c[C_NNEW], stream);
+	return rk_as_oh(RK_REPR_2024, (const int8_t *)(h->d.states + first * 5), d_out, out_dtype, n_new, stream);
 }
 
 int rk_astar_commit(rk_astar_t *h, const float *d_values, void *stream)

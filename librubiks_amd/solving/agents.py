@@ -238,6 +238,17 @@ def _oh_dtype(net) -> torch.dtype:
 	return torch.float32
 
 
+def _has_f32_weights(net) -> bool:
+	"""True for a torch module whose first floating-point parameter is float32 (a forward pass on thousands of rows then
+	costs milliseconds); False for low-precision nets and for parameter-free heuristics."""
+	params = getattr(net, "parameters", None)
+	if callable(params):
+		for prm in params():
+			if prm.dtype in _OH_CODES:
+				return prm.dtype == torch.float32
+	return False
+
+
 def _value_f32(out) -> torch.Tensor:
 	"""The net's value head as a contiguous float32 vector on the GPU."""
 	if isinstance(out, (list, tuple)):
@@ -260,8 +271,10 @@ class AStar(DeepAgent):
 	    (K, 480) one-hot batch -> `rk_astar_step_commit`: six small launches around the net, no host synchronisation; the
 	    host polls the engine's status every few iterations (never past the state budget; steps after a win are no-ops
 	    on the device).  `use_hipgraph=True` captures the iteration once (the net must be capturable) and replays it.
-	  * K >= 2048 (the net dominates): `rk_astar_expand` synchronises once per iteration (about 30 us against
-	    milliseconds of net) so that the net runs on exactly the new states instead of the padded batch.
+	  * `exact_batch` (default: K >= 2048 with a float32 net, i.e. when a forward pass costs milliseconds):
+	    `rk_astar_expand` synchronises once per iteration so that the net runs on exactly the new states instead of the
+	    padded batch (measured with fc_small at N = 700 ... 1000: 15 % faster in float32, but 20 % slower than running
+	    ahead of the GPU with the three times faster bf16 net).
 
 	`capacity` bounds the number of stored states when a search is limited only by time (the reference grows its
 	arrays without bound): the pool doubles (a new engine, the search restarts from the root) until `max_capacity`;
@@ -271,8 +284,9 @@ class AStar(DeepAgent):
 	max_capacity = 64_000_000
 
 	def __init__(self, net, lambda_: float, expansions: int, capacity: int = None, poll: int = 4, use_hipgraph: bool = False,
-	             fused_first_layer: bool = False):
+	             fused_first_layer: bool = False, exact_batch: bool = None):
 		super().__init__(net)
+		self.exact_batch = exact_batch
 		# fused_first_layer: the engine hands the net the new nodes' 20-byte states and the net's first Linear(480, H)
 		# reads them directly (librubiks_amd.oh_linear) -- no one-hot batch exists at all
 		self._from_states = None
@@ -370,7 +384,8 @@ class AStar(DeepAgent):
 					self._iteration(h, oh, code)
 			budget = int(min(max_states, cap))
 			done = won = err = solved_idx = 0
-			exact = K >= 2048 and graph is None and not self.record_pops
+			exact = self.exact_batch if self.exact_batch is not None else (K >= 2048 and _has_f32_weights(self.net))
+			exact = exact and graph is None and not self.record_pops
 			info = (C.c_longlong * 5)()
 			while exact:
 				# one synchronisation per iteration, the net sees exactly the new states (agents.py:315, :369-383)

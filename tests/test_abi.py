@@ -130,3 +130,29 @@ def test_repr_switch():
 		def which(self):
 			return cube.get_is2024()
 	assert User().which() is False and cube.get_is2024()
+
+
+def test_from_saved_uses_a_loader_or_the_reference_model():
+	"""`from_saved` keeps the reference's signatures (agents.py:72-76, 144-148, 404-407, 635-639, 720-723); the net comes
+	from a caller-supplied loader or, in the drop-in situation, from the reference's own `librubiks.model.Model`."""
+	from librubiks_amd.solving import agents
+
+	class Net:
+		def eval(self):
+			return self
+	seen = []
+
+	def loader(loc, use_best):
+		seen.append((loc, use_best))
+		return Net()
+	a = agents.AStar.from_saved("some/folder", True, lambda_=0.2, expansions=64, loader=loader)
+	assert isinstance(a.net, Net) and a.lambda_ == 0.2 and a.expansions == 64
+	m = agents.MCTS.from_saved("some/folder", False, c=0.6, search_graph=True, loader=loader)
+	assert m.c == 0.6 and m.search_graph is True
+	e = agents.EGVM.from_saved("x", True, epsilon=0.3, workers=10, depth=50, loader=loader)
+	assert (e.epsilon, e.workers, e.depth) == (0.3, 10, 50)
+	p = agents.PolicySearch.from_saved("x", True, sample_policy=True, loader=loader)
+	assert p.sample_policy and isinstance(agents.ValueSearch.from_saved("x", False, loader=loader).net, Net)
+	assert seen[0] == ("some/folder", True) and len(seen) == 5
+	with pytest.raises(ImportError, match="librubiks.model"):
+		agents.AStar.from_saved("some/folder", True, lambda_=0.2, expansions=64)       # the reference is not installed here
