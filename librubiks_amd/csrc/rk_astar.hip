@@ -91,7 +91,7 @@ struct AstarDev {
 	int32_t *seen; uint32_t *child_slot; uint8_t *flags; int32_t *rank_local;
 	uint8_t *newway, *shortcut; int32_t *val1, *val2;
 	Rec *rec0, *rec1;
-	unsigned long long *chain0, *chain1, *chain2;                    // chained-scan words
+	unsigned long long *chain0, *chain1, *chain2;                    // look-back words {epoch, total} of the in-launch compactions
 	uint8_t *hit;
 	double *gather_in;                                               // sharded: this rank's all-gather contribution
 };
@@ -625,7 +625,7 @@ void k_end(AstarDev d, int new_in_rec1, int count_iteration)
 		for (int j = d.q.levels; j < QL; j++) { s_meta[Q_HEAD * QL + j] = 0; s_meta[Q_LEN * QL + j] = 0; s_meta[Q_CUR * QL + j] = 0; s_meta[Q_TAKE * QL + j] = 0; }
 		const bool ran = SHARDED ? s_ctr[C_DONE] == 0 : n_pop > 0;
 		if (ran && count_iteration) s_ctr[C_ITERS] += 1;
-		s_ctr[C_EPOCH] += 1;                                             // chained-scan words of this launch sequence expire
+		s_ctr[C_EPOCH] += 1;                                             // look-back words of this launch sequence expire
 		const int n_states = s_ctr[C_NSTATES];
 		s_ctr[C_NBEFORE] = n_states;
 		s_ctr[C_OPEN] = open;
@@ -729,7 +729,7 @@ __global__ void k_astar_find(const uint32_t *query, const uint32_t *states, cons
 //   k_shard_decide     identical on every rank: stop conditions (won, budget, capacity, time, error, nothing open) and
 //                      the global top-N by (cost, rank, position) -> how many of its own candidates this rank pops
 //   k_shard_expand     expand those, build the 32-byte child records, bucket them by owner into the send blocks with a
-//                      stable (batch-order) partition: per-owner chained scan across workgroups, all in ONE launch.
+//                      stable (batch-order) partition: per-owner ticket + look-back scan across workgroups, all in ONE launch.
 //                      The send block of a peer also carries the shortcut offers of the PREVIOUS iteration.
 //   [all-to-all]       equal splits of one block per peer: {header, <= K records, <= K offers}; the counts travel in
 //                      the header, so there is no count exchange and no host involvement
@@ -1094,7 +1094,7 @@ static int astar_reset_impl(rk_astar_t *h, const int8_t *h_start_state, double l
 	d.lambda = lambda;
 	RK_HIP(hipMemsetAsync(d.table, 0, ((size_t)d.mask + 1) * sizeof(uint32_t), st));
 	RK_HIP(hipMemsetAsync(d.mark, 0xFF, (h->cap + 1) * sizeof(uint32_t), st));
-	// chained-scan epochs restart with the iteration counter: forget the words of the previous search
+	// look-back epochs restart with the search: forget the words of the previous one
 	const size_t n_scan_blocks = ((size_t)(d.world == 1 ? d.K : d.KI) + 64 + ASCAN - 1) / ASCAN + 1;
 	RK_HIP(hipMemsetAsync(d.chain0, 0, n_scan_blocks * sizeof(unsigned long long), st));
 	RK_HIP(hipMemsetAsync(d.chain1, 0, n_scan_blocks * d.world * sizeof(unsigned long long), st));
