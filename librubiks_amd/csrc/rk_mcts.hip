@@ -9,7 +9,9 @@
 // into ONE 512-byte, 512-byte-aligned record per node -- exactly four 128-byte lines, one page -- so that a level of
 // the descent (and a step of the backup) is one contiguous fetch instead of six arrays gigabytes apart:
 //   +0 expanded uint32 (leaves = !expanded) | +8 V float64 | +16 N int32[12] | +64 neighbors int32[12] |
-//   +112 P float64[12] | +208 W float64[12] | +304 L float64[12] | +400 stamp int32[12] | +448 unused
+//   +112 P float64[12] | +208 W float64[12] | +304 L float64[12] | +400 stamp int32[12] |
+//   +448 sumN int32 = sum of N, +456 sqrtN float64 = sqrt(sumN): maintained by the backup (64 path nodes in parallel) so
+//   that the descent -- a serial pointer chase -- reads sqrt(sum N) (agents.py:580) instead of reducing and rooting it
 // (stamp = simulation number of the last N increment: NumPy's `N[path, actions] += 1` counts a repeated (node, action)
 // pair once), plus states int8 (cap,20) kept dense, a hash table state -> index, and the current path.
 //
@@ -38,14 +40,24 @@ struct MctsDev {
 	uint8_t *nodes;           // 512-byte node records
 	uint32_t *table;
 	int32_t *path_nodes; uint8_t *path_actions;
-	int32_t *path_len, *n_states, *max_states, *sims, *solve_action, *solve_leaf, *error;
-	uint8_t *done, *solved;
+	int32_t *tree;            // per-tree scalars, one 32-byte record each (TR_*): both kernels fetch them with ONE 32-byte load
+	                          // instead of five dependent round trips to five arrays
 	// per-simulation hand-off between expand and backup
 	uint32_t *children; int32_t *child_idx; uint8_t *child_new;
 };
 
+enum { TR_PLEN = 0, TR_NSTATES, TR_MAXSTATES, TR_SIMS, TR_SOLVE_ACTION, TR_SOLVE_LEAF, TR_ERROR, TR_FLAGS /* done | solved << 8 */, TR_INTS = 8 };
+
+struct TreeRec { int32_t v[TR_INTS]; };
+
+__device__ __forceinline__ TreeRec load_tree(const int32_t *tree, int t)
+{
+	const u32x4 a = reinterpret_cast<const u32x4 *>(tree)[2 * t], b = reinterpret_cast<const u32x4 *>(tree)[2 * t + 1];
+	return TreeRec{{(int32_t)a.x, (int32_t)a.y, (int32_t)a.z, (int32_t)a.w, (int32_t)b.x, (int32_t)b.y, (int32_t)b.z, (int32_t)b.w}};
+}
+
 constexpr int NODE_BYTES = 512;
-constexpr int OFF_EXPANDED = 0, OFF_V = 8, OFF_N = 16, OFF_NB = 64, OFF_P = 112, OFF_W = 208, OFF_L = 304, OFF_STAMP = 400;
+constexpr int OFF_EXPANDED = 0, OFF_V = 8, OFF_N = 16, OFF_NB = 64, OFF_P = 112, OFF_W = 208, OFF_L = 304, OFF_STAMP = 400, OFF_SUMN = 448, OFF_SQRTN = 456;
 
 struct Node {
 	uint8_t *p;
@@ -57,6 +69,8 @@ struct Node {
 	__device__ __forceinline__ double *W() const { return reinterpret_cast<double *>(p + OFF_W); }
 	__device__ __forceinline__ double *L() const { return reinterpret_cast<double *>(p + OFF_L); }
 	__device__ __forceinline__ int32_t *stamp() const { return reinterpret_cast<int32_t *>(p + OFF_STAMP); }
+	__device__ __forceinline__ int32_t *sumN() const { return reinterpret_cast<int32_t *>(p + OFF_SUMN); }
+	__device__ __forceinline__ double &sqrtN() const { return *reinterpret_cast<double *>(p + OFF_SQRTN); }
 };
 
 __device__ __forceinline__ Node node_of(const MctsDev &d, size_t node0, int idx)
@@ -126,7 +140,7 @@ __device__ __forceinline__ void fence_wave_to_wave()
 
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64)
-void k_mcts_root(MctsDev d, const uint32_t *starts)
+void k_mcts_root(MctsDev d, const uint32_t *starts, const int32_t *max_states)
 {
 	const int t = blockIdx.x, lane = threadIdx.x;
 	uint32_t s[5];
@@ -137,16 +151,17 @@ void k_mcts_root(MctsDev d, const uint32_t *starts)
 		#pragma unroll
 		for (int j = 0; j < 5; j++) st[j] = s[j];
 		d.table[(size_t)t * (d.tmask + 1) + (mcts_hash(s) & d.tmask)] = 1u;
-		d.n_states[t] = 1;
+		int32_t *tr = d.tree + (size_t)t * TR_INTS;
+		tr[TR_NSTATES] = 1;
+		tr[TR_MAXSTATES] = max_states[t];
 		d.path_nodes[(size_t)t * d.max_path] = 1;
-		d.path_len[t] = 1;
-		d.sims[t] = 0;
-		d.error[t] = 0;
-		d.solve_action[t] = -1;
-		d.solve_leaf[t] = -1;
+		tr[TR_PLEN] = 1;
+		tr[TR_SIMS] = 0;
+		tr[TR_ERROR] = 0;
+		tr[TR_SOLVE_ACTION] = -1;
+		tr[TR_SOLVE_LEAF] = -1;
 		const bool solved = is_solved5(s);            // agents.py:468: a solved start returns immediately
-		d.done[t] = solved ? 1 : 0;
-		d.solved[t] = solved ? 2 : 0;
+		tr[TR_FLAGS] = solved ? (1 | (2 << 8)) : 0;
 	}
 }
 
@@ -179,14 +194,16 @@ void k_mcts_expand(MctsDev d)
 	const bool active = lane < 12;
 	const size_t cbase = (size_t)t * 12 + lane;
 	if (active) d.child_new[cbase] = 0;
-	if (d.done[t]) return;
-	const int n = d.n_states[t];
-	if (n + 12 > d.max_states[t]) {                   // loop guard of agents.py:476
-		if (lane == 0) d.done[t] = 1;
+	const TreeRec tr = load_tree(d.tree, t);
+	int32_t *trw = d.tree + (size_t)t * TR_INTS;
+	if (tr.v[TR_FLAGS] & 0xFF) return;                 // done
+	const int n = tr.v[TR_NSTATES];
+	if (n + 12 > tr.v[TR_MAXSTATES]) {                // loop guard of agents.py:476
+		if (lane == 0) trw[TR_FLAGS] = tr.v[TR_FLAGS] | 1;
 		return;
 	}
 	const size_t node0 = (size_t)t * d.cap1;
-	const int plen = d.path_len[t];
+	const int plen = tr.v[TR_PLEN];
 	const int leaf = d.path_nodes[(size_t)t * d.max_path + plen - 1];
 
 	uint32_t s[5];
@@ -226,13 +243,13 @@ void k_mcts_expand(MctsDev d)
 	}
 	const unsigned long long solvedmask = __ballot(active && is_solved5(s));   // agents.py:540-543: first solved child
 	if (solvedmask != 0ull && lane == __ffsll((long long)solvedmask) - 1) {
-		d.solved[t] = 1;
-		d.solve_action[t] = lane;
-		d.solve_leaf[t] = idx;
+		trw[TR_FLAGS] = (tr.v[TR_FLAGS] & 0xFF) | (1 << 8);              // solved = 1
+		trw[TR_SOLVE_ACTION] = lane;
+		trw[TR_SOLVE_LEAF] = idx;
 	}
 	if (lane == 0) {
 		node_of(d, node0, leaf).expanded() = 1u;                           // leaves[leaf] = False, agents.py:536
-		d.n_states[t] = n + __popcll(newmask);
+		trw[TR_NSTATES] = n + __popcll(newmask);
 	}
 }
 
@@ -248,8 +265,10 @@ void k_mcts_backup_select(MctsDev d, const float *probs, const float *values)
 	uint8_t *pacts = d.path_actions + (size_t)t * d.max_path;
 	// everything that does not depend on another load is requested before the first wait (the early exits used to put a
 	// round trip between each of these: six of them before any work)
-	const uint8_t is_done = d.done[t], tree_solved = d.solved[t];
-	const int plen = d.path_len[t], sims_before = d.sims[t];
+	const TreeRec tr = load_tree(d.tree, t);
+	int32_t *trw = d.tree + (size_t)t * TR_INTS;
+	const int is_done = tr.v[TR_FLAGS] & 0xFF, tree_solved = tr.v[TR_FLAGS] >> 8;
+	const int plen = tr.v[TR_PLEN], sims_before = tr.v[TR_SIMS];
 	const int idx = active ? d.child_idx[cbase] : 0;
 	const bool is_new = active && d.child_new[cbase] != 0;
 	const float vf = active ? values[cbase] : 0.0f;
@@ -281,15 +300,21 @@ void k_mcts_backup_select(MctsDev d, const float *probs, const float *values)
 		const int cnt = nd.N()[act];
 		const int last = atomicExch(&nd.stamp()[act], sim);
 		if (has_new && best > w) nd.W()[act] = best;                       // agents.py:562
-		if (last != sim) nd.N()[act] = cnt + 1;                            // agents.py:568 (a repeated pair counts once)
+		if (last != sim) {                                                 // agents.py:568 (a repeated pair counts once)
+			nd.N()[act] = cnt + 1;
+			// the node may sit on the path more than once (with different actions): the sum is an atomic count, and the
+			// root of the LARGEST count must stay (non-negative doubles order like their bit patterns)
+			const int total = atomicAdd(nd.sumN(), 1) + 1;
+			atomicMax(reinterpret_cast<unsigned long long *>(&nd.sqrtN()), (unsigned long long)__double_as_longlong(sqrt((double)total)));
+		}
 		nd.L()[act] = 0.0;                                                 // agents.py:569
 		node_of(d, node0, pnodes[e + 1]).L()[act ^ 1] = 0.0;               // agents.py:570
 	}
-	if (lane == 0) d.sims[t] = sim;
+	if (lane == 0) trw[TR_SIMS] = sim;
 	if (tree_solved) {                                                     // agents.py:482-487
 		if (lane == 0) {
-			pacts[plen - 1] = (uint8_t)d.solve_action[t];
-			d.done[t] = 1;
+			pacts[plen - 1] = (uint8_t)tr.v[TR_SOLVE_ACTION];
+			trw[TR_FLAGS] = tr.v[TR_FLAGS] | 1;
 		}
 		return;
 	}
@@ -304,24 +329,23 @@ void k_mcts_backup_select(MctsDev d, const float *probs, const float *values)
 	int cur = 1, len = 1, owed_lane = -1;
 	for (;;) {
 		const Node nd = node_of(d, node0, cur);                            // one 512-byte record: four adjacent lines
-		const int col = active ? lane : 0;
+		const int col = lane < 12 ? lane : 11;                             // idle lanes re-read column 11: no branches, no extra lines
 		const uint32_t expanded = nd.expanded();
-		const int nA = active ? nd.N()[col] : 0;
-		const double pA = active ? nd.P()[col] : 0.0, wA = active ? nd.W()[col] : 0.0;
-		double lval = active ? nd.L()[col] : 0.0;
-		const int nb = active ? nd.nb()[col] : 0;
+		const double sqrtN = nd.sqrtN();
+		const int nA = nd.N()[col];
+		const double pA = nd.P()[col], wA = nd.W()[col];
+		double lval = nd.L()[col];
+		const int nb = nd.nb()[col];
 		if (lane == owed_lane) { lval += d.nu; nd.L()[col] = lval; }       // agents.py:591
 		if (!expanded) break;
-		const int sumN = __builtin_amdgcn_readfirstlane(row_sum_i(nA));
 		double x = -INFINITY;
 		int best_a = lane;
-		if (active) {
-			const double sqrtN = sqrt((double)sumN);
-			double U = d.c * pA;
+		{
+			double U = d.c * pA;                                           // U = c * P * sqrt(sum N) / (1 + N), left to right
 			U = U * sqrtN;
 			U = U / (double)(1 + nA);
 			const double Q = wA - lval;
-			x = U + Q;
+			x = active ? U + Q : -INFINITY;
 		}
 		best_a = __builtin_amdgcn_readfirstlane(row_argmax_first(x, best_a));   // first arg-max (np.argmax), wave-uniform
 		const int next = __builtin_amdgcn_readlane(nb, best_a);
@@ -334,11 +358,11 @@ void k_mcts_backup_select(MctsDev d, const float *probs, const float *values)
 		len++;
 		cur = next;
 		if (len >= (int)d.max_path || next <= 0) {
-			if (lane == 0) { d.error[t] = next <= 0 ? 2 : 1; d.done[t] = 1; }
+			if (lane == 0) { trw[TR_ERROR] = next <= 0 ? 2 : 1; trw[TR_FLAGS] = tr.v[TR_FLAGS] | 1; }
 			break;
 		}
 	}
-	if (lane == 0) d.path_len[t] = len;
+	if (lane == 0) trw[TR_PLEN] = len;
 }
 
 }  // namespace rk
@@ -350,6 +374,7 @@ struct rk_mcts {
 	size_t capacity = 0;
 	std::vector<void *> allocs;
 	uint32_t *starts_dev = nullptr;
+	int32_t *max_states_dev = nullptr;
 	bool ready = false;
 };
 
@@ -392,11 +417,11 @@ int rk_mcts_create(rk_mcts_t **out, int n_trees, size_t capacity_per_tree, size_
 	A(states, rows * 5); A(nodes, (rows + 1) * NODE_BYTES);
 	A(table, T * (size_t)ts);
 	A(path_nodes, T * max_path); A(path_actions, T * max_path);
-	A(path_len, T); A(n_states, T); A(max_states, T); A(sims, T); A(solve_action, T); A(solve_leaf, T); A(error, T);
-	A(done, T); A(solved, T);
+	A(tree, T * TR_INTS + 16);
 	A(children, T * 12 * 5 + 64); A(child_idx, T * 12); A(child_new, T * 12);
 	#undef A
 	if (!e) e = mcts_alloc(h, &h->starts_dev, T * 5);
+	if (!e) e = mcts_alloc(h, &h->max_states_dev, T);
 	if (e) { rk_mcts_destroy(h); return e; }
 	*out = h;
 	return RK_OK;
@@ -430,9 +455,9 @@ int rk_mcts_reset(rk_mcts_t *h, const int8_t *h_start_states, const long long *h
 	RK_HIP(hipMemsetAsync(d.child_new, 0, T * 12, st));
 	RK_HIP(hipMemsetAsync(d.child_idx, 0, T * 12 * sizeof(int32_t), st));
 	RK_HIP(hipMemsetAsync(d.children, 0, (T * 12 * 5) * sizeof(uint32_t), st));
-	RK_HIP(hipMemcpyAsync(d.max_states, ms.data(), T * sizeof(int32_t), hipMemcpyHostToDevice, st));
+	RK_HIP(hipMemcpyAsync(h->max_states_dev, ms.data(), T * sizeof(int32_t), hipMemcpyHostToDevice, st));
 	RK_HIP(hipMemcpyAsync(h->starts_dev, h_start_states, T * STATE_BYTES, hipMemcpyHostToDevice, st));
-	hipLaunchKernelGGL(k_mcts_root, dim3(d.T), dim3(64), 0, st, d, h->starts_dev);
+	hipLaunchKernelGGL(k_mcts_root, dim3(d.T), dim3(64), 0, st, d, h->starts_dev, h->max_states_dev);
 	RK_HIP(hipGetLastError());
 	RK_HIP(hipStreamSynchronize(st));           // host buffers may go away after return
 	h->ready = true;
@@ -497,18 +522,13 @@ int rk_mcts_status(rk_mcts_t *h, long long *h_status, void *stream)
 	hipStream_t st = (hipStream_t)stream;
 	const MctsDev &d = h->d;
 	const size_t T = (size_t)d.T;
-	std::vector<uint8_t> done(T), solved(T);
-	std::vector<int32_t> n(T), sims(T), plen(T), err(T);
-	RK_HIP(hipMemcpyAsync(done.data(), d.done, T, hipMemcpyDeviceToHost, st));
-	RK_HIP(hipMemcpyAsync(solved.data(), d.solved, T, hipMemcpyDeviceToHost, st));
-	RK_HIP(hipMemcpyAsync(n.data(), d.n_states, T * 4, hipMemcpyDeviceToHost, st));
-	RK_HIP(hipMemcpyAsync(sims.data(), d.sims, T * 4, hipMemcpyDeviceToHost, st));
-	RK_HIP(hipMemcpyAsync(plen.data(), d.path_len, T * 4, hipMemcpyDeviceToHost, st));
-	RK_HIP(hipMemcpyAsync(err.data(), d.error, T * 4, hipMemcpyDeviceToHost, st));
+	std::vector<int32_t> rec(T * TR_INTS);
+	RK_HIP(hipMemcpyAsync(rec.data(), d.tree, T * TR_INTS * sizeof(int32_t), hipMemcpyDeviceToHost, st));
 	RK_HIP(hipStreamSynchronize(st));
 	for (size_t t = 0; t < T; t++) {
+		const int32_t *tr = rec.data() + t * TR_INTS;
 		long long *r = h_status + 6 * t;
-		r[0] = done[t]; r[1] = solved[t]; r[2] = n[t]; r[3] = sims[t]; r[4] = plen[t]; r[5] = err[t];
+		r[0] = tr[TR_FLAGS] & 0xFF; r[1] = tr[TR_FLAGS] >> 8; r[2] = tr[TR_NSTATES]; r[3] = tr[TR_SIMS]; r[4] = tr[TR_PLEN]; r[5] = tr[TR_ERROR];
 	}
 	return RK_OK;
 }
@@ -555,11 +575,11 @@ long long rk_mcts_path(rk_mcts_t *h, int tree, long long *h_actions, long long *
 	const MctsDev &d = h->d;
 	if (tree < 0 || tree >= d.T) return fail(RK_EINVAL, "rk_mcts_path: tree %d out of range", tree);
 	hipStream_t st = (hipStream_t)stream;
-	int32_t plen = 0;
-	uint8_t solved = 0;
-	RK_HIP(hipMemcpyAsync(&plen, d.path_len + tree, 4, hipMemcpyDeviceToHost, st));
-	RK_HIP(hipMemcpyAsync(&solved, d.solved + tree, 1, hipMemcpyDeviceToHost, st));
+	int32_t tr[TR_INTS];
+	RK_HIP(hipMemcpyAsync(tr, d.tree + (size_t)tree * TR_INTS, sizeof tr, hipMemcpyDeviceToHost, st));
 	RK_HIP(hipStreamSynchronize(st));
+	const int32_t plen = tr[TR_PLEN];
+	const int solved = tr[TR_FLAGS] >> 8;
 	if (plen < 1) return fail(RK_ESTATE, "rk_mcts_path: empty path");
 	std::vector<int32_t> nodes((size_t)plen);
 	std::vector<uint8_t> acts((size_t)plen);

@@ -156,29 +156,30 @@ void k_ohl_mfma(const uint32_t *__restrict__ states, const uint16_t *__restrict_
 	uint8_t *stage = s_d[wv];
 	const size_t r_begin = (size_t)blockIdx.y * rows_per_group;
 	const size_t r_end = r_begin + rows_per_group < n ? r_begin + rows_per_group : n;
-	// the states of the NEXT row tile are requested before the current one is multiplied: with two waves per SIMD nothing
-	// else would hide the load latency (about twice the tile's MFMA time)
-	uint32_t nxt[5] = {0u, 0u, 0u, 0u, 0u};
-	{
-		const size_t m0 = r_begin + (size_t)wv * 32;
-		if (m0 < r_end) {
-			const size_t row = m0 + r < r_end ? m0 + r : r_end - 1;
-			#pragma unroll
-			for (int j = 0; j < 5; j++) nxt[j] = states[row * 5 + j];
-		}
-	}
-	for (size_t m0 = r_begin + (size_t)wv * 32; m0 < r_end; m0 += 128) {
-		uint32_t s5[5];
+	// A wave multiplies TWO 32-row tiles per pass (rows m0 .. m0+63): the B fragments it reads from LDS serve both (the
+	// LDS pipe, at 78 % busy with one tile per pass, was co-limiting with the matrix pipe) and four independent
+	// accumulator chains keep the MFMAs issuing back to back.  The states of the NEXT pass are requested before the current
+	// one is multiplied: with two waves per SIMD nothing else would hide that load latency.
+	uint32_t nxt[2][5] = {{0u, 0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u, 0u}};
+	auto request = [&](size_t m0) {
 		#pragma unroll
-		for (int j = 0; j < 5; j++) s5[j] = nxt[j];
-		if (m0 + 128 < r_end) {
-			const size_t row = m0 + 128 + r < r_end ? m0 + 128 + r : r_end - 1;     // tail rows repeat the last row (never stored)
+		for (int t = 0; t < 2; t++) {
+			const size_t row = m0 + 32 * t + r < r_end ? m0 + 32 * t + r : r_end - 1;       // tail rows repeat the last row (never stored)
 			#pragma unroll
-			for (int j = 0; j < 5; j++) nxt[j] = states[row * 5 + j];
+			for (int j = 0; j < 5; j++) nxt[t][j] = states[row * 5 + j];
 		}
-		f32x16 acc0, acc1;
+	};
+	if (r_begin + (size_t)wv * 64 < r_end) request(r_begin + (size_t)wv * 64);
+	for (size_t m0 = r_begin + (size_t)wv * 64; m0 < r_end; m0 += 256) {
+		uint32_t s5[2][5];
 		#pragma unroll
-		for (int v = 0; v < 16; v++) { acc0[v] = bias0; acc1[v] = bias1; }
+		for (int t = 0; t < 2; t++)
+			#pragma unroll
+			for (int j = 0; j < 5; j++) s5[t][j] = nxt[t][j];
+		if (m0 + 256 < r_end) request(m0 + 256);
+		f32x16 acc[2][2];
+		#pragma unroll
+		for (int v = 0; v < 16; v++) { acc[0][0][v] = bias0; acc[0][1][v] = bias1; acc[1][0][v] = bias0; acc[1][1][v] = bias1; }
 		#pragma unroll
 		for (int ks = 0; ks < OHL_K / 16; ks++) {
 			// This lane's eight one-hot columns start at 16 ks + 8 h: inside cubie (16 ks + 8 h) / 24 at offset 0, 8 or 16.
@@ -187,35 +188,45 @@ void k_ohl_mfma(const uint32_t *__restrict__ states, const uint16_t *__restrict_
 			// different banks).  Built from compares on the VALU it took ~20 operations per k-step and, with the bf16
 			// rounding of the epilogue done by hand, made the kernel VALU-bound (37 % of the MFMA rate).
 			const int k_lo = 16 * ks, k_hi = 16 * ks + 8;
-			const uint32_t c_lo = (s5[(k_lo / 24) >> 2] >> (8 * ((k_lo / 24) & 3))) & 0xFFu;
-			const uint32_t c_hi = (s5[(k_hi / 24) >> 2] >> (8 * ((k_hi / 24) & 3))) & 0xFFu;
-			uint32_t rel = (h ? c_hi : c_lo) - off3[ks % 3];             // wraps to a huge value when the code is below the offset
-			rel = rel < 8u ? rel : 8u;                                   // (codes >= 24 also end up at the zero entry)
-			const u32x4 a = s_frag[rel];
-			const u32x4 b0 = *reinterpret_cast<const u32x4 *>(wrow0 + 32 * ks);
-			const u32x4 b1 = *reinterpret_cast<const u32x4 *>(wrow1 + 32 * ks);
-			const bf16x8 A = __builtin_bit_cast(bf16x8, a);
-			acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(bf16x8, b0), acc0, 0, 0, 0);
-			acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(bf16x8, b1), acc1, 0, 0, 0);
+			bf16x8 A[2];
+			#pragma unroll
+			for (int t = 0; t < 2; t++) {
+				const uint32_t c_lo = (s5[t][(k_lo / 24) >> 2] >> (8 * ((k_lo / 24) & 3))) & 0xFFu;
+				const uint32_t c_hi = (s5[t][(k_hi / 24) >> 2] >> (8 * ((k_hi / 24) & 3))) & 0xFFu;
+				uint32_t rel = (h ? c_hi : c_lo) - off3[ks % 3];         // wraps to a huge value when the code is below the offset
+				rel = rel < 8u ? rel : 8u;                               // (codes >= 24 also end up at the zero entry)
+				A[t] = __builtin_bit_cast(bf16x8, s_frag[rel]);
+			}
+			const bf16x8 B0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(wrow0 + 32 * ks));
+			const bf16x8 B1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(wrow1 + 32 * ks));
+			acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B0, acc[0][0], 0, 0, 0);
+			acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B0, acc[1][0], 0, 0, 0);
+			acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B1, acc[0][1], 0, 0, 0);
+			acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B1, acc[1][1], 0, 0, 0);
 		}
-		// epilogue: C/D element v of lane (r, h) is row (v & 3) + 8 (v >> 2) + 4 h, column r; v_cvt_pk_bf16_f32 rounds two
-		// values per instruction (nearest even), the halves go to LDS as 16-bit stores
+		// epilogue, one 32-row tile after the other through the wave's staging area: C/D element v of lane (r, h) is row
+		// (v & 3) + 8 (v >> 2) + 4 h, column r; v_cvt_pk_bf16_f32 rounds two values per instruction (nearest even), the
+		// halves go to LDS as 16-bit stores and leave as whole 128-byte rows
 		#pragma unroll
-		for (int v = 0; v < 16; v++) {
-			const int i = (v & 3) + 8 * (v >> 2) + 4 * h;
-			const f32x2 pair = {acc0[v], acc1[v]};
-			const uint32_t packed = __builtin_bit_cast(uint32_t, __builtin_convertvector(pair, bf16x2));
-			reinterpret_cast<uint16_t *>(stage + i * OHL_DROW)[r] = (uint16_t)packed;
-			reinterpret_cast<uint16_t *>(stage + i * OHL_DROW)[32 + r] = (uint16_t)(packed >> 16);
+		for (int t = 0; t < 2; t++) {
+			#pragma unroll
+			for (int v = 0; v < 16; v++) {
+				const int i = (v & 3) + 8 * (v >> 2) + 4 * h;
+				const f32x2 pair = {acc[t][0][v], acc[t][1][v]};
+				const uint32_t packed = __builtin_bit_cast(uint32_t, __builtin_convertvector(pair, bf16x2));
+				reinterpret_cast<uint16_t *>(stage + i * OHL_DROW)[r] = (uint16_t)packed;
+				reinterpret_cast<uint16_t *>(stage + i * OHL_DROW)[32 + r] = (uint16_t)(packed >> 16);
+			}
+			wave_lds_fence();
+			#pragma unroll
+			for (int it = 0; it < 4; it++) {                                     // 32 rows x 128 B, 16 B per lane
+				const int idx = it * 64 + lane, i = idx >> 3, ch = idx & 7;
+				const u32x4 val = *reinterpret_cast<const u32x4 *>(stage + i * OHL_DROW + ch * 16);
+				const size_t row = m0 + 32 * t + i;
+				if (row < r_end) *reinterpret_cast<u32x4 *>(out + row * (size_t)H + c0 + ch * 8) = val;
+			}
+			wave_lds_fence();
 		}
-		wave_lds_fence();
-		#pragma unroll
-		for (int it = 0; it < 4; it++) {                                         // 32 rows x 128 B, 16 B per lane
-			const int idx = it * 64 + lane, i = idx >> 3, ch = idx & 7;
-			const u32x4 val = *reinterpret_cast<const u32x4 *>(stage + i * OHL_DROW + ch * 16);
-			if (m0 + i < r_end) *reinterpret_cast<u32x4 *>(out + (m0 + i) * (size_t)H + c0 + ch * 8) = val;
-		}
-		wave_lds_fence();
 	}
 }
 
@@ -273,7 +284,7 @@ int rk_ohl_forward(rk_ohl_t *h, const int8_t *d_states, void *d_out, int out_dty
 	hipStream_t st = (hipStream_t)stream;
 	const unsigned col_tiles = (unsigned)(h->H / OHL_TN);
 	// about one workgroup per CU (gather: 120 KB of LDS each) or two (MFMA): the weight slice is loaded once per workgroup
-	const size_t quantum = route == RK_OHL_MFMA ? 128 : OHL_GATHER_ROWS;
+	const size_t quantum = route == RK_OHL_MFMA ? 256 : OHL_GATHER_ROWS;
 	size_t groups = (route == RK_OHL_MFMA ? 512u : 256u) / col_tiles;
 	if (groups < 1) groups = 1;
 	const size_t max_groups = (n + quantum - 1) / quantum;
