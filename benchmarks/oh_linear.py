@@ -23,6 +23,9 @@ torch.manual_seed(0)
 lin32 = torch.nn.Linear(480, H).cuda()
 lin16 = torch.nn.Linear(480, H).cuda().to(torch.bfloat16)
 f32, f16 = OhLinear(lin32), OhLinear(lin16)
+# the layer as it stands in the net (model.py:157-159): Linear, ELU, BatchNorm1d in eval mode
+elu, bn16, bn32 = torch.nn.ELU(), torch.nn.BatchNorm1d(H).cuda().to(torch.bfloat16).eval(), torch.nn.BatchNorm1d(H).cuda().eval()
+e32, e16 = OhLinear(lin32).set_epilogue(elu, bn32), OhLinear(lin16).set_epilogue(elu, bn16.float())
 g = torch.Generator(device="cuda")
 g.manual_seed(0)
 for n in (12_000, 120_000, 337_500, 2_700_000):
@@ -34,11 +37,18 @@ for n in (12_000, 120_000, 337_500, 2_700_000):
 	rows["  of which as_oh bf16"] = timed(lambda: cube.device.as_oh(states, oh16, torch.bfloat16), 20) * 1e3
 	rows["rk_ohl MFMA bf16 (one-hot in registers)"] = timed(lambda: f16(states, y16, route="mfma"), 20) * 1e3
 	rows["rk_ohl GATHER, bf16 weights, bf16 out"] = timed(lambda: f16(states, y16, route="gather"), 20) * 1e3
+	with torch.no_grad():
+		rows["as_oh bf16 + torch bf16 GEMM + ELU + BatchNorm (torch)"] = timed(lambda: bn16(elu(torch.nn.functional.linear(cube.device.as_oh(states, oh16, torch.bfloat16), lin16.weight, lin16.bias))), 20) * 1e3
+		rows["rk_ohl MFMA bf16 + torch ELU + BatchNorm"] = timed(lambda: bn16(elu(f16(states, y16, route="mfma"))), 20) * 1e3
+	rows["rk_ohl MFMA bf16 with ELU + BatchNorm epilogue"] = timed(lambda: e16(states, y16, route="mfma"), 20) * 1e3
 	if n <= 337_500:
 		oh32 = torch.empty((n, 480), dtype=torch.float32, device="cuda")
 		y32 = torch.empty((n, H), dtype=torch.float32, device="cuda")
 		rows["as_oh f32 + torch f32 GEMM"] = timed(lambda: torch.nn.functional.linear(cube.device.as_oh(states, oh32), lin32.weight, lin32.bias), 20) * 1e3
 		rows["rk_ohl GATHER f32 (exact)"] = timed(lambda: f32(states, y32, route="gather"), 20) * 1e3
+		with torch.no_grad():
+			rows["rk_ohl GATHER f32 + torch ELU + BatchNorm"] = timed(lambda: bn32(elu(f32(states, y32, route="gather"))), 20) * 1e3
+		rows["rk_ohl GATHER f32 with ELU + BatchNorm epilogue"] = timed(lambda: e32(states, y32, route="gather"), 20) * 1e3
 		del oh32, y32
 	rows["unit"] = "ms"
 	rows["output_bytes_bf16"] = n * H * 2

@@ -37,6 +37,10 @@ class TimedNet(torch.nn.Module):
 		return out
 
 
+FUSED = {0: False, 1: True, 2: "epilogue", 3: "folded"}
+FUSED_NOTE = {0: "", 1: ", first layer fused (rk_ohl)", 2: ", first layer fused with ELU + BatchNorm epilogue (rk_ohl)",
+              3: ", first layer fused with ELU + BatchNorm epilogue (rk_ohl), other BatchNorm layers folded"}
+
 def bench_astar(args):
 	net = FcSmall().cuda().eval()
 	if args.bf16:
@@ -44,7 +48,7 @@ def bench_astar(args):
 	rows = []
 	for timed in ((False,) if args.fused else (False, True)):
 		use = TimedNet(net) if timed else net
-		agent = AStar(use, args.lam, args.expansions, fused_first_layer=bool(args.fused))
+		agent = AStar(use, args.lam, args.expansions, fused_first_layer=FUSED[args.fused])
 		np.random.seed(12345)
 		agent.search(cube.scramble(args.depth, True)[0], time_limit=None, max_states=min(args.max_states, 40 * args.expansions))   # warm-up: engine, allocator, GEMM selection
 		if timed:
@@ -62,7 +66,7 @@ def bench_astar(args):
 			tot_iter += agent.iterations
 			solved += ok
 		row = {"bench": "astar", "config": f"depth-{args.depth} scrambles, lambda={args.lam}, N={args.expansions}, max_states={args.max_states}, fc_small random init"
-		       + (" bf16" if args.bf16 else " fp32") + (", first layer fused (rk_ohl)" if args.fused else ""), "games": args.games, "solved": solved, "states": tot_states, "iterations": tot_iter,
+		       + (" bf16" if args.bf16 else " fp32") + FUSED_NOTE[args.fused], "games": args.games, "solved": solved, "states": tot_states, "iterations": tot_iter,
 		       "seconds": tot_t, "states_per_s": tot_states / tot_t, "expansions_per_s": tot_iter * args.expansions / tot_t,
 		       "ms_per_iteration": tot_t / max(tot_iter, 1) * 1e3}
 		if timed:
@@ -127,7 +131,7 @@ def bench_mcts(args):
 		starts.append(s)
 	starts = np.array(starts)
 	cap = args.sims * 12 + 64
-	agent = MCTSBatch(net, args.c, T, capacity=cap, max_path=args.max_path, fused_first_layer=bool(args.fused))
+	agent = MCTSBatch(net, args.c, T, capacity=cap, max_path=args.max_path, fused_first_layer=FUSED[args.fused])
 	torch.cuda.synchronize()
 	t0 = time.perf_counter()
 	solved = agent.search(starts, max_states=cap, max_sims=args.sims, use_graph=bool(args.graph), poll=args.poll)
@@ -135,7 +139,7 @@ def bench_mcts(args):
 	dt = time.perf_counter() - t0
 	st = agent.status
 	row = {"bench": "mcts", "config": f"{T} trees x {args.sims} sims, depth-{args.depth} scrambles, c={args.c}, fc_small random init {'bf16' if args.bf16 else 'fp32'}, "
-	       f"hipGraph={'on' if args.graph else 'off'}" + (", first layer fused (rk_ohl)" if args.fused else ""), "seconds": dt, "tree_sims": int(st[:, 3].sum()), "tree_sims_per_s": float(st[:, 3].sum()) / dt,
+	       f"hipGraph={'on' if args.graph else 'off'}" + FUSED_NOTE[args.fused], "seconds": dt, "tree_sims": int(st[:, 3].sum()), "tree_sims_per_s": float(st[:, 3].sum()) / dt,
 	       "steps": agent.simulations, "ms_per_step": dt / agent.simulations * 1e3, "solved": int(solved.sum()), "states": int(st[:, 2].sum()),
 	       "states_per_s": float(st[:, 2].sum()) / dt, "max_path_len": int(st[:, 4].max())}
 	print(json.dumps(row), flush=True)
@@ -153,7 +157,8 @@ if __name__ == "__main__":
 	ap.add_argument("--max-states", type=int, default=150_000)
 	ap.add_argument("--lam", type=float, default=0.16)
 	ap.add_argument("--bf16", type=int, default=0)
-	ap.add_argument("--fused", type=int, default=0, help="first Linear reads the 20-byte states (rk_ohl_*), no one-hot batch")
+	ap.add_argument("--fused", type=int, default=0, help="1: first Linear reads the 20-byte states (rk_ohl_*), no one-hot batch; "
+	                "2: and its ELU + BatchNorm run in the kernel's epilogue; 3: and the other BatchNorm layers are folded into the next Linear")
 	ap.add_argument("--trees", type=int, default=256)
 	ap.add_argument("--sims", type=int, default=4096)
 	ap.add_argument("--c", type=float, default=0.6)

@@ -51,6 +51,10 @@ extern "C" {
 
 #define RK_OHL_GATHER 0  /* exact float32 gather-sum through an LDS-resident weight slice */
 #define RK_OHL_MFMA   1  /* bf16 MFMA with the one-hot operand synthesised in registers */
+/* epilogue activation of the fused first layer (rk_ohl_set_epilogue) */
+#define RK_OHL_ACT_NONE 0
+#define RK_OHL_ACT_ELU  1  /* x > 0 ? x : alpha (exp(x) - 1)          nn.ELU, the reference's default, model.py:30 */
+#define RK_OHL_ACT_RELU 2
 
 /* ---- library ------------------------------------------------------------------------------ */
 int         rk_version(void);
@@ -132,6 +136,11 @@ typedef struct rk_ohl rk_ohl_t;
 int rk_ohl_create(rk_ohl_t **out, const void *d_weight, int w_dtype, const void *d_bias, int H, void *stream);
 int rk_ohl_destroy(rk_ohl_t *h);
 int rk_ohl_forward(rk_ohl_t *h, const int8_t *d_states, void *d_out, int out_dtype, size_t n, int route, void *stream);
+/* Optional epilogue of every later rk_ohl_forward:  y = scale * act(x W^T + b) + shift  per output column -- the
+ * activation (model.py:157) and the eval-mode BatchNorm1d (model.py:158-159: scale = gamma / sqrt(var + eps), shift =
+ * beta - mean * scale) that follow the layer, computed in float32 on the accumulators.  d_scale / d_shift: H float32
+ * values on the device, copied; both null = no affine part.  act RK_OHL_ACT_NONE and null pointers restore the plain layer. */
+int rk_ohl_set_epilogue(rk_ohl_t *h, int act, float alpha, const float *d_scale, const float *d_shift, void *stream);
 
 /* as_correct (cube.py:371-380): 686 one-hot int8 (n,288) -> float32 (n,48) of +1/-1. */
 int rk_as_correct686(const int8_t *d_states, float *d_out, size_t n, void *stream);

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "librubiks_hip.so")
 REPR_2024, REPR_686 = 0, 1
 OH_F32, OH_F16, OH_BF16, OH_STATES = 0, 1, 2, 3
 OHL_GATHER, OHL_MFMA = 0, 1
+OHL_ACT_NONE, OHL_ACT_ELU, OHL_ACT_RELU = 0, 1, 2
 INT64_MAX = (1 << 63) - 1
 
 _vp, _sz, _i = C.c_void_p, C.c_size_t, C.c_int
@@ -47,6 +48,7 @@ SIGNATURES = {
 	"rk_ohl_create": (_i, [C.POINTER(_vp), _vp, _i, _vp, _i, _vp]),
 	"rk_ohl_destroy": (_i, [_vp]),
 	"rk_ohl_forward": (_i, [_vp, _vp, _vp, _i, _sz, _i, _vp]),
+	"rk_ohl_set_epilogue": (_i, [_vp, _i, C.c_float, _vp, _vp, _vp]),
 	"rk_as_correct686": (_i, [_vp, _vp, _sz, _vp]),
 	"rk_astar_create": (_i, [C.POINTER(_vp), _sz, _i]),
 	"rk_astar_destroy": (_i, [_vp]),

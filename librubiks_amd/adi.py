@@ -20,7 +20,7 @@ from librubiks_amd import gpu, no_grad, _ffi, cube
 
 @no_grad
 def adi_traindata(net, rollout_games: int, rollout_depth: int, alpha: float, reward_method: str = "lapanfix",
-                  ff_batches: int = 1, fused_first_layer: bool = False):
+                  ff_batches: int = 1, fused_first_layer=False):
 	assert reward_method in ("paper", "lapanfix", "schultzfix", "reward0")
 	_ffi.require_gpu()
 	net.eval()
@@ -43,8 +43,8 @@ def adi_traindata(net, rollout_games: int, rollout_depth: int, alpha: float, rew
 	step = -(-12 * n // max(1, ff_batches))
 	if fused_first_layer:
 		# the net's first Linear reads the 2.7 M children's 20-byte states directly: the (12 n, 480) one-hot never exists
-		from librubiks_amd.oh_linear import fuse_first_linear
-		from_states = fuse_first_linear(net)
+		from librubiks_amd.oh_linear import fused_net
+		from_states = fused_net(net, fused_first_layer)
 		for lo in range(0, 12 * n, step):
 			hi = min(lo + step, 12 * n)
 			values[lo:hi] = from_states(substates[lo:hi], policy=False, value=True).reshape(-1).float()

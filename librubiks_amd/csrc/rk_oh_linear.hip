@@ -73,14 +73,30 @@ __device__ __forceinline__ uint32_t code_of(const uint32_t s5[5], int cubie)
 	return c < 24u ? c : 23u;                 // states hold codes 0..23; never index past the weight slice
 }
 
+// Optional epilogue  y = scale * act(x W^T + b) + shift  per output column: the activation that follows the layer
+// (model.py:157: ELU by default) and the eval-mode BatchNorm1d behind it (model.py:158-159) as its affine map
+// scale = gamma / sqrt(var + eps), shift = beta - mean * scale -- two more passes over the (n, H) activations that never
+// happen.  ACT: 0 none, 1 ELU(alpha) = x > 0 ? x : alpha (exp(x) - 1), 2 ReLU.  FAST: v_exp_f32 (bf16 outputs keep 8 bits).
+template <int ACT, bool FAST>
+__device__ __forceinline__ float ohl_act(float v, float alpha)
+{
+	if (ACT == 1) {
+		const float neg = v < 0.0f ? v : 0.0f;
+		const float e = (FAST ? __expf(neg) : expf(neg)) - 1.0f;
+		return v > 0.0f ? v : alpha * e;
+	}
+	if (ACT == 2) return v > 0.0f ? v : 0.0f;
+	return v;
+}
+
 // ---- route GATHER ------------------------------------------------------------------------------------------------
 constexpr int OHL_GATHER_THREADS = 512;      // 8 waves (two per SIMD, so that one wave's LDS latency hides behind the other's adds)
 constexpr int OHL_GATHER_ROWS = OHL_GATHER_THREADS / 16;
 
-template <bool OUT_BF16>
+template <bool OUT_BF16, int ACT, bool AFFINE>
 __global__ __launch_bounds__(OHL_GATHER_THREADS)
 void k_ohl_gather(const uint32_t *__restrict__ states, const float *__restrict__ wt, const float *__restrict__ bias, void *__restrict__ out,
-                  size_t n, int H, size_t rows_per_group)
+                  size_t n, int H, size_t rows_per_group, float alpha, const float *__restrict__ scale, const float *__restrict__ shift)
 {
 	__shared__ __attribute__((aligned(16))) float s_w[OHL_K * OHL_TN];       // 122 880 B: this workgroup's 64 columns of W^T
 	const int tid = threadIdx.x, c0 = blockIdx.x * OHL_TN;
@@ -91,6 +107,8 @@ void k_ohl_gather(const uint32_t *__restrict__ states, const float *__restrict__
 	__syncthreads();
 	const int lane = tid & 63, wv = tid >> 6, sub = lane >> 4, q = lane & 15;
 	const f32x4 b = *reinterpret_cast<const f32x4 *>(bias + c0 + 4 * q);
+	f32x4 sc = {1.0f, 1.0f, 1.0f, 1.0f}, sh = {0.0f, 0.0f, 0.0f, 0.0f};
+	if (AFFINE) { sc = *reinterpret_cast<const f32x4 *>(scale + c0 + 4 * q); sh = *reinterpret_cast<const f32x4 *>(shift + c0 + 4 * q); }
 	const size_t r_begin = (size_t)blockIdx.y * rows_per_group;
 	const size_t r_end = r_begin + rows_per_group < n ? r_begin + rows_per_group : n;
 	uint32_t nxt[5] = {0u, 0u, 0u, 0u, 0u};
@@ -115,6 +133,13 @@ void k_ohl_gather(const uint32_t *__restrict__ states, const float *__restrict__
 			const f32x4 w = reinterpret_cast<const f32x4 *>(s_w)[(24 * i + (int)code_of(s5, i)) * 16 + q];
 			acc.x += w.x; acc.y += w.y; acc.z += w.z; acc.w += w.w;
 		}
+		if (ACT != 0) {
+			acc.x = ohl_act<ACT, false>(acc.x, alpha); acc.y = ohl_act<ACT, false>(acc.y, alpha);
+			acc.z = ohl_act<ACT, false>(acc.z, alpha); acc.w = ohl_act<ACT, false>(acc.w, alpha);
+		}
+		if (AFFINE) {                                                        // (multiply, then add: no contraction, -ffp-contract=off)
+			acc.x = acc.x * sc.x + sh.x; acc.y = acc.y * sc.y + sh.y; acc.z = acc.z * sc.z + sh.z; acc.w = acc.w * sc.w + sh.w;
+		}
 		if (OUT_BF16) {
 			u32x2 v;
 			v.x = f32_to_bf16_rne(acc.x) | (f32_to_bf16_rne(acc.y) << 16);
@@ -130,9 +155,10 @@ void k_ohl_gather(const uint32_t *__restrict__ states, const float *__restrict__
 constexpr int OHL_WROW = 976;                // bytes per LDS row of the W tile (480 bf16 + 16 B pad)
 constexpr int OHL_DROW = 144;                // bytes per LDS row of a wave's output staging (64 bf16 + 16 B pad)
 
+template <int ACT, bool AFFINE>
 __global__ __launch_bounds__(256, 2)
 void k_ohl_mfma(const uint32_t *__restrict__ states, const uint16_t *__restrict__ wb, const float *__restrict__ bias, uint16_t *__restrict__ out,
-                size_t n, int H, size_t rows_per_group)
+                size_t n, int H, size_t rows_per_group, float alpha, const float *__restrict__ scale, const float *__restrict__ shift)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t s_w[OHL_TN * OHL_WROW];      // 62 464 B
 	__shared__ __attribute__((aligned(16))) uint8_t s_d[4][32 * OHL_DROW];       // 18 432 B
@@ -152,6 +178,8 @@ void k_ohl_mfma(const uint32_t *__restrict__ states, const uint16_t *__restrict_
 	// offset of this lane's eight columns inside their cubie, by k-step mod 3: (16 ks + 8 h) % 24
 	const uint32_t off3[3] = {h ? 8u : 0u, h ? 0u : 16u, h ? 16u : 8u};
 	const float bias0 = bias[c0 + r], bias1 = bias[c0 + 32 + r];
+	float sc0 = 1.0f, sc1 = 1.0f, sh0 = 0.0f, sh1 = 0.0f;
+	if (AFFINE) { sc0 = scale[c0 + r]; sc1 = scale[c0 + 32 + r]; sh0 = shift[c0 + r]; sh1 = shift[c0 + 32 + r]; }
 	const uint8_t *wrow0 = s_w + r * OHL_WROW + 16 * h, *wrow1 = s_w + (32 + r) * OHL_WROW + 16 * h;
 	uint8_t *stage = s_d[wv];
 	const size_t r_begin = (size_t)blockIdx.y * rows_per_group;
@@ -212,7 +240,9 @@ void k_ohl_mfma(const uint32_t *__restrict__ states, const uint16_t *__restrict_
 			#pragma unroll
 			for (int v = 0; v < 16; v++) {
 				const int i = (v & 3) + 8 * (v >> 2) + 4 * h;
-				const f32x2 pair = {acc[t][0][v], acc[t][1][v]};
+				f32x2 pair = {acc[t][0][v], acc[t][1][v]};
+				if (ACT != 0) { pair.x = ohl_act<ACT, true>(pair.x, alpha); pair.y = ohl_act<ACT, true>(pair.y, alpha); }
+				if (AFFINE) { pair.x = pair.x * sc0 + sh0; pair.y = pair.y * sc1 + sh1; }
 				const uint32_t packed = __builtin_bit_cast(uint32_t, __builtin_convertvector(pair, bf16x2));
 				reinterpret_cast<uint16_t *>(stage + i * OHL_DROW)[r] = (uint16_t)packed;
 				reinterpret_cast<uint16_t *>(stage + i * OHL_DROW)[32 + r] = (uint16_t)(packed >> 16);
@@ -238,6 +268,9 @@ struct rk_ohl {
 	int H = 0;
 	float *wt_f32 = nullptr, *bias = nullptr;
 	uint16_t *w_bf16 = nullptr;
+	int act = RK_OHL_ACT_NONE;                    // epilogue (rk_ohl_set_epilogue)
+	float alpha = 1.0f;
+	float *affine = nullptr;                      // scale[H] then shift[H], or null
 };
 
 extern "C" {
@@ -266,8 +299,31 @@ int rk_ohl_create(rk_ohl_t **out, const void *d_weight, int w_dtype, const void 
 int rk_ohl_destroy(rk_ohl_t *h)
 {
 	if (!h) return RK_OK;
-	(void)hipFree(h->wt_f32); (void)hipFree(h->w_bf16); (void)hipFree(h->bias);
+	(void)hipFree(h->wt_f32); (void)hipFree(h->w_bf16); (void)hipFree(h->bias); (void)hipFree(h->affine);
 	delete h;
+	return RK_OK;
+}
+
+int rk_ohl_set_epilogue(rk_ohl_t *h, int act, float alpha, const float *d_scale, const float *d_shift, void *stream)
+{
+	if (!h) return fail(RK_EINVAL, "rk_ohl_set_epilogue: null handle");
+	if (act != RK_OHL_ACT_NONE && act != RK_OHL_ACT_ELU && act != RK_OHL_ACT_RELU) return fail(RK_EINVAL, "rk_ohl_set_epilogue: unknown activation %d", act);
+	if ((d_scale == nullptr) != (d_shift == nullptr)) return fail(RK_EINVAL, "rk_ohl_set_epilogue: scale and shift come together");
+	hipStream_t st = (hipStream_t)stream;
+	if (d_scale) {
+		if (!h->affine) {
+			hipError_t e = hipMalloc((void **)&h->affine, 2 * (size_t)h->H * sizeof(float));
+			if (e != hipSuccess) { h->affine = nullptr; return fail(RK_EHIP, "rk_ohl_set_epilogue: hipMalloc failed: %s", hipGetErrorString(e)); }
+		}
+		RK_HIP(hipMemcpyAsync(h->affine, d_scale, (size_t)h->H * sizeof(float), hipMemcpyDeviceToDevice, st));
+		RK_HIP(hipMemcpyAsync(h->affine + h->H, d_shift, (size_t)h->H * sizeof(float), hipMemcpyDeviceToDevice, st));
+		RK_HIP(hipStreamSynchronize(st));          // the caller's tensors may go away
+	} else if (h->affine) {
+		(void)hipFree(h->affine);
+		h->affine = nullptr;
+	}
+	h->act = act;
+	h->alpha = alpha;
 	return RK_OK;
 }
 
@@ -294,14 +350,25 @@ int rk_ohl_forward(rk_ohl_t *h, const int8_t *d_states, void *d_out, int out_dty
 	rows = (rows + quantum - 1) / quantum * quantum;
 	groups = (n + rows - 1) / rows;
 	const dim3 grid(col_tiles, (unsigned)groups);
+	const float *scale = h->affine, *shift = h->affine ? h->affine + h->H : nullptr;
+	const float alpha = h->alpha;
+	// the epilogue is a compile-time variant: {none, ELU, ReLU} x {no affine, affine}
+	#define RK_OHL_GATHER_GO(BF, ACT, AFF) hipLaunchKernelGGL((k_ohl_gather<BF, ACT, AFF>), grid, dim3(OHL_GATHER_THREADS), 0, st, \
+		(const uint32_t *)d_states, h->wt_f32, h->bias, d_out, n, h->H, rows, alpha, scale, shift)
+	#define RK_OHL_MFMA_GO(ACT, AFF) hipLaunchKernelGGL((k_ohl_mfma<ACT, AFF>), grid, dim3(256), 0, st, \
+		(const uint32_t *)d_states, h->w_bf16, h->bias, (uint16_t *)d_out, n, h->H, rows, alpha, scale, shift)
+	#define RK_OHL_BY_EPILOGUE(GO, ...) do { \
+		if (scale) { if (h->act == RK_OHL_ACT_ELU) GO(__VA_ARGS__ 1, true); else if (h->act == RK_OHL_ACT_RELU) GO(__VA_ARGS__ 2, true); else GO(__VA_ARGS__ 0, true); } \
+		else       { if (h->act == RK_OHL_ACT_ELU) GO(__VA_ARGS__ 1, false); else if (h->act == RK_OHL_ACT_RELU) GO(__VA_ARGS__ 2, false); else GO(__VA_ARGS__ 0, false); } } while (0)
 	if (route == RK_OHL_GATHER) {
-		if (out_dtype == RK_OH_F32)
-			hipLaunchKernelGGL(k_ohl_gather<false>, grid, dim3(OHL_GATHER_THREADS), 0, st, (const uint32_t *)d_states, h->wt_f32, h->bias, d_out, n, h->H, rows);
-		else
-			hipLaunchKernelGGL(k_ohl_gather<true>, grid, dim3(OHL_GATHER_THREADS), 0, st, (const uint32_t *)d_states, h->wt_f32, h->bias, d_out, n, h->H, rows);
+		if (out_dtype == RK_OH_F32) RK_OHL_BY_EPILOGUE(RK_OHL_GATHER_GO, false,);
+		else RK_OHL_BY_EPILOGUE(RK_OHL_GATHER_GO, true,);
 	} else {
-		hipLaunchKernelGGL(k_ohl_mfma, grid, dim3(256), 0, st, (const uint32_t *)d_states, h->w_bf16, h->bias, (uint16_t *)d_out, n, h->H, rows);
+		RK_OHL_BY_EPILOGUE(RK_OHL_MFMA_GO,);
 	}
+	#undef RK_OHL_BY_EPILOGUE
+	#undef RK_OHL_MFMA_GO
+	#undef RK_OHL_GATHER_GO
 	RK_HIP(hipGetLastError());
 	return RK_OK;
 }

@@ -9,6 +9,10 @@ first `nn.Linear(480, H)` of `Model`, librubiks/model.py:127 / :150).
 the matrix cores in bf16 with the one-hot operand synthesised in registers.  `fuse_first_linear(net)` wraps a net of the
 reference's shape (`shared_net` = Sequential starting with a Linear, `policy_net`, `value_net`) into a callable that takes
 states instead of one-hot rows: `AStar(..., fused_first_layer=True)` and `adi_traindata(..., fused_first_layer=True)` use it.
+
+`fuse_first_linear(net, epilogue=True)` also moves the activation and the eval-mode BatchNorm1d that follow the layer
+(model.py:157-159) into the kernel's epilogue, `fold_batchnorm=True` folds the remaining eval-mode BatchNorm1d layers into
+the Linear layers behind them: the same function in exact arithmetic, different float rounding (so not the default).
 """
 from __future__ import annotations
 
@@ -46,6 +50,27 @@ class OhLinear:
 		except Exception:
 			pass
 
+	def set_epilogue(self, activation: torch.nn.Module = None, batchnorm: torch.nn.BatchNorm1d = None):
+		"""
+		Later calls return  scale * act(x W^T + b) + shift: `activation` nn.ELU / nn.ReLU / None, `batchnorm` an EVAL-mode
+		BatchNorm1d (its running statistics and affine parameters are copied now, like the weights were) or None.
+		"""
+		act, alpha = _ffi.OHL_ACT_NONE, 1.0
+		if isinstance(activation, torch.nn.ELU):
+			act, alpha = _ffi.OHL_ACT_ELU, float(activation.alpha)
+		elif isinstance(activation, torch.nn.ReLU):
+			act = _ffi.OHL_ACT_RELU
+		elif activation is not None:
+			raise TypeError(f"no fused epilogue for {type(activation).__name__}: ELU and ReLU are built")
+		scale = shift = None
+		if batchnorm is not None:
+			scale, shift = batchnorm_affine(batchnorm)
+			if scale.numel() != self.out_features:
+				raise ValueError("BatchNorm1d width differs from the layer's")
+		_ffi.check(_ffi.lib().rk_ohl_set_epilogue(self._h, act, alpha, scale.data_ptr() if scale is not None else None,
+		                                          shift.data_ptr() if shift is not None else None, _ffi.stream_ptr()))
+		return self
+
 	def __call__(self, states: torch.Tensor, out: torch.Tensor = None, route: str = None) -> torch.Tensor:
 		route = route or self.route
 		if states.dtype != torch.int8 or not states.is_cuda or not states.is_contiguous() or states.shape[-1] != 20:
@@ -58,20 +83,96 @@ class OhLinear:
 		return out
 
 
-def fuse_first_linear(net, route: str = None):
+def batchnorm_affine(bn: torch.nn.BatchNorm1d):
+	"""eval-mode BatchNorm1d as y = scale * x + shift (float32, computed in float64): scale = gamma / sqrt(var + eps), shift = beta - mean * scale"""
+	if bn.training or bn.running_mean is None:
+		raise ValueError("only an eval-mode BatchNorm1d with running statistics is an affine map (call net.eval() first)")
+	var, mean = bn.running_var.detach().double(), bn.running_mean.detach().double()
+	gamma = bn.weight.detach().double() if bn.weight is not None else torch.ones_like(var)
+	beta = bn.bias.detach().double() if bn.bias is not None else torch.zeros_like(var)
+	scale = gamma / torch.sqrt(var + bn.eps)
+	return scale.float().contiguous(), (beta - mean * scale).float().contiguous()
+
+
+class _Affine(torch.nn.Module):
+	def __init__(self, scale, shift, dtype):
+		super().__init__()
+		self.scale, self.shift = scale.to(dtype), shift.to(dtype)
+
+	def forward(self, x):
+		return x * self.scale + self.shift
+
+
+def _fold(modules, pending):
+	"""
+	modules with every eval-mode BatchNorm1d folded into the Linear behind it; `pending` = (scale, shift) float64 of an
+	affine map still to be applied to the input of `modules`.  -> (list of modules, affine map left over at the end)
+	"""
+	out = []
+	for m in modules:
+		if isinstance(m, torch.nn.BatchNorm1d) and not m.training and m.running_mean is not None:
+			s, t = (x.double() for x in batchnorm_affine(m))
+			pending = (s, t) if pending is None else (pending[0] * s, pending[1] * s + t)
+			continue
+		if pending is not None:
+			if isinstance(m, torch.nn.Linear):
+				s, t = pending
+				w = m.weight.detach().double()
+				lin = torch.nn.Linear(m.in_features, m.out_features, bias=True, device=m.weight.device, dtype=m.weight.dtype)
+				with torch.no_grad():
+					lin.weight.copy_((w * s[None, :]).to(m.weight.dtype))
+					lin.bias.copy_(((m.bias.detach().double() if m.bias is not None else 0.0) + w @ t).to(m.weight.dtype))
+				m, pending = lin, None
+			else:                                  # something else wants the normalised values: apply the map as it stands
+				ref = next(iter(m.parameters()), None)
+				out.append(_Affine(pending[0], pending[1], ref.dtype if ref is not None else torch.float32))
+				pending = None
+		out.append(m)
+	return out, pending
+
+
+def fused_net(net, mode):
+	"""`fused_first_layer` option of the agents and of adi_traindata: True -> the layer alone (exact for float32 nets),
+	"epilogue" -> with its activation and BatchNorm in the kernel, "folded" -> and every other eval-mode BatchNorm folded"""
+	if mode not in (True, "epilogue", "folded"):
+		raise ValueError('fused_first_layer is False, True, "epilogue" or "folded"')
+	net.eval()
+	return fuse_first_linear(net, epilogue=mode in ("epilogue", "folded"), fold_batchnorm=mode == "folded")
+
+
+def fuse_first_linear(net, route: str = None, epilogue: bool = False, fold_batchnorm: bool = False):
 	"""
 	-> callable(states, policy=True, value=True) with the semantics of `net(as_oh(states), policy, value)` for a net of
 	the reference's structure (model.py:117-141): shared_net[0] is the Linear(480, H) that gets fused, the rest runs as is.
+	epilogue: shared_net[1] (ELU / ReLU) and, in eval mode, shared_net[2] (BatchNorm1d) run inside the layer's kernel.
+	fold_batchnorm: the other eval-mode BatchNorm1d layers are folded into the Linear layers that follow them.
+	Both snapshot the net as it is now (like the weights of the first layer) and change float rounding, not the function.
 	"""
 	shared = getattr(net, "shared_net", None)
 	if not isinstance(shared, torch.nn.Sequential) or not isinstance(shared[0], torch.nn.Linear):
 		raise TypeError("fuse_first_linear needs a net whose shared_net starts with nn.Linear(480, H) (the reference's Model)")
-	first, rest = OhLinear(shared[0], route), shared[1:]
+	first, taken = OhLinear(shared[0], route), 1
+	dtype = shared[0].weight.dtype
+	if epilogue and len(shared) > 1 and isinstance(shared[1], (torch.nn.ELU, torch.nn.ReLU)):
+		bn = shared[2] if len(shared) > 2 and isinstance(shared[2], torch.nn.BatchNorm1d) and not shared[2].training \
+		     and shared[2].running_mean is not None else None
+		first.set_epilogue(shared[1], bn)
+		taken = 3 if bn is not None else 2
+	rest, policy_net, value_net = shared[taken:], net.policy_net, net.value_net
+	if fold_batchnorm:
+		mods, pending = _fold(list(rest), None)
+		rest = torch.nn.Sequential(*mods)
+		pol, left_p = _fold(list(policy_net), pending)
+		val, left_v = _fold(list(value_net), pending)
+		if left_p is not None: pol.append(_Affine(left_p[0], left_p[1], dtype))
+		if left_v is not None: val.append(_Affine(left_v[0], left_v[1], dtype))
+		policy_net, value_net = torch.nn.Sequential(*pol), torch.nn.Sequential(*val)
 
 	def forward(states: torch.Tensor, policy: bool = True, value: bool = True):
-		x = rest(first(states).to(shared[0].weight.dtype))
-		out = ([net.policy_net(x)] if policy else []) + ([net.value_net(x)] if value else [])
+		x = rest(first(states).to(dtype))
+		out = ([policy_net(x)] if policy else []) + ([value_net(x)] if value else [])
 		return out if len(out) > 1 else out[0]
 
 	forward.first = first
+	forward.modules = (rest, policy_net, value_net)
 	return forward

@@ -284,15 +284,15 @@ class AStar(DeepAgent):
 	max_capacity = 64_000_000
 
 	def __init__(self, net, lambda_: float, expansions: int, capacity: int = None, poll: int = 4, use_hipgraph: bool = False,
-	             fused_first_layer: bool = False, exact_batch: bool = None):
+	             fused_first_layer=False, exact_batch: bool = None):
 		super().__init__(net)
 		self.exact_batch = exact_batch
 		# fused_first_layer: the engine hands the net the new nodes' 20-byte states and the net's first Linear(480, H)
 		# reads them directly (librubiks_amd.oh_linear) -- no one-hot batch exists at all
 		self._from_states = None
 		if fused_first_layer:
-			from librubiks_amd.oh_linear import fuse_first_linear
-			self._from_states = fuse_first_linear(net)
+			from librubiks_amd.oh_linear import fused_net
+			self._from_states = fused_net(net, fused_first_layer)
 		self.lambda_ = lambda_
 		self.expansions = int(expansions)
 		self.capacity = capacity
@@ -535,13 +535,13 @@ class MCTSBatch(DeepAgent):
 	"""
 
 	def __init__(self, net, c: float, n_trees: int, capacity: int = 50_000, max_path: int = None, nu: float = 100.0,
-	             fused_first_layer: bool = False):
+	             fused_first_layer=False):
 		super().__init__(net)
 		# fused_first_layer: the net's first Linear(480, H) reads the children's 20-byte states (librubiks_amd.oh_linear)
 		self._from_states = None
 		if fused_first_layer:
-			from librubiks_amd.oh_linear import fuse_first_linear
-			self._from_states = fuse_first_linear(net)
+			from librubiks_amd.oh_linear import fused_net
+			self._from_states = fused_net(net, fused_first_layer)
 		self.c, self.nu, self.n_trees = float(c), float(nu), int(n_trees)
 		self.capacity = int(capacity)
 		self.max_path = int(max_path or max(4096, 2 * self.capacity))

@@ -120,3 +120,79 @@ def test_fused_net_in_mcts():
 		i, j = np.nonzero(a["neighbors"][1:n + 1])
 		moved = orc.multi_rotate(a["states"][i + 1], j // 2, 1 - j % 2)
 		assert (moved == a["states"][a["neighbors"][i + 1, j]]).all()
+
+
+def _randomise_batchnorm(net, seed=0):
+	"""fresh BatchNorm layers are (almost) the identity in eval mode: give them statistics and affine parameters worth folding"""
+	g = torch.Generator().manual_seed(seed)
+	for m in net.modules():
+		if isinstance(m, torch.nn.BatchNorm1d):
+			with torch.no_grad():
+				m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.3)
+				m.running_var.copy_(torch.rand(m.num_features, generator=g) * 1.5 + 0.25)
+				m.weight.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+				m.bias.copy_(torch.randn(m.num_features, generator=g) * 0.2)
+	return net
+
+
+@pytest.mark.parametrize("route", ["gather", "mfma"])
+@pytest.mark.parametrize("act", ["elu", "elu0.7", "relu", None])
+@pytest.mark.parametrize("affine", [False, True])
+def test_epilogue_activation_and_batchnorm(route, act, affine):
+	"""y = BatchNorm_eval(act(x W^T + b)) out of the layer's kernel (model.py:157-159) against the torch modules in float32.
+	Tolerances: float32 route 1e-5 relative (exp and the affine map round differently from torch's kernels), bf16 route 2^-7."""
+	H, n = 512, 777
+	dtype = torch.float32 if route == "gather" else torch.bfloat16
+	lin = _layer(H, dtype, seed=5)
+	states = torch.from_numpy(random_walk(n, 15, seed=77)).cuda()
+	module = {"elu": torch.nn.ELU(), "elu0.7": torch.nn.ELU(alpha=0.7), "relu": torch.nn.ReLU(), None: None}[act]
+	bn = None
+	if affine:
+		bn = _randomise_batchnorm(torch.nn.Sequential(torch.nn.BatchNorm1d(H)), seed=3)[0].cuda().eval()
+	layer = OhLinear(lin, route=route).set_epilogue(module, bn)
+	y = layer(states)
+	with torch.no_grad():
+		ref = torch.nn.functional.linear(cube.device.as_oh(states), lin.weight.float(), lin.bias.float())
+		if module is not None:
+			ref = module(ref)
+		if bn is not None:
+			ref = bn(ref)
+	if route == "gather":
+		assert y.dtype == torch.float32 and torch.allclose(y, ref, rtol=1e-5, atol=2e-6)
+	else:
+		assert y.dtype == torch.bfloat16 and torch.allclose(y.float(), ref, rtol=2.0 ** -7, atol=2e-3)
+	# and the epilogue can be taken off again
+	plain = layer.set_epilogue(None, None)(states)
+	assert torch.equal(plain, OhLinear(lin, route=route)(states))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("mode", ["epilogue", "folded"])
+def test_fused_net_with_epilogue_and_folded_batchnorm(dtype, mode):
+	"""fc_small with the first layer's ELU + BatchNorm in the kernel ("epilogue") and the other BatchNorm layers folded into
+	the following Linear layers ("folded"): the same function as the net on one-hot rows up to float rounding."""
+	from benchmarks.nets import FcSmall
+	from librubiks_amd.oh_linear import fused_net
+	from librubiks_amd.solving.agents import AStar
+	net = _randomise_batchnorm(FcSmall(seed=1), seed=8).cuda().eval()
+	states = torch.from_numpy(random_walk(500, 14, seed=19)).cuda()
+	with torch.no_grad():
+		want_p, want_v = net(cube.device.as_oh(states))                 # float32 truth
+		use = net if dtype == torch.float32 else _randomise_batchnorm(FcSmall(seed=1), seed=8).cuda().eval().to(dtype)
+		f = fused_net(use, mode)
+		got_p, got_v = f(states)
+	if mode == "folded":
+		assert not any(isinstance(m, torch.nn.BatchNorm1d) for seq in f.modules for m in seq)
+	tol = dict(rtol=2e-4, atol=2e-4) if dtype == torch.float32 else dict(rtol=0.06, atol=0.06 * float(want_v.abs().max()))
+	assert torch.allclose(got_v.float(), want_v, **tol) and torch.allclose(got_p.float(), want_p, **tol)
+	if dtype == torch.float32:
+		np.random.seed(33)
+		start, _, _ = orc.scramble(8, True)
+		agent = AStar(net, 0.2, 40, fused_first_layer=mode)
+		ok = agent.search(start, None, 15_000)
+		assert len(agent) <= 15_000 and (agent.states[1] == start).all()
+		if ok:
+			s = start
+			for a in agent.action_queue:
+				s = orc.rotate(s, a // 2, 1 - a % 2)
+			assert orc.is_solved(s)
