@@ -109,6 +109,14 @@ struct MergePlan {
 	Rec *dst;
 };
 
+// How the sorted new records reach the queue insert: runs of 256 (K <= 2048), the 2048-record chunks as they are
+// (K <= 16 384: the insert's merge is multi-way, no merge pass needed), or one run (larger K: k_merge_pass merges the
+// chunks first).  0 = one run.
+__device__ __host__ __forceinline__ int new_chunk_of(int chunk, int Kpad)
+{
+	return chunk == SMALL_CHUNK ? SMALL_CHUNK : (Kpad <= MAX_NEW_RUNS * SORT_CHUNK ? SORT_CHUNK : 0);
+}
+
 // meta = pointer to [4][QL] ints (global or LDS copy).  live range of level j after the pending pop: [head+take, len)
 // new_chunk: the new records are sorted runs of this length (SMALL_CHUNK), or one run (0)
 __device__ __forceinline__ void make_plan(const QueueDev &q, const int32_t *meta, const Rec *newrun, int n_new, int new_chunk, MergePlan &p)
@@ -520,21 +528,28 @@ __global__ void k_merge_pass(AstarDev d, int L, int from)
 // other buffer; read half of relaxation case 2 (agents.py:362), which also clears the marks this batch set.
 // Every record finds its output slot as its own offset plus one binary search per other run.  With K <= 2048 the new
 // records are up to eight 256-record runs: each workgroup stages them in LDS first (32 KB), so those searches -- most of
-// them -- never leave the CU.
+// them -- never leave the CU.  Runs that stay in global memory -- the queue levels, and with 2048 < K <= 16 384 the
+// new records' 2048-record chunks -- get a coarse index in LDS (below).
+constexpr int SAMPLES = 256;
+constexpr int POOL_RECS = SORT_CHUNK + 3 * SAMPLES;                     // 45 056 B: staged new records + 3 indexed runs, or 11 indexed runs
+constexpr int MAX_SAMPLED = POOL_RECS / SAMPLES;
+
 template <bool SHARDED>
 __global__ __launch_bounds__(256)
 void k_queue_insert(AstarDev d, int new_in_rec1)
 {
 	__shared__ MergePlan s_plan;
-	__shared__ Rec s_newrecs[SORT_CHUNK];
+	__shared__ Rec s_pool[POOL_RECS];
 	__shared__ int32_t s_qmeta[4 * QL];
-	const bool small = d.chunk == SMALL_CHUNK;
+	const int nc = new_chunk_of(d.chunk, d.Kpad);
+	const bool small = nc == SMALL_CHUNK;
+	Rec *const s_newrecs = s_pool;
 	if (threadIdx.x < 4 * QL) s_qmeta[threadIdx.x] = d.q.meta[threadIdx.x];     // one parallel load instead of a dependent chain
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		const int n_new = d.ctr[C_NNEW];
-		// with more than one 2048-chunk the merge passes ping-pong; otherwise the sorted run(s) are in rec0
-		make_plan(d.q, s_qmeta, (!small && n_new > SORT_CHUNK && new_in_rec1) ? d.rec1 : d.rec0, n_new, small ? SMALL_CHUNK : 0, s_plan);
+		// after merge passes (one run out of more than eight chunks) the result ping-pongs; otherwise the sorted run(s) are in rec0
+		make_plan(d.q, s_qmeta, (nc == 0 && n_new > SORT_CHUNK && new_in_rec1) ? d.rec1 : d.rec0, n_new, nc, s_plan);
 	}
 	__syncthreads();
 	if (small && s_plan.total > 0) {
@@ -548,17 +563,17 @@ void k_queue_insert(AstarDev d, int new_in_rec1)
 	const MergePlan &p = s_plan;
 	// Long runs that stay in global memory (the queue levels) get a coarse index in LDS: every `step`-th record, at most
 	// SAMPLES per run, so that a binary search spends its first steps on the CU and only log2(step) of them in memory.
-	constexpr int SAMPLES = 256, SAMPLED_RUNS = 3;
-	__shared__ Rec s_samples[SAMPLED_RUNS][SAMPLES];
-	__shared__ int s_step[SAMPLED_RUNS], s_nsamp[SAMPLED_RUNS];
+	__shared__ int s_step[MAX_SAMPLED], s_nsamp[MAX_SAMPLED];
+	Rec *const s_samples = small ? s_pool + SORT_CHUNK : s_pool;          // [sampled runs][SAMPLES]
+	const int sampled_runs = small ? 3 : MAX_SAMPLED;
 	const int first_global = small ? p.n_new_runs : 0;
 	if (p.total > 0) {
-		for (int k = 0; k < SAMPLED_RUNS; k++) {
+		for (int k = 0; k < sampled_runs; k++) {
 			const int r = first_global + k;
 			if (r >= p.n_runs) break;
 			const int len = p.len[r], step = (len + SAMPLES - 1) / SAMPLES;
 			const int ns = step > 1 ? (len + step - 1) / step : 0;             // short runs are searched directly
-			if ((int)threadIdx.x < ns) s_samples[k][threadIdx.x] = p.run[r][(size_t)threadIdx.x * step];
+			if ((int)threadIdx.x < ns) s_samples[k * SAMPLES + threadIdx.x] = p.run[r][(size_t)threadIdx.x * step];
 			if (threadIdx.x == 0) { s_step[k] = step; s_nsamp[k] = ns; }
 		}
 		__syncthreads();
@@ -572,8 +587,8 @@ void k_queue_insert(AstarDev d, int new_in_rec1)
 		for (int r2 = 0; r2 < p.n_runs; r2++) {
 			if (r2 == r) continue;
 			const int k = r2 - first_global;
-			if (k >= 0 && k < SAMPLED_RUNS && s_nsamp[k] > 0) {
-				const int sp = lower_bound_rec(s_samples[k], s_nsamp[k], x);   // first sample >= x
+			if (k >= 0 && k < sampled_runs && s_nsamp[k] > 0) {
+				const int sp = lower_bound_rec(s_samples + k * SAMPLES, s_nsamp[k], x);   // first sample >= x
 				const int lo = sp > 0 ? (sp - 1) * s_step[k] : 0;
 				const int hi = sp < s_nsamp[k] ? sp * s_step[k] : p.len[r2];
 				pos += lo + lower_bound_rec(p.run[r2] + lo, hi - lo, x);
@@ -634,8 +649,8 @@ void k_end(AstarDev d, int new_in_rec1, int count_iteration)
 	if (tid == 0) {
 		const int n_new = s_ctr[C_NNEW];
 		MergePlan p;
-		const bool small = d.chunk == SMALL_CHUNK;
-		make_plan(d.q, s_old, (!small && n_new > SORT_CHUNK && new_in_rec1) ? d.rec1 : d.rec0, n_new, small ? SMALL_CHUNK : 0, p);
+		const int nc = new_chunk_of(d.chunk, d.Kpad);
+		make_plan(d.q, s_old, (nc == 0 && n_new > SORT_CHUNK && new_in_rec1) ? d.rec1 : d.rec0, n_new, nc, p);
 		int open = 0;
 		for (int j = 0; j < d.q.levels; j++) {
 			int head = s_old[Q_HEAD * QL + j] + s_old[Q_TAKE * QL + j], len = s_old[Q_LEN * QL + j], cur = s_old[Q_CUR * QL + j];
@@ -1017,7 +1032,8 @@ int launch_commit(rk_astar *h, const float *d_values, const uint8_t *recv, hipSt
 		hipLaunchKernelGGL((k_records_sort<SMALL_CHUNK>), dim3(d.Kpad / SMALL_CHUNK), dim3(SMALL_CHUNK / 2), 0, st, d, d_values);
 	} else {
 		hipLaunchKernelGGL((k_records_sort<SORT_CHUNK>), dim3(d.Kpad / SORT_CHUNK), dim3(SORT_CHUNK / 2), 0, st, d, d_values);
-		for (int L = SORT_CHUNK; L < d.Kpad; L <<= 1) {
+		// up to eight chunks go to the queue insert as they are (its merge is multi-way); more are merged into one run first
+		for (int L = SORT_CHUNK; L < d.Kpad && new_chunk_of(d.chunk, d.Kpad) == 0; L <<= 1) {
 			hipLaunchKernelGGL(k_merge_pass, dim3(blocks(d.Kpad)), dim3(256), 0, st, d, L, from);
 			from ^= 1;
 		}
