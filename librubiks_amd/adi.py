@@ -49,10 +49,12 @@ def adi_traindata(net, rollout_games: int, rollout_depth: int, alpha: float, rew
 			hi = min(lo + step, 12 * n)
 			values[lo:hi] = from_states(substates[lo:hi], policy=False, value=True).reshape(-1).float()
 	else:
-		buf = torch.empty((min(step, 12 * n), 480), dtype=torch.float32, device=gpu)
+		from librubiks_amd.solving.agents import _oh_dtype
+		oh_dtype = _oh_dtype(net)                  # a bf16 net gets bf16 rows straight from the kernel (0 / 1 are exact)
+		buf = torch.empty((min(step, 12 * n), 480), dtype=oh_dtype, device=gpu)
 		for lo in range(0, 12 * n, step):
 			hi = min(lo + step, 12 * n)
-			cube.device.as_oh(substates[lo:hi], out=buf[:hi - lo])
+			cube.device.as_oh(substates[lo:hi], buf[:hi - lo], oh_dtype)
 			values[lo:hi] = net(buf[:hi - lo], policy=False, value=True).reshape(-1).float()
 	values = (values + rewards).reshape(-1, 12)                                                   # train.py:313-314
 	policy_targets = torch.argmax(values, dim=1)

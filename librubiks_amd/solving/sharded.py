@@ -259,3 +259,58 @@ class ShardedAStar(DeepAgent):
 
 	def __str__(self):
 		return f"Sharded AStar x{self.tp.world} (lambda={self.lambda_}, N={self.expansions})"
+
+
+class PartitionedMCTS:
+	"""
+	`MCTSBatch` across the GPUs of one node (BASELINE config 4 at N > 1): the trees are independent searches, so they are
+	PARTITIONED, not sharded -- rank r owns the trees r, r + world, r + 2 world, ... of the batch and runs them with its
+	own `MCTSBatch` engine; no collective in the search loop.  One all-gather of fixed size at the end hands every rank
+	the whole batch's results (solved flag, explored states, simulations and the action queue of every tree), so the
+	caller sees what one `MCTSBatch` over all trees would have returned; every tree is the reference's MCTS run on that
+	start state alone (agents.py:415-645), whichever rank ran it.
+	"""
+
+	def __init__(self, net, c: float, n_trees: int, capacity: int = 50_000, max_path: int = None, group=None, **kw):
+		from librubiks_amd.solving.agents import MCTSBatch
+		self.tr = Transport(group)
+		self.n_trees = int(n_trees)
+		self.mine = np.arange(self.tr.rank, self.n_trees, self.tr.world)
+		self.max_path = int(max_path or 4096)
+		self.local = MCTSBatch(net, c, max(len(self.mine), 1), capacity=capacity, max_path=max_path, **kw)
+		self.solved = self.states = self.sims = None
+		self._queues = None
+
+	def search(self, states: np.ndarray, time_limit: float = None, max_states=None, max_sims: int = None, **kw) -> np.ndarray:
+		states = np.ascontiguousarray(states, np.int8).reshape(self.n_trees, 20)
+		per = -(-self.n_trees // self.tr.world)                              # trees per rank, rounded up: fixed-size rows
+		row = 4 + self.max_path                                             # solved, states, sims, path length, actions
+		out = np.full((per, row), -1, np.int32)
+		if len(self.mine):
+			solved = self.local.search(states[self.mine], time_limit, max_states, max_sims, **kw)
+			st = self.local.status
+			for k in range(len(self.mine)):
+				q = list(self.local.action_queue_of(k)) if solved[k] else []
+				if len(q) > self.max_path:
+					raise RuntimeError(f"a solution of {len(q)} moves exceeds max_path = {self.max_path}")
+				out[k, :4] = (int(solved[k]), int(st[k, 2]), int(st[k, 3]), len(q))
+				out[k, 4:4 + len(q)] = q
+		every = self.tr.all_gather(torch.from_numpy(out).reshape(-1).to(gpu if self.tr.on_device else "cpu"))
+		every = every.cpu().numpy().reshape(self.tr.world, per, row)
+		self.solved, self.states, self.sims = (np.zeros(self.n_trees, t) for t in (bool, np.int64, np.int64))
+		self._queues = [deque() for _ in range(self.n_trees)]
+		for r in range(self.tr.world):
+			for k, tree in enumerate(range(r, self.n_trees, self.tr.world)):
+				rec = every[r, k]
+				self.solved[tree], self.states[tree], self.sims[tree] = bool(rec[0]), rec[1], rec[2]
+				self._queues[tree] = deque(int(a) for a in rec[4:4 + rec[3]])
+		return self.solved
+
+	def action_queue_of(self, tree: int) -> deque:
+		return self._queues[tree]
+
+	def __len__(self):
+		return int(self.states.sum()) if self.states is not None else 0
+
+	def __str__(self):
+		return f"MCTS x{self.n_trees} partitioned over {self.tr.world} ranks"

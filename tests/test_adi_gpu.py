@@ -47,3 +47,18 @@ def test_adi_at_training_scale():
 	assert (oh.sum(dim=1) == 20).all()
 	# the first state of every game is solved under lapanfix -> target 0; one move away -> reward +1 dominates
 	assert (value.view(7500, 30)[:, 0] == 0).all() and (value.view(7500, 30)[:, 1] == 1).all()
+
+
+@pytest.mark.parametrize("mode", [False, True, "folded"])
+def test_adi_with_a_bf16_net(mode):
+	"""A bfloat16 net gets bfloat16 one-hot rows (or the states, with the fused first layer): same one-hot targets as the
+	float32 net, values within bf16 rounding of it (tolerance 0.05 on values of order 1)."""
+	from benchmarks.nets import FcSmall
+	net32 = FcSmall(seed=2).cuda().eval()
+	net16 = FcSmall(seed=2).cuda().eval().to(torch.bfloat16)
+	np.random.seed(9)
+	oh32, p32, v32, _ = adi_traindata(net32, 40, 10, 0.5, "lapanfix", ff_batches=2)
+	np.random.seed(9)
+	oh16, p16, v16, _ = adi_traindata(net16, 40, 10, 0.5, "lapanfix", ff_batches=3, fused_first_layer=mode)
+	assert oh16.dtype == torch.float32 and torch.equal(oh32, oh16)
+	assert torch.allclose(v16, v32, atol=0.05) and (p16 == p32).float().mean() > 0.8

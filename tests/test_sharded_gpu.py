@@ -288,3 +288,52 @@ def test_rccl_transport_world1(tmp_path):
 	rs, rG, rp, ra = ref.arrays()
 	assert (z["states"] == rs).all() and (z["G"] == rG).all() and (z["parents"] == rp).all() and (z["pact"] == ra).all()
 	assert z["queue"].tolist() == list(ref.action_queue)
+
+
+def _rank_partitioned_mcts(rank, world, port, out_dir):
+	import torch.distributed as dist
+	from librubiks_amd.solving.sharded import PartitionedMCTS
+	from oracle.search_oracle import PolicyStubNet
+	os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+	dist.init_process_group("gloo", rank=rank, world_size=world)
+	try:
+		torch.cuda.set_device(0)
+		agent = PartitionedMCTS(PolicyStubNet(), 1.5, len(_MCTS_STARTS()), capacity=2500)
+		solved = agent.search(_MCTS_STARTS(), max_states=2500, max_sims=400)
+		np.savez(os.path.join(out_dir, f"pm_r{rank}.npz"), solved=solved, states=agent.states, sims=agent.sims, mine=agent.mine,
+		         queues=np.array([list(agent.action_queue_of(t)) + [-1] * (64 - len(agent.action_queue_of(t))) for t in range(agent.n_trees)]))
+	finally:
+		dist.destroy_process_group()
+
+
+def _MCTS_STARTS():
+	out = []
+	for i in range(7):                                                       # an odd number: the ranks get 4 and 3 trees
+		np.random.seed(300 + i)
+		out.append(orc.scramble(4 + i % 3, True)[0])
+	return np.array(out)
+
+
+def test_partitioned_mcts_gloo(tmp_path):
+	"""configs[3] at N > 1: trees partitioned over ranks, no collective in the loop; every rank ends with the whole batch's
+	results, and they equal one MCTSBatch over all trees (each tree is the reference's search of its start state alone)."""
+	from librubiks_amd.solving.agents import MCTSBatch
+	from oracle.search_oracle import PolicyStubNet
+	mp.spawn(_rank_partitioned_mcts, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+	z = [np.load(tmp_path / f"pm_r{r}.npz") for r in range(2)]
+	assert z[0]["mine"].tolist() == [0, 2, 4, 6] and z[1]["mine"].tolist() == [1, 3, 5]
+	for k in ("solved", "states", "sims", "queues"):
+		assert (z[0][k] == z[1][k]).all()
+	starts = _MCTS_STARTS()
+	one = MCTSBatch(PolicyStubNet(), 1.5, len(starts), capacity=2500)
+	solved = one.search(starts, max_states=2500, max_sims=400)
+	assert (solved == z[0]["solved"]).all() and 2 <= solved.sum() < len(starts)      # solved and unsolved trees both covered
+	assert (one.status[:, 2] == z[0]["states"]).all()
+	for t in range(len(starts)):
+		q = [a for a in z[0]["queues"][t] if a >= 0]
+		assert q == list(one.action_queue_of(t) if solved[t] else [])
+		if solved[t]:
+			s = starts[t]
+			for a in q:
+				s = orc.rotate(s, a // 2, 1 - a % 2)
+			assert orc.is_solved(s)
