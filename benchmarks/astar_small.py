@@ -19,10 +19,12 @@ from librubiks_amd import cube  # noqa: E402
 from librubiks_amd.solving.agents import AStar  # noqa: E402
 
 net = FcSmall().cuda().eval()
-for name, nn in (("stub", FastStub()), ("fc_small fp32", net), ("fc_small bf16", FcSmall().cuda().eval().to(torch.bfloat16))):
+bf16 = FcSmall().cuda().eval().to(torch.bfloat16)
+for name, nn, fused in (("stub", FastStub(), False), ("fc_small fp32", net, False), ("fc_small bf16", bf16, False),
+                        ("fc_small bf16, first layer fused with epilogue, BatchNorm folded", bf16, "folded")):
 	for N in (10, 27, 100, 700):
 		for graph in (False, True):
-			agent = AStar(nn, 0.2, N, poll=16, use_hipgraph=graph)
+			agent = AStar(nn, 0.2, N, poll=16, use_hipgraph=graph, fused_first_layer=fused)
 			np.random.seed(3)
 			state, _, _ = cube.scramble(16, True)
 			agent.search(state, None, 3000 + 12 * N)   # warm

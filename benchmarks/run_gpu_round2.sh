@@ -27,12 +27,16 @@ timeout -k 10 300 python benchmarks/astar_small.py 2>/dev/null | grep '^{' > $O/
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_astar100 -- python3 benchmarks/astar_profile.py --expansions 100 --net stub > $O/prof_astar100.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_astar1000 -- python3 benchmarks/astar_profile.py --expansions 1000 --net bf16 --max-states 400000 > $O/prof_astar1000.log 2>&1
 rm -f $O/search.json
-for a in "" "--bf16 1" "--fused 1" "--bf16 1 --fused 1"; do python benchmarks/search.py astar $a 2>/dev/null | grep '^{' >> $O/search.json; done
-for a in "" "--bf16 1" "--fused 1" "--bf16 1 --fused 1"; do python benchmarks/search.py mcts $a 2>/dev/null | tail -1 >> $O/search.json; done
+for a in "" "--bf16 1" "--fused 1" "--bf16 1 --fused 1" "--bf16 1 --fused 2" "--bf16 1 --fused 3" "--fused 3"; do python benchmarks/search.py astar $a 2>/dev/null | grep '^{' >> $O/search.json; done
+for a in "" "--bf16 1" "--fused 1" "--bf16 1 --fused 1" "--bf16 1 --fused 3" "--fused 3"; do python benchmarks/search.py mcts $a 2>/dev/null | tail -1 >> $O/search.json; done
+timeout -k 10 600 python benchmarks/adi.py 2>/dev/null | grep '^{' > $O/adi.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_mcts256 -- python3 benchmarks/search.py mcts --sims 256 > $O/prof_mcts256.log 2>&1
 # sharded search rehearsals (no multi-GPU node: world 1, and two ranks over gloo on the one GPU)
 rm -f $O/sharded.json
 timeout -k 10 200 python benchmarks/sharded.py --depth 14 --expansions 100 --max-states 300000 --games 2 --net stub 2>/dev/null | grep '^{' >> $O/sharded.json
 RK_BENCH_BACKEND=gloo timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 benchmarks/sharded.py --depth 14 --expansions 100 --max-states 300000 --games 2 --net stub 2>/dev/null | grep '^{' >> $O/sharded.json
 timeout -k 10 200 python benchmarks/sharded.py --depth 20 --expansions 700 --max-states 2000000 --games 1 --net fc_small_bf16 --time-limit 30 2>/dev/null | grep '^{' >> $O/sharded.json
+# configs[3] across ranks: trees partitioned (world 1, and two ranks over gloo sharing the GPU)
+timeout -k 10 300 python benchmarks/sharded.py --mcts 256 --net fc_small_bf16 --fused folded 2>/dev/null | grep '^{' >> $O/sharded.json
+RK_BENCH_BACKEND=gloo timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29535 benchmarks/sharded.py --mcts 128 --net fc_small_bf16 --fused folded 2>/dev/null | grep '^{' >> $O/sharded.json
 cat $O/search.json | cut -c1-300

@@ -34,6 +34,10 @@ def main():
 	ap.add_argument("--time-limit", type=float, default=60.0)
 	ap.add_argument("--poll", type=int, default=4)
 	ap.add_argument("--net", default="fc_small", choices=["fc_small", "fc_small_bf16", "stub"])
+	ap.add_argument("--mcts", type=int, default=0, help="instead of A*: configs[3] with this many trees PER RANK (weak scaling), partitioned "
+	                "over the ranks (PartitionedMCTS: no collective in the loop, one all-gather of results at the end)")
+	ap.add_argument("--sims", type=int, default=4096)
+	ap.add_argument("--fused", default="", choices=["", "epilogue", "folded"], help="--mcts: fused first layer mode")
 	args = ap.parse_args()
 
 	rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -59,6 +63,34 @@ def main():
 		net = FcSmall(seed=0).cuda().eval()               # same seed on every rank: identical weights
 		if args.net.endswith("bf16"):
 			net = net.to(torch.bfloat16)
+	if args.mcts:
+		from librubiks_amd.solving.sharded import PartitionedMCTS
+		trees = args.mcts * world
+		starts = []
+		for i in range(trees):
+			np.random.seed(1000 + i)
+			starts.append(cube.scramble(14, True)[0])
+		agent = PartitionedMCTS(net, 0.6, trees, capacity=12 * args.sims + 16, max_path=4096, **({"fused_first_layer": args.fused} if args.fused else {}))
+		agent.search(np.array(starts), max_sims=8, use_graph=False)                    # warm-up
+		torch.cuda.synchronize()
+		if world > 1:
+			dist.barrier()
+		t0 = time.perf_counter()
+		solved = agent.search(np.array(starts), max_sims=args.sims, use_graph=True, poll=64)
+		torch.cuda.synchronize()
+		dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+		if world > 1:
+			dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+		if rank == 0:
+			print(json.dumps({"bench": "partitioned_mcts", "config": f"configs[3] per rank: {args.mcts} trees x {args.sims} sims, depth-14 scrambles, c=0.6, "
+			                  f"net={args.net}{', fused ' + args.fused if args.fused else ''}, hipGraph=on, world={world}", "world": world,
+			                  "backend": backend if world > 1 else "local", "trees": trees, "seconds_max_over_ranks": float(dt[0]),
+			                  "tree_sims": int(agent.sims.sum()), "tree_sims_per_s": float(agent.sims.sum()) / float(dt[0]),
+			                  "solved": int(solved.sum()), "states": int(agent.states.sum()), "scaling": "weak"}), flush=True)
+		if world > 1:
+			dist.barrier()
+			dist.destroy_process_group()
+		return
 	cap = args.capacity or int(args.max_states / world * 1.5) + 12 * args.expansions * world + 1024
 	agent = ShardedAStar(net, args.lam, args.expansions, capacity=cap, poll=args.poll, profile=True)
 	rows = []
