@@ -178,6 +178,10 @@ int rk_astar_reset(rk_astar_t *h, const int8_t *h_start_state, double lambda, vo
 int rk_astar_set_budget(rk_astar_t *h, long long max_states, void *stream);
 int rk_astar_step_expand(rk_astar_t *h, void *d_onehot, int out_dtype, void *stream);
 int rk_astar_step_commit(rk_astar_t *h, const float *d_values, void *stream);
+/* The value vectors handed to rk_astar_step_commit / rk_astar_commit / rk_astar_shard_push are float32 (default) or, after
+ * rk_astar_set_values_dtype(h, RK_OH_BF16), bfloat16 as a bf16 net emits them (same pointer arguments; bf16 -> float32 is
+ * exact, so the cost lambda * G - value is the same number; saves one conversion kernel per iteration).  Sticky until changed. */
+int rk_astar_set_values_dtype(rk_astar_t *h, int dtype);
 int rk_astar_status(rk_astar_t *h, long long *h_status /* [8] */, void *stream);
 /* The same iteration as three calls for hosts that want to feed the net exactly the new states: rk_astar_expand
  * synchronises, h_info = {popped, new, won, solved_index, n_states}; rk_astar_new_states_oh writes the one-hot of the
@@ -296,6 +300,13 @@ int rk_mcts_set_root_pv(rk_mcts_t *h, const float *d_probs, const float *d_value
 int rk_mcts_expand(rk_mcts_t *h, void *stream);
 int rk_mcts_children_oh(rk_mcts_t *h, void *d_out, int out_dtype, void *stream);
 int rk_mcts_backup_select(rk_mcts_t *h, const float *d_probs, const float *d_values, void *stream);
+/* The same step from the net's RAW outputs: d_logits (T*12, 12) and d_values (T*12), both float32 (dtype RK_OH_F32) or
+ * both bfloat16 (RK_OH_BF16); the softmax of agents.py:551 (exp(x - max) / sum in float32) runs inside the kernel, which
+ * saves the conversion, softmax and copy kernels of every simulation. */
+int rk_mcts_backup_select_logits(rk_mcts_t *h, const void *d_logits, const void *d_values, int dtype, void *stream);
+/* Device pointer to the (T*12, 20) int8 child states of the pending simulation (what rk_mcts_children_oh encodes): a net
+ * whose first layer reads states (rk_ohl_forward) can take them where they lie. */
+const int8_t *rk_mcts_children(rk_mcts_t *h);
 /* Synchronises.  h_status is (T, 6) int64: done, solved, n_states, simulations, path_len, error. */
 int rk_mcts_status(rk_mcts_t *h, long long *h_status, void *stream);
 /* Rows [first, first+count) of one tree's arrays to HOST buffers in the reference's dtypes (any may be NULL):

@@ -56,6 +56,7 @@ SIGNATURES = {
 	"rk_astar_set_budget": (_i, [_vp, C.c_longlong, _vp]),
 	"rk_astar_step_expand": (_i, [_vp, _vp, _i, _vp]),
 	"rk_astar_step_commit": (_i, [_vp, _vp, _vp]),
+	"rk_astar_set_values_dtype": (_i, [_vp, _i]),
 	"rk_astar_status": (_i, [_vp, _vp, _vp]),
 	"rk_astar_expand": (_i, [_vp, _i, _vp, _vp]),
 	"rk_astar_new_states_oh": (_i, [_vp, _vp, _i, _vp]),
@@ -98,6 +99,8 @@ SIGNATURES = {
 	"rk_mcts_expand": (_i, [_vp, _vp]),
 	"rk_mcts_children_oh": (_i, [_vp, _vp, _i, _vp]),
 	"rk_mcts_backup_select": (_i, [_vp, _vp, _vp, _vp]),
+	"rk_mcts_backup_select_logits": (_i, [_vp, _vp, _vp, _i, _vp]),
+	"rk_mcts_children": (_vp, [_vp]),
 	"rk_mcts_status": (_i, [_vp, _vp, _vp]),
 	"rk_mcts_export": (_i, [_vp, _i, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 	"rk_mcts_path": (C.c_longlong, [_vp, _i, _vp, _vp, _sz, _vp]),

@@ -83,6 +83,7 @@ struct AstarDev {
 	int N, K, Kpad, chunk;                      // expansions, 12 N, K rounded up to the sort chunk, sort chunk (256 or 2048)
 	int world, rank, KI;                        // sharded: ranks, this rank, incoming child slots = world * K
 	double lambda;
+	int values_bf16;                            // the net's values arrive as bfloat16 instead of float32 (rk_astar_set_values_dtype)
 	uint32_t *states; int32_t *G, *parents; uint8_t *pact, *prank; uint32_t *table, *mark;
 	int32_t *ctr;
 	QueueDev q;
@@ -436,7 +437,8 @@ __device__ __forceinline__ Rec cost_record(const AstarDev &d, const float *value
 {
 	if (j >= n_new) return Rec{~0ull, 0xFFFFFFFF00000000ull + (uint64_t)j};
 	const uint32_t idx = n_before + 1u + (uint32_t)j;
-	const double hv = (double)(-values[j]);
+	const float val = d.values_bf16 ? __builtin_bit_cast(float, (uint32_t)reinterpret_cast<const uint16_t *>(values)[j] << 16) : values[j];
+	const double hv = (double)(-val);
 	const double lg = d.lambda * (double)d.G[idx];
 	return Rec{sortable_key(lg + hv), (uint64_t)idx};
 }
@@ -1180,6 +1182,14 @@ int rk_astar_step_expand(rk_astar_t *h, void *d_onehot, int out_dtype, void *str
 	launch_append<false>(h, nullptr, d_onehot, out_dtype, st);
 	RK_HIP(hipGetLastError());
 	h->pending = true;
+	return RK_OK;
+}
+
+int rk_astar_set_values_dtype(rk_astar_t *h, int dtype)
+{
+	if (!h) return fail(RK_EINVAL, "rk_astar_set_values_dtype: null handle");
+	if (dtype != RK_OH_F32 && dtype != RK_OH_BF16) return fail(RK_EINVAL, "rk_astar_set_values_dtype: float32 or bfloat16");
+	h->d.values_bf16 = dtype == RK_OH_BF16 ? 1 : 0;
 	return RK_OK;
 }
 

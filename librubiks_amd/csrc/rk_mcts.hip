@@ -253,9 +253,37 @@ void k_mcts_expand(MctsDev d)
 	}
 }
 
+// The net's outputs as the kernel takes them.  IN = 0: float32 probabilities (the caller ran softmax, agents.py:551) and
+// float32 values; IN = 1 / 2: the net's raw LOGITS and values in float32 / bfloat16 -- the softmax over a child's 12
+// logits (exp(x - max) / sum in float32, as torch computes it) happens here, which takes two conversion kernels, the
+// softmax kernel and a copy out of every simulation.
+template <int IN>
+__device__ __forceinline__ float net_scalar(const void *p, size_t i)
+{
+	if (IN == 2) return __builtin_bit_cast(float, (uint32_t)reinterpret_cast<const uint16_t *>(p)[i] << 16);
+	return reinterpret_cast<const float *>(p)[i];
+}
+
+template <int IN>
+__device__ __forceinline__ void child_policy(const void *probs, size_t row, float out[12])
+{
+	#pragma unroll
+	for (int k = 0; k < 12; k++) out[k] = net_scalar<IN>(probs, row * 12 + k);
+	if (IN == 0) return;
+	float m = out[0];
+	#pragma unroll
+	for (int k = 1; k < 12; k++) m = out[k] > m ? out[k] : m;
+	float sum = 0.0f;
+	#pragma unroll
+	for (int k = 0; k < 12; k++) { out[k] = expf(out[k] - m); sum += out[k]; }
+	#pragma unroll
+	for (int k = 0; k < 12; k++) out[k] = out[k] / sum;
+}
+
 // expand_leaf, second half (agents.py:546-571) + find_leaf (agents.py:575-595)
+template <int IN>
 __global__ __launch_bounds__(64)
-void k_mcts_backup_select(MctsDev d, const float *probs, const float *values)
+void k_mcts_backup_select(MctsDev d, const void *probs, const void *values)
 {
 	const int t = blockIdx.x, lane = threadIdx.x;
 	const bool active = lane < 12;
@@ -271,16 +299,18 @@ void k_mcts_backup_select(MctsDev d, const float *probs, const float *values)
 	const int plen = tr.v[TR_PLEN], sims_before = tr.v[TR_SIMS];
 	const int idx = active ? d.child_idx[cbase] : 0;
 	const bool is_new = active && d.child_new[cbase] != 0;
-	const float vf = active ? values[cbase] : 0.0f;
+	const float vf = active ? net_scalar<IN>(values, cbase) : 0.0f;
 	if (is_done) return;
 	const int leaf = pnodes[plen - 1];
 	const double v = (double)vf;
 	if (is_new) {
 		const Node child = node_of(d, node0, idx);
 		child.V() = v;                                                     // agents.py:557
+		float pk[12];
+		child_policy<IN>(probs, cbase, pk);
 		#pragma unroll
 		for (int k = 0; k < 12; k++) {
-			child.P()[k] = (double)probs[cbase * 12 + k];                  // agents.py:556
+			child.P()[k] = (double)pk[k];                                  // agents.py:556
 			child.W()[k] = v;                                              // agents.py:561
 		}
 	}
@@ -325,7 +355,9 @@ void k_mcts_backup_select(MctsDev d, const float *probs, const float *values)
 	// loss the previous step owes this node's reverse edge (agents.py:591) is applied on arrival by the lane that owns
 	// that column, so there is no second dependent round trip for the read-modify-write.
 	// (Tried in round 2 and dropped: touching all 12 children's records as soon as `neighbors` arrives, to overlap the
-	// next level's miss with this level's f64 arithmetic -- 31.7 us against 30.6 us without it.)
+	// next level's miss with this level's f64 arithmetic -- 31.7 us against 30.6 us without it; and a copy of the previous
+	// path's records in LDS (56 KB, two records per wave instruction) from which the descent reads while it follows
+	// that path: 54.7 us against 49.4 us per simulation over 4096 simulations -- the copy costs more than the hits save.)
 	int cur = 1, len = 1, owed_lane = -1;
 	for (;;) {
 		const Node nd = node_of(d, node0, cur);                            // one 512-byte record: four adjacent lines
@@ -511,9 +543,28 @@ int rk_mcts_backup_select(rk_mcts_t *h, const float *d_probs, const float *d_val
 {
 	if (!h || !h->ready) return fail(RK_ESTATE, "rk_mcts_backup_select: reset the engine first");
 	if (!d_probs || !d_values) return fail(RK_EINVAL, "rk_mcts_backup_select: null pointer");
-	hipLaunchKernelGGL(k_mcts_backup_select, dim3(h->d.T), dim3(64), 0, (hipStream_t)stream, h->d, d_probs, d_values);
+	hipLaunchKernelGGL(k_mcts_backup_select<0>, dim3(h->d.T), dim3(64), 0, (hipStream_t)stream, h->d, (const void *)d_probs, (const void *)d_values);
 	RK_HIP(hipGetLastError());
 	return RK_OK;
+}
+
+int rk_mcts_backup_select_logits(rk_mcts_t *h, const void *d_logits, const void *d_values, int dtype, void *stream)
+{
+	if (!h || !h->ready) return fail(RK_ESTATE, "rk_mcts_backup_select_logits: reset the engine first");
+	if (!d_logits || !d_values) return fail(RK_EINVAL, "rk_mcts_backup_select_logits: null pointer");
+	if (dtype == RK_OH_F32)
+		hipLaunchKernelGGL(k_mcts_backup_select<1>, dim3(h->d.T), dim3(64), 0, (hipStream_t)stream, h->d, d_logits, d_values);
+	else if (dtype == RK_OH_BF16)
+		hipLaunchKernelGGL(k_mcts_backup_select<2>, dim3(h->d.T), dim3(64), 0, (hipStream_t)stream, h->d, d_logits, d_values);
+	else
+		return fail(RK_EINVAL, "rk_mcts_backup_select_logits: logits and values must be float32 or bfloat16");
+	RK_HIP(hipGetLastError());
+	return RK_OK;
+}
+
+const int8_t *rk_mcts_children(rk_mcts_t *h)
+{
+	return h ? reinterpret_cast<const int8_t *>(h->d.children) : nullptr;
 }
 
 int rk_mcts_status(rk_mcts_t *h, long long *h_status, void *stream)

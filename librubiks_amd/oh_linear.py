@@ -72,14 +72,17 @@ class OhLinear:
 		return self
 
 	def __call__(self, states: torch.Tensor, out: torch.Tensor = None, route: str = None) -> torch.Tensor:
-		route = route or self.route
 		if states.dtype != torch.int8 or not states.is_cuda or not states.is_contiguous() or states.shape[-1] != 20:
 			raise ValueError("states must be a contiguous (n, 20) int8 tensor on the GPU")
-		n = states.numel() // 20
+		return self.from_pointer(states.data_ptr(), states.numel() // 20, out, route, states.device)
+
+	def from_pointer(self, d_states: int, n: int, out: torch.Tensor = None, route: str = None, device=None) -> torch.Tensor:
+		"""The layer on n 20-byte states at a device address (an engine's own buffer: rk_mcts_children), no tensor around them."""
+		route = route or self.route
 		dtype = torch.bfloat16 if route == "mfma" else self.dtype
 		if out is None:
-			out = torch.empty((n, self.out_features), dtype=dtype, device=states.device)
-		_ffi.check(_ffi.lib().rk_ohl_forward(self._h, states.data_ptr(), out.data_ptr(), _CODES[out.dtype], n, _ROUTES[route], _ffi.stream_ptr()))
+			out = torch.empty((n, self.out_features), dtype=dtype, device=device or "cuda")
+		_ffi.check(_ffi.lib().rk_ohl_forward(self._h, d_states, out.data_ptr(), _CODES[out.dtype], n, _ROUTES[route], _ffi.stream_ptr()))
 		return out
 
 
@@ -168,11 +171,14 @@ def fuse_first_linear(net, route: str = None, epilogue: bool = False, fold_batch
 		if left_v is not None: val.append(_Affine(left_v[0], left_v[1], dtype))
 		policy_net, value_net = torch.nn.Sequential(*pol), torch.nn.Sequential(*val)
 
-	def forward(states: torch.Tensor, policy: bool = True, value: bool = True):
-		x = rest(first(states).to(dtype))
+	def tail(x: torch.Tensor, policy: bool = True, value: bool = True):
+		x = rest(x.to(dtype))
 		out = ([policy_net(x)] if policy else []) + ([value_net(x)] if value else [])
 		return out if len(out) > 1 else out[0]
 
-	forward.first = first
+	def forward(states: torch.Tensor, policy: bool = True, value: bool = True):
+		return tail(first(states), policy, value)
+
+	forward.first, forward.tail = first, tail          # engines that own the states call first.from_pointer(...) and tail(...)
 	forward.modules = (rest, policy_net, value_net)
 	return forward

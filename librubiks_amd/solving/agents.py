@@ -256,6 +256,20 @@ def _value_f32(out) -> torch.Tensor:
 	return out.detach().to(device=gpu, dtype=torch.float32).reshape(-1).contiguous()
 
 
+def _values_for_engine(h, out) -> torch.Tensor:
+	"""
+	The net's value head as the A* engine takes it: a bfloat16 net's values go in as they are (the engine widens them,
+	exactly; rk_astar_set_values_dtype), anything else as a contiguous float32 vector.  Tells the engine which it is.
+	"""
+	v = out[-1] if isinstance(out, (list, tuple)) else out
+	if isinstance(v, torch.Tensor) and v.is_cuda and v.dtype == torch.bfloat16 and v.is_contiguous():
+		v, code = v.detach().reshape(-1), _ffi.OH_BF16
+	else:
+		v, code = _value_f32(v), _ffi.OH_F32
+	_ffi.check(_ffi.lib().rk_astar_set_values_dtype(h, code))
+	return v
+
+
 class CapacityExhausted(RuntimeWarning):
 	"""A search that was limited only by time stopped because its node pool was full (the reference grows its arrays)."""
 
@@ -343,7 +357,7 @@ class AStar(DeepAgent):
 	def _iteration(self, h, oh, code):
 		lib = _ffi.lib()
 		_ffi.check(lib.rk_astar_step_expand(h, oh.data_ptr(), code, _ffi.stream_ptr()))
-		values = _value_f32((self._from_states or self.net)(oh, policy=False, value=True))
+		values = _values_for_engine(h, (self._from_states or self.net)(oh, policy=False, value=True))
 		self._keep = values                # the commit kernels read it after this call returns
 		_ffi.check(lib.rk_astar_step_commit(h, values.data_ptr(), _ffi.stream_ptr()))
 
@@ -400,7 +414,7 @@ class AStar(DeepAgent):
 				values = None
 				if n_new:
 					_ffi.check(lib.rk_astar_new_states_oh(h, oh.data_ptr(), code, _ffi.stream_ptr()))
-					values = _value_f32((self._from_states or self.net)(oh[:n_new], policy=False, value=True))
+					values = _values_for_engine(h, (self._from_states or self.net)(oh[:n_new], policy=False, value=True))
 				_ffi.check(lib.rk_astar_commit(h, values.data_ptr() if values is not None else None, _ffi.stream_ptr()))
 				if time.perf_counter() - t0 >= time_limit:
 					break
@@ -581,10 +595,21 @@ class MCTSBatch(DeepAgent):
 	def _step(self, oh, h):
 		lib = _ffi.lib()
 		_ffi.check(lib.rk_mcts_expand(h, _ffi.stream_ptr()))
-		fused = self._from_states is not None
-		_ffi.check(lib.rk_mcts_children_oh(h, oh.data_ptr(), _ffi.OH_STATES if fused else _OH_CODES[oh.dtype], _ffi.stream_ptr()))
-		p, v = _policy_value_f32((self._from_states if fused else self.net)(oh))
-		self._keep = (p, v)            # the kernels read these after this call returns
+		if self._from_states is not None:
+			# the first layer reads the children where the engine keeps them; no one-hot, no copy
+			x = self._from_states.first.from_pointer(lib.rk_mcts_children(h), 12 * self.n_trees)
+			p, v = self._from_states.tail(x)
+		else:
+			_ffi.check(lib.rk_mcts_children_oh(h, oh.data_ptr(), _OH_CODES[oh.dtype], _ffi.stream_ptr()))
+			p, v = self.net(oh)
+		if isinstance(p, torch.Tensor) and p.is_cuda and p.dtype == v.dtype and p.dtype in (torch.float32, torch.bfloat16) \
+		   and p.is_contiguous() and v.is_contiguous():
+			# raw logits and values in the net's dtype: the softmax (agents.py:551) runs inside the backup kernel
+			self._keep = (p, v)        # the kernels read these after this call returns
+			_ffi.check(lib.rk_mcts_backup_select_logits(h, p.data_ptr(), v.data_ptr(), _OH_CODES[p.dtype], _ffi.stream_ptr()))
+			return
+		p, v = _policy_value_f32((p, v))
+		self._keep = (p, v)
 		_ffi.check(lib.rk_mcts_backup_select(h, p.data_ptr(), v.data_ptr(), _ffi.stream_ptr()))
 
 	@no_grad

@@ -42,7 +42,7 @@ import torch
 import torch.distributed as dist
 
 from librubiks_amd import gpu, no_grad, _ffi, cube
-from librubiks_amd.solving.agents import DeepAgent, _value_f32, _oh_dtype, _OH_CODES
+from librubiks_amd.solving.agents import DeepAgent, _values_for_engine, _oh_dtype, _OH_CODES
 
 STOP_REASONS = {0: "running", 1: "won", 2: "budget", 3: "capacity", 4: "time", 5: "nothing open", 6: "engine error"}
 
@@ -119,8 +119,13 @@ class ShardedAStar(DeepAgent):
 	"""Collective agent: every rank constructs it and calls `search` with the same arguments."""
 
 	def __init__(self, net, lambda_: float, expansions: int, capacity: int = 2_000_000, group=None, force_collectives: bool = False,
-	             poll: int = 1, profile: bool = False):
+	             poll: int = 1, profile: bool = False, fused_first_layer=False):
 		super().__init__(net)
+		# fused_first_layer (True / "epilogue" / "folded"): the net's first Linear reads the new nodes' 20-byte states
+		self._from_states = None
+		if fused_first_layer:
+			from librubiks_amd.oh_linear import fused_net
+			self._from_states = fused_net(net, fused_first_layer)
 		self.lambda_, self.expansions, self.capacity = lambda_, int(expansions), int(capacity)
 		self.tp = Transport(group, force_collectives)
 		self.poll = max(1, int(poll))
@@ -167,9 +172,13 @@ class ShardedAStar(DeepAgent):
 		_ffi.check(lib.rk_astar_shard_bind(h, mine.data_ptr()))
 		_ffi.check(lib.rk_astar_shard_reset(h, state.ctypes.data, float(self.lambda_), send.data_ptr(), st()))
 		root_owner = lib.rk_shard_owner(state.ctypes.data, tp.world)
-		oh_dtype = _oh_dtype(self.net)
-		oh = torch.zeros((12 * N * tp.world, 480), dtype=oh_dtype, device=gpu)
-		code = _OH_CODES[oh_dtype]
+		if self._from_states is not None:
+			oh = torch.from_numpy(cube.repeat_state(cube.get_solved(), 12 * N * tp.world)).to(gpu)     # rows = states
+			code, forward = _ffi.OH_STATES, self._from_states
+		else:
+			oh_dtype = _oh_dtype(self.net)
+			oh = torch.zeros((12 * N * tp.world, 480), dtype=oh_dtype, device=gpu)
+			code, forward = _OH_CODES[oh_dtype], self.net
 		decision = (C.c_longlong * 8)()
 		marks = []                                                       # per iteration: events between the phases
 
@@ -198,7 +207,7 @@ class ShardedAStar(DeepAgent):
 			mark(row)
 			_ffi.check(lib.rk_astar_shard_insert(h, got.data_ptr(), send.data_ptr(), oh.data_ptr(), code, st()))
 			mark(row)
-			values = _value_f32(self.net(oh, policy=False, value=True))
+			values = _values_for_engine(h, forward(oh, policy=False, value=True))
 			self._keep = (values, gathered)
 			mark(row)
 			_ffi.check(lib.rk_astar_shard_push(h, values.data_ptr(), got.data_ptr(), send.data_ptr(), st()))

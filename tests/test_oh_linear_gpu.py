@@ -196,3 +196,43 @@ def test_fused_net_with_epilogue_and_folded_batchnorm(dtype, mode):
 			for a in agent.action_queue:
 				s = orc.rotate(s, a // 2, 1 - a % 2)
 			assert orc.is_solved(s)
+
+
+def test_bf16_net_outputs_go_to_the_engines_as_they_are():
+	"""A bfloat16 net's values (A*) and raw logits + values (MCTS: softmax inside the backup kernel) are taken without
+	conversion kernels.  bf16 -> float32 is exact, so A* must build the very same search as with the values converted
+	by torch first; the MCTS tree's P and V must equal softmax / value of a fresh forward (bf16 rounding: atol 1e-2)."""
+	from benchmarks.nets import FcSmall
+	from librubiks_amd.solving.agents import AStar, MCTSBatch
+	net = FcSmall(seed=6).cuda().eval().to(torch.bfloat16)
+
+	class AsFloat32:                                   # the same net, values handed over as float32 (the old path)
+		def eval(self): return self
+		def parameters(self): return net.parameters()
+		def __call__(self, x, policy=True, value=True):
+			out = net(x, policy=policy, value=value)
+			return [o.float() for o in out] if isinstance(out, list) else out.float()
+
+	np.random.seed(12)
+	start, _, _ = orc.scramble(9, True)
+	a, b = AStar(net, 0.2, 60), AStar(AsFloat32(), 0.2, 60)
+	ra, rb = a.search(start, None, 25_000), b.search(start, None, 25_000)
+	n = len(a)
+	assert ra == rb and n == len(b) and n > 5_000
+	assert (a.states[1:n + 1] == b.states[1:n + 1]).all() and (a.G[1:n + 1] == b.G[1:n + 1]).all() and (a.parents[1:n + 1] == b.parents[1:n + 1]).all()
+
+	starts = []
+	for i in range(4):
+		np.random.seed(80 + i)
+		starts.append(orc.scramble(7, True)[0])
+	for fused in (False, "folded"):
+		agent = MCTSBatch(net, 1.0, 4, capacity=1200, fused_first_layer=fused)
+		agent.search(np.array(starts), max_states=1200, max_sims=80, use_graph=True, poll=16)
+		t = agent.tree_arrays(2)
+		m = t["n"]
+		assert m > 400
+		with torch.no_grad():
+			p, v = net(cube.as_oh(t["states"][1:m + 1]).to(torch.bfloat16))
+		assert np.allclose(t["P"][1:m + 1], p.float().softmax(dim=1).cpu().numpy(), atol=1e-2)
+		assert np.allclose(t["V"][1:m + 1], v.float().reshape(-1).cpu().numpy(), atol=2e-2)
+		assert np.allclose(t["P"][1:m + 1].sum(axis=1), 1.0, atol=1e-6)

@@ -337,3 +337,21 @@ def test_partitioned_mcts_gloo(tmp_path):
 			for a in q:
 				s = orc.rotate(s, a // 2, 1 - a % 2)
 			assert orc.is_solved(s)
+
+
+def test_sharded_world1_with_fused_first_layer():
+	"""ShardedAStar hands the net the new nodes' 20-byte states (RK_OH_STATES through rk_astar_shard_insert): at world 1
+	it is the single-GPU engine with the same option, node for node (same fixed batch shape, so the same net numbers)."""
+	from benchmarks.nets import FcSmall
+	net = FcSmall(seed=4).cuda().eval()
+	np.random.seed(77)
+	start, _, _ = orc.scramble(10, True)
+	one = AStar(net, 0.2, 50, fused_first_layer=True)
+	many = ShardedAStar(net, 0.2, 50, capacity=30_000, fused_first_layer=True)
+	a, b = one.search(start, None, 20_000), many.search(start, None, 20_000)
+	assert a == b and len(one) == len(many)
+	states, G, parents, pact = many.local_arrays()
+	n = len(one)
+	assert (states[1:n + 1] == one.states[1:n + 1]).all() and (G[1:n + 1] == one.G[1:n + 1]).all()
+	if a:
+		assert list(one.action_queue) == list(many.action_queue)
