@@ -20,6 +20,7 @@
 //
 // Which one is faster where is measured by benchmarks/oh_linear.py (profiles/r02_oh_linear.json).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -343,6 +344,9 @@ int rk_ohl_forward(rk_ohl_t *h, const int8_t *d_states, void *d_out, int out_dty
 	const size_t quantum = route == RK_OHL_MFMA ? 256 : OHL_GATHER_ROWS;
 	size_t groups = (route == RK_OHL_MFMA ? 512u : 256u) / col_tiles;
 	if (groups < 1) groups = 1;
+#ifdef RK_TUNING
+	if (const char *e = getenv("RK_OHL_GROUPS")) { const long g = atol(e); if (g > 0) groups = (size_t)g; }   // benchmarks/tune_ohl.py
+#endif
 	const size_t max_groups = (n + quantum - 1) / quantum;
 	if (groups > max_groups) groups = max_groups;
 	if (groups > 65535) groups = 65535;
