@@ -51,6 +51,10 @@ def test_reference_traces(golden, tag):
 @pytest.mark.parametrize("seed,depth,lam,n,budget", [
 	(101, 5, 0.0, 3, 4_000), (102, 7, 0.3, 17, 20_000), (103, 9, 1.0, 128, 30_000), (104, 6, 0.05, 1000, 40_000),
 	(105, 10, 0.6, 50, 25_000), (106, 4, 2.5, 7, 10_000), (107, 12, 0.2, 400, 120_000),
+	# K = 12 N decides how the new records are sorted and merged: runs of 256 (K <= 2048), up to eight 2048-record chunks
+	# handed to the queue insert as they are (K <= 16 384: 104 above), chunks merged into one run first (the two below;
+	# N = 10 000 is the reference's largest configuration, 59 chunks and six merge passes)
+	(108, 11, 0.15, 1500, 150_000), (109, 13, 0.1, 10_000, 400_000),
 ])
 def test_against_oracle(seed, depth, lam, n, budget):
 	np.random.seed(seed)
