@@ -185,7 +185,10 @@ __global__ void k_astar_root(AstarDev d, const uint32_t *root, int insert)
 // reads per candidate -- stay on the CU; `s_heads` may be null (then everything is read from global memory).
 constexpr int POP_LDS = 6144;                   // 96 KB of 16-byte records
 
-__device__ __forceinline__ void pop_select(const AstarDev &d, const int32_t *meta, int n_cand, int n_exp, Rec *s_heads)
+// Candidates are handled by threads first, first + stride, ...: one workgroup (end-of-iteration kernel) or a grid (k_pop_wide).
+__device__ __forceinline__ bool pop_is_wide(const AstarDev &d) { return d.world == 1 && d.q.levels * d.N > POP_LDS; }
+
+__device__ __forceinline__ void pop_select(const AstarDev &d, const int32_t *meta, int n_cand, int n_exp, Rec *s_heads, int first, int stride)
 {
 	const QueueDev &q = d.q;
 	const bool staged = s_heads != nullptr && q.levels * n_exp <= POP_LDS;
@@ -197,7 +200,7 @@ __device__ __forceinline__ void pop_select(const AstarDev &d, const int32_t *met
 		}
 		__syncthreads();
 	}
-	for (int cand = threadIdx.x; cand < q.levels * n_exp; cand += blockDim.x) {
+	for (int cand = first; cand < q.levels * n_exp; cand += stride) {
 		const int j = cand / n_exp, i = cand - j * n_exp;
 		const int head = meta[Q_HEAD * QL + j], live = meta[Q_LEN * QL + j] - head;
 		if (i >= live) continue;
@@ -262,22 +265,29 @@ __global__ __launch_bounds__(256)
 void k_expand_lookup(AstarDev d)
 {
 	__shared__ u32x4 s_act[36];
+	__shared__ int s_take[QL];
 	stage_action_tables(s_act, threadIdx.x);
+	if (threadIdx.x < QL) s_take[threadIdx.x] = 0;
 	__syncthreads();
 	const int c = blockIdx.x * blockDim.x + threadIdx.x;
 	const int n_pop = d.ctr[C_NPOP];
-	if (c >= 12 * n_pop) return;
-	const int i = c / 12, a = c - 12 * i;
-	if (a == 0) atomicAdd(&qmeta(d.q, Q_TAKE)[d.cand_level[i]], 1);     // the queue learns which level the node leaves
-	uint32_t s[5];
-	load5(d.states + (size_t)d.exp_idx[i] * 5, s);
-	uint32_t tab[12];
-	load_action_table(s_act, (uint32_t)a, tab);
-	move5(s, tab);
-	#pragma unroll
-	for (int j = 0; j < 5; j++) d.children[(size_t)c * 5 + j] = s[j];
-	d.solved[c] = is_solved5(s) ? 1 : 0;
-	lookup_elect(d, s, c, [&](int c2, uint32_t o[5]) { child_of(d, s_act, c2, o); });
+	if (c < 12 * n_pop) {
+		const int i = c / 12, a = c - 12 * i;
+		// the queue learns which level the node leaves -- counted per workgroup in LDS: one global atomic per popped node
+		// put N operations on a single address (10 000 at the reference's largest N: half of this kernel's time)
+		if (a == 0) atomicAdd(&s_take[d.cand_level[i]], 1);
+		uint32_t s[5];
+		load5(d.states + (size_t)d.exp_idx[i] * 5, s);
+		uint32_t tab[12];
+		load_action_table(s_act, (uint32_t)a, tab);
+		move5(s, tab);
+		#pragma unroll
+		for (int j = 0; j < 5; j++) d.children[(size_t)c * 5 + j] = s[j];
+		d.solved[c] = is_solved5(s) ? 1 : 0;
+		lookup_elect(d, s, c, [&](int c2, uint32_t o[5]) { child_of(d, s_act, c2, o); });
+	}
+	__syncthreads();
+	if (threadIdx.x < QL && s_take[threadIdx.x] > 0) atomicAdd(&qmeta(d.q, Q_TAKE)[threadIdx.x], s_take[threadIdx.x]);
 }
 
 // Sharded mode: incoming child slots.  The receive buffer is `world` blocks of {32-byte header, K records of 32 B,
@@ -687,7 +697,9 @@ void k_end(AstarDev d, int new_in_rec1, int count_iteration)
 	if (tid < C_COUNT) d.ctr[tid] = s_ctr[tid];
 	else if (tid >= 64 && tid < 64 + 4 * QL) d.q.meta[tid - 64] = s_meta[tid - 64];
 	__syncthreads();
-	pop_select(d, s_meta, s_ncand, s_nexp, s_heads);
+	// With many expansions (levels * N candidates beyond what one workgroup can stage) the selection runs as its own
+	// grid-wide kernel right behind this one: on a single workgroup it was 64 us of the iteration at N = 10 000.
+	if (!pop_is_wide(d)) pop_select(d, s_meta, s_ncand, s_nexp, s_heads, tid, blockDim.x);
 	if (SHARDED) {
 		// this rank's contribution to the all-gather: pool size, win flag, solved index, error, then the candidate costs
 		__syncthreads();
@@ -719,7 +731,17 @@ void k_pop_select_only(AstarDev d, int n_exp)
 		s_ncand = n_cand;
 	}
 	__syncthreads();
-	pop_select(d, s_meta, s_ncand, n_exp, nullptr);
+	if (!pop_is_wide(d)) pop_select(d, s_meta, s_ncand, n_exp, nullptr, threadIdx.x, blockDim.x);
+}
+
+// the pop selection as a grid (single-GPU engines with levels * N > POP_LDS): launched behind k_end / k_pop_select_only
+__global__ __launch_bounds__(256)
+void k_pop_wide(AstarDev d)
+{
+	__shared__ int32_t s_meta[4 * QL];
+	if (threadIdx.x < 4 * QL) s_meta[threadIdx.x] = d.q.meta[threadIdx.x];
+	__syncthreads();
+	pop_select(d, s_meta, d.ctr[C_NCAND], d.ctr[C_NEXP], nullptr, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 __global__ void k_set_budget(AstarDev d, int budget)
@@ -854,15 +876,17 @@ void k_shard_expand(AstarDev d, uint8_t *send)
 	__shared__ u32x4 s_act[36];
 	__shared__ int s_wave[4];
 	__shared__ int s_ticket, s_base;
+	__shared__ int s_take[QL];
 	stage_action_tables(s_act, threadIdx.x);
-	const int b = scan_ticket(&d.ctr[C_TICKET1], &s_ticket);
+	if (threadIdx.x < QL) s_take[threadIdx.x] = 0;
+	const int b = scan_ticket(&d.ctr[C_TICKET1], &s_ticket);                // (contains the barrier that publishes s_take)
 	const int n_pop = d.ctr[C_NPOP], K = 12 * n_pop;
 	const int c = b * ASCAN + threadIdx.x;
 	const bool valid = c < K;
 	uint32_t s[5] = {0, 0, 0, 0, 0}, meta6 = 0, p = 0, owner = 0xFFFFFFFFu;
 	if (valid) {
 		const int i = c / 12, a = c - 12 * i;
-		if (a == 0) atomicAdd(&qmeta(d.q, Q_TAKE)[d.cand_level[i]], 1);
+		if (a == 0) atomicAdd(&s_take[d.cand_level[i]], 1);                 // per workgroup, see k_expand_lookup
 		p = (uint32_t)d.exp_idx[i];
 		load5(d.states + (size_t)p * 5, s);
 		uint32_t tab[12];
@@ -885,6 +909,7 @@ void k_shard_expand(AstarDev d, uint8_t *send)
 		if (b == (int)gridDim.x - 1 && threadIdx.x == 0) reinterpret_cast<uint32_t *>(blk)[0] = (uint32_t)(base + total);
 		__syncthreads();                                                 // s_base is reused by the next owner
 	}
+	if (threadIdx.x < QL && s_take[threadIdx.x] > 0) atomicAdd(&qmeta(d.q, Q_TAKE)[threadIdx.x], s_take[threadIdx.x]);
 }
 
 // Shortcut offer (16 B): {parent_idx, new G for the parent, index of the child on this rank, this rank | rev(action) << 8}
@@ -997,6 +1022,7 @@ int dev_alloc(rk_astar *h, T **p, size_t count)
 }
 
 inline unsigned blocks(size_t n, unsigned per = 256) { return (unsigned)((n + per - 1) / per); }
+inline bool pop_is_wide_host(const AstarDev &d) { return d.world == 1 && d.q.levels * d.N > POP_LDS; }
 
 constexpr int WALK_MAX = 1 << 16;
 
@@ -1042,7 +1068,10 @@ int launch_commit(rk_astar *h, const float *d_values, const uint8_t *recv, hipSt
 	}
 	const unsigned grid = std::min<unsigned>(1024u, std::max<unsigned>(blocks((size_t)d.Kpad * 4), 8u));
 	hipLaunchKernelGGL((k_queue_insert<SHARDED>), dim3(grid), dim3(256), 0, st, d, from);
-	if (!SHARDED) hipLaunchKernelGGL((k_end<false>), dim3(1), dim3(1024), 0, st, d, from, 1);
+	if (!SHARDED) {
+		hipLaunchKernelGGL((k_end<false>), dim3(1), dim3(1024), 0, st, d, from, 1);
+		if (pop_is_wide_host(d)) hipLaunchKernelGGL(k_pop_wide, dim3(blocks((size_t)d.q.levels * d.N)), dim3(256), 0, st, d);
+	}
 	(void)recv;
 	return from;
 }
@@ -1227,6 +1256,7 @@ int rk_astar_expand(rk_astar_t *h, int n_expand, long long *h_info, void *stream
 	int32_t c[C_COUNT];
 	if (n_expand != h->n_exp) {
 		hipLaunchKernelGGL(k_pop_select_only, dim3(1), dim3(1024), 0, st, h->d, n_expand);
+		if (pop_is_wide_host(h->d)) hipLaunchKernelGGL(k_pop_wide, dim3(blocks((size_t)h->d.q.levels * h->d.N)), dim3(256), 0, st, h->d);
 		h->n_exp = n_expand;
 	}
 	if (!h->budget_explicit) {
