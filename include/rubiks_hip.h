@@ -300,10 +300,13 @@ int rk_mcts_set_root_pv(rk_mcts_t *h, const float *d_probs, const float *d_value
 int rk_mcts_expand(rk_mcts_t *h, void *stream);
 int rk_mcts_children_oh(rk_mcts_t *h, void *d_out, int out_dtype, void *stream);
 int rk_mcts_backup_select(rk_mcts_t *h, const float *d_probs, const float *d_values, void *stream);
-/* The same step from the net's RAW outputs: d_logits (T*12, 12) and d_values (T*12), both float32 (dtype RK_OH_F32) or
- * both bfloat16 (RK_OH_BF16); the softmax of agents.py:551 (exp(x - max) / sum in float32) runs inside the kernel, which
- * saves the conversion, softmax and copy kernels of every simulation. */
-int rk_mcts_backup_select_logits(rk_mcts_t *h, const void *d_logits, const void *d_values, int dtype, void *stream);
+/* The same step from the net's RAW outputs: d_logits, T*12 rows of 12 logits `logits_stride` elements apart, and d_values,
+ * T*12 values `values_stride` elements apart (12 and 1 for separate contiguous heads; 13 and 13 for one (T*12, 13) tensor of
+ * merged heads with d_values = d_logits + 12 elements), both float32 (dtype RK_OH_F32) or both bfloat16 (RK_OH_BF16); the
+ * softmax of agents.py:551 (exp(x - max) / sum in float32) runs inside the kernel, which saves the conversion, softmax and
+ * copy kernels of every simulation. */
+int rk_mcts_backup_select_logits(rk_mcts_t *h, const void *d_logits, int logits_stride, const void *d_values, int values_stride,
+                                 int dtype, void *stream);
 /* Device pointer to the (T*12, 20) int8 child states of the pending simulation (what rk_mcts_children_oh encodes): a net
  * whose first layer reads states (rk_ohl_forward) can take them where they lie. */
 const int8_t *rk_mcts_children(rk_mcts_t *h);

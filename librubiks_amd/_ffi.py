@@ -99,7 +99,7 @@ SIGNATURES = {
 	"rk_mcts_expand": (_i, [_vp, _vp]),
 	"rk_mcts_children_oh": (_i, [_vp, _vp, _i, _vp]),
 	"rk_mcts_backup_select": (_i, [_vp, _vp, _vp, _vp]),
-	"rk_mcts_backup_select_logits": (_i, [_vp, _vp, _vp, _i, _vp]),
+	"rk_mcts_backup_select_logits": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp]),
 	"rk_mcts_children": (_vp, [_vp]),
 	"rk_mcts_status": (_i, [_vp, _vp, _vp]),
 	"rk_mcts_export": (_i, [_vp, _i, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

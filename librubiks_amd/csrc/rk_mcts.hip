@@ -265,10 +265,10 @@ __device__ __forceinline__ float net_scalar(const void *p, size_t i)
 }
 
 template <int IN>
-__device__ __forceinline__ void child_policy(const void *probs, size_t row, float out[12])
+__device__ __forceinline__ void child_policy(const void *probs, size_t row, int stride, float out[12])
 {
 	#pragma unroll
-	for (int k = 0; k < 12; k++) out[k] = net_scalar<IN>(probs, row * 12 + k);
+	for (int k = 0; k < 12; k++) out[k] = net_scalar<IN>(probs, row * (size_t)stride + k);
 	if (IN == 0) return;
 	float m = out[0];
 	#pragma unroll
@@ -283,7 +283,7 @@ __device__ __forceinline__ void child_policy(const void *probs, size_t row, floa
 // expand_leaf, second half (agents.py:546-571) + find_leaf (agents.py:575-595)
 template <int IN>
 __global__ __launch_bounds__(64)
-void k_mcts_backup_select(MctsDev d, const void *probs, const void *values)
+void k_mcts_backup_select(MctsDev d, const void *probs, const void *values, int p_stride, int v_stride)
 {
 	const int t = blockIdx.x, lane = threadIdx.x;
 	const bool active = lane < 12;
@@ -299,7 +299,7 @@ void k_mcts_backup_select(MctsDev d, const void *probs, const void *values)
 	const int plen = tr.v[TR_PLEN], sims_before = tr.v[TR_SIMS];
 	const int idx = active ? d.child_idx[cbase] : 0;
 	const bool is_new = active && d.child_new[cbase] != 0;
-	const float vf = active ? net_scalar<IN>(values, cbase) : 0.0f;
+	const float vf = active ? net_scalar<IN>(values, cbase * (size_t)v_stride) : 0.0f;
 	if (is_done) return;
 	const int leaf = pnodes[plen - 1];
 	const double v = (double)vf;
@@ -307,7 +307,7 @@ void k_mcts_backup_select(MctsDev d, const void *probs, const void *values)
 		const Node child = node_of(d, node0, idx);
 		child.V() = v;                                                     // agents.py:557
 		float pk[12];
-		child_policy<IN>(probs, cbase, pk);
+		child_policy<IN>(probs, cbase, p_stride, pk);
 		#pragma unroll
 		for (int k = 0; k < 12; k++) {
 			child.P()[k] = (double)pk[k];                                  // agents.py:556
@@ -543,19 +543,20 @@ int rk_mcts_backup_select(rk_mcts_t *h, const float *d_probs, const float *d_val
 {
 	if (!h || !h->ready) return fail(RK_ESTATE, "rk_mcts_backup_select: reset the engine first");
 	if (!d_probs || !d_values) return fail(RK_EINVAL, "rk_mcts_backup_select: null pointer");
-	hipLaunchKernelGGL(k_mcts_backup_select<0>, dim3(h->d.T), dim3(64), 0, (hipStream_t)stream, h->d, (const void *)d_probs, (const void *)d_values);
+	hipLaunchKernelGGL(k_mcts_backup_select<0>, dim3(h->d.T), dim3(64), 0, (hipStream_t)stream, h->d, (const void *)d_probs, (const void *)d_values, 12, 1);
 	RK_HIP(hipGetLastError());
 	return RK_OK;
 }
 
-int rk_mcts_backup_select_logits(rk_mcts_t *h, const void *d_logits, const void *d_values, int dtype, void *stream)
+int rk_mcts_backup_select_logits(rk_mcts_t *h, const void *d_logits, int logits_stride, const void *d_values, int values_stride, int dtype, void *stream)
 {
 	if (!h || !h->ready) return fail(RK_ESTATE, "rk_mcts_backup_select_logits: reset the engine first");
 	if (!d_logits || !d_values) return fail(RK_EINVAL, "rk_mcts_backup_select_logits: null pointer");
+	if (logits_stride < 12 || values_stride < 1) return fail(RK_EINVAL, "rk_mcts_backup_select_logits: strides are in elements, at least 12 and 1");
 	if (dtype == RK_OH_F32)
-		hipLaunchKernelGGL(k_mcts_backup_select<1>, dim3(h->d.T), dim3(64), 0, (hipStream_t)stream, h->d, d_logits, d_values);
+		hipLaunchKernelGGL(k_mcts_backup_select<1>, dim3(h->d.T), dim3(64), 0, (hipStream_t)stream, h->d, d_logits, d_values, logits_stride, values_stride);
 	else if (dtype == RK_OH_BF16)
-		hipLaunchKernelGGL(k_mcts_backup_select<2>, dim3(h->d.T), dim3(64), 0, (hipStream_t)stream, h->d, d_logits, d_values);
+		hipLaunchKernelGGL(k_mcts_backup_select<2>, dim3(h->d.T), dim3(64), 0, (hipStream_t)stream, h->d, d_logits, d_values, logits_stride, values_stride);
 	else
 		return fail(RK_EINVAL, "rk_mcts_backup_select_logits: logits and values must be float32 or bfloat16");
 	RK_HIP(hipGetLastError());

@@ -134,6 +134,49 @@ def _fold(modules, pending):
 	return out, pending
 
 
+def _merge_heads(pol, val):
+	"""
+	The policy and the value head (lists of modules of equal structure: Linear, activation, ..., Linear; model.py:128-129)
+	as ONE stack: the first Linear layers side by side (both read the shared trunk), the later ones block-diagonal, so
+	both heads cost one GEMM per layer and one activation kernel.  -> (Sequential giving (n, 12 + 1) rows, 12) or None if
+	the heads do not match.  Zeros off the diagonal add exact zeros; the accumulation order inside the GEMM may differ.
+	"""
+	if len(pol) != len(val):
+		return None
+	out, first, wp, wv = [], True, 0, 0
+	for a, b in zip(pol, val):
+		if isinstance(a, torch.nn.Linear) and isinstance(b, torch.nn.Linear) and a.weight.dtype == b.weight.dtype:
+			if first and a.in_features != b.in_features:
+				return None
+			dev, dt = a.weight.device, a.weight.dtype
+			if first:
+				w = torch.cat([a.weight.detach(), b.weight.detach()], 0)
+			else:
+				if a.in_features != wp or b.in_features != wv:
+					return None
+				w = torch.zeros((a.out_features + b.out_features, wp + wv), device=dev, dtype=dt)
+				w[:a.out_features, :wp] = a.weight.detach()
+				w[a.out_features:, wp:] = b.weight.detach()
+			bias = torch.cat([a.bias.detach() if a.bias is not None else torch.zeros(a.out_features, device=dev, dtype=dt),
+			                  b.bias.detach() if b.bias is not None else torch.zeros(b.out_features, device=dev, dtype=dt)])
+			lin = torch.nn.Linear(w.shape[1], w.shape[0], bias=True, device=dev, dtype=dt)
+			with torch.no_grad():
+				lin.weight.copy_(w)
+				lin.bias.copy_(bias)
+			out.append(lin)
+			first, wp, wv = False, a.out_features, b.out_features
+		elif isinstance(a, torch.nn.ELU) and isinstance(b, torch.nn.ELU) and a.alpha == b.alpha:
+			out.append(torch.nn.ELU(alpha=a.alpha))
+		elif isinstance(a, torch.nn.ReLU) and isinstance(b, torch.nn.ReLU):
+			out.append(torch.nn.ReLU())
+		elif isinstance(a, _Affine) and isinstance(b, _Affine):
+			m = _Affine(torch.cat([a.scale, b.scale]), torch.cat([a.shift, b.shift]), a.scale.dtype)
+			out.append(m)
+		else:
+			return None
+	return (torch.nn.Sequential(*out), wp) if not first else None
+
+
 def fused_net(net, mode):
 	"""`fused_first_layer` option of the agents and of adi_traindata: True -> the layer alone (exact for float32 nets),
 	"epilogue" -> with its activation and BatchNorm in the kernel, "folded" -> and every other eval-mode BatchNorm folded"""
@@ -170,9 +213,15 @@ def fuse_first_linear(net, route: str = None, epilogue: bool = False, fold_batch
 		if left_p is not None: pol.append(_Affine(left_p[0], left_p[1], dtype))
 		if left_v is not None: val.append(_Affine(left_v[0], left_v[1], dtype))
 		policy_net, value_net = torch.nn.Sequential(*pol), torch.nn.Sequential(*val)
+		merged = _merge_heads(pol, val)                # both heads as one stack, used when both are asked for (MCTS)
+	else:
+		merged = None
 
 	def tail(x: torch.Tensor, policy: bool = True, value: bool = True):
 		x = rest(x.to(dtype))
+		if policy and value and merged is not None:
+			both = merged[0](x)                        # (n, 12 + 1): the heads are views of one tensor
+			return [both[:, :merged[1]], both[:, merged[1]:]]
 		out = ([policy_net(x)] if policy else []) + ([value_net(x)] if value else [])
 		return out if len(out) > 1 else out[0]
 
@@ -181,4 +230,5 @@ def fuse_first_linear(net, route: str = None, epilogue: bool = False, fold_batch
 
 	forward.first, forward.tail = first, tail          # engines that own the states call first.from_pointer(...) and tail(...)
 	forward.modules = (rest, policy_net, value_net)
+	forward.merged_heads = merged[0] if merged is not None else None
 	return forward

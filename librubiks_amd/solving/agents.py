@@ -603,10 +603,12 @@ class MCTSBatch(DeepAgent):
 			_ffi.check(lib.rk_mcts_children_oh(h, oh.data_ptr(), _OH_CODES[oh.dtype], _ffi.stream_ptr()))
 			p, v = self.net(oh)
 		if isinstance(p, torch.Tensor) and p.is_cuda and p.dtype == v.dtype and p.dtype in (torch.float32, torch.bfloat16) \
-		   and p.is_contiguous() and v.is_contiguous():
-			# raw logits and values in the net's dtype: the softmax (agents.py:551) runs inside the backup kernel
+		   and p.dim() == 2 and p.stride(1) == 1 and p.stride(0) >= 12 and v.numel() == len(p) and v.reshape(len(p), -1).stride(0) >= 1:
+			# raw logits and values in the net's dtype (rows may be views into one tensor of merged heads): the softmax
+			# (agents.py:551) runs inside the backup kernel
 			self._keep = (p, v)        # the kernels read these after this call returns
-			_ffi.check(lib.rk_mcts_backup_select_logits(h, p.data_ptr(), v.data_ptr(), _OH_CODES[p.dtype], _ffi.stream_ptr()))
+			_ffi.check(lib.rk_mcts_backup_select_logits(h, p.data_ptr(), p.stride(0), v.data_ptr(), v.reshape(len(p), -1).stride(0),
+			                                            _OH_CODES[p.dtype], _ffi.stream_ptr()))
 			return
 		p, v = _policy_value_f32((p, v))
 		self._keep = (p, v)

@@ -56,3 +56,24 @@ def test_fold_leaves_training_mode_batchnorm_alone():
 	bn = _bn(8, 7).train()
 	mods, pending = _fold([bn, torch.nn.Linear(8, 4)], None)
 	assert pending is None and mods[0] is bn
+
+
+def test_merged_heads_are_the_two_heads_side_by_side():
+	from librubiks_amd.oh_linear import _Affine, _merge_heads
+	torch.manual_seed(5)
+	pol = [torch.nn.Linear(16, 8), torch.nn.ELU(), torch.nn.Linear(8, 12)]
+	val = [torch.nn.Linear(16, 8), torch.nn.ELU(), torch.nn.Linear(8, 1)]
+	merged, width = _merge_heads(pol, val)
+	x = torch.randn(9, 16)
+	with torch.no_grad():
+		both = merged(x)
+		assert both.shape == (9, 13) and width == 12
+		assert torch.allclose(both[:, :12], torch.nn.Sequential(*pol)(x), rtol=1e-5, atol=1e-6)
+		assert torch.allclose(both[:, 12:], torch.nn.Sequential(*val)(x), rtol=1e-5, atol=1e-6)
+		# the block-diagonal layer has exact zeros off the diagonal
+		w = merged[2].weight
+		assert (w[:12, 8:] == 0).all() and (w[12:, :8] == 0).all()
+	# heads that do not match stay separate
+	assert _merge_heads(pol, val[:2]) is None
+	assert _merge_heads(pol, [torch.nn.Linear(16, 8), torch.nn.ReLU(), torch.nn.Linear(8, 1)]) is None
+	assert _merge_heads(pol, [torch.nn.Linear(20, 8), torch.nn.ELU(), torch.nn.Linear(8, 1)]) is None
