@@ -30,6 +30,9 @@ rm -f $O/search.json
 for a in "" "--bf16 1" "--fused 1" "--bf16 1 --fused 1" "--bf16 1 --fused 2" "--bf16 1 --fused 3" "--fused 3"; do python benchmarks/search.py astar $a 2>/dev/null | grep '^{' >> $O/search.json; done
 for a in "" "--bf16 1" "--fused 1" "--bf16 1 --fused 1" "--bf16 1 --fused 3" "--fused 3"; do python benchmarks/search.py mcts $a 2>/dev/null | tail -1 >> $O/search.json; done
 timeout -k 10 600 python benchmarks/adi.py 2>/dev/null | grep '^{' > $O/adi.json
+rm -f $O/astar_batch.json
+for a in "" "--bf16 1" "--bf16 1 --fused 3"; do python benchmarks/search.py astar_batch --expansions 100 --max-states 50000 $a 2>/dev/null | tail -1 >> $O/astar_batch.json; done
+for a in "--bf16 1" "--bf16 1 --fused 3"; do python benchmarks/search.py astar_batch $a 2>/dev/null | tail -1 >> $O/astar_batch.json; done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_mcts256 -- python3 benchmarks/search.py mcts --sims 256 > $O/prof_mcts256.log 2>&1
 # sharded search rehearsals (no multi-GPU node: world 1, and two ranks over gloo on the one GPU)
 rm -f $O/sharded.json

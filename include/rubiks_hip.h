@@ -208,23 +208,23 @@ long long rk_astar_export_open(rk_astar_t *h, double *h_costs, long long *h_indi
 long long rk_astar_next_pops(rk_astar_t *h, long long *h_indices, size_t max_len, void *stream);
 
 /* ---- batched A*: S independent searches in lock-step, no host synchronisation inside an iteration -------------
- * Every search follows agents.py:171-413 exactly as rk_astar_* does; all sizes that vary (nodes popped, new states,
- * queue length, won, out of budget) live in device memory, so one iteration of ALL searches is a fixed sequence of
- * launches around one net forward on the padded (S * 12 N, 480) one-hot batch -- capturable in a hipGraph:
+ * Every search is a complete rk_astar_* engine (agents.py:171-413: its own pool, hash table, open queue, counter block);
+ * the batch launches the same kernels with a second grid dimension (search), so one iteration of ALL searches is the
+ * six launches of one search around one net forward on the padded (S * 12 N, 480) batch -- capturable in a hipGraph:
  *   rk_astarb_step_expand : loop guard + pop + fan-out + membership / first-occurrence / append + goal test for every
- *                           search, then the one-hot of the new states into d_onehot (S, 12 N, 480) (rows past a
- *                           search's new states are zero)
- *   rk_astarb_step_commit : d_values (S * 12 N) from the net; cost, push, relaxation, bookkeeping
+ *                           search, then the net's rows of the new states into d_onehot: search s owns rows
+ *                           s * 12 N ... (one-hot of out_dtype, or the 20-byte states with RK_OH_STATES); rows past a
+ *                           search's new states keep what they held
+ *   rk_astarb_step_commit : d_values (S * 12 N) from the net (float32, or bfloat16 after rk_astarb_set_values_dtype);
+ *                           cost, push, relaxation, bookkeeping, next pop lists
  *   rk_astarb_status      : synchronises; h_status (S, 7) int64 = done, won (2 = start already solved), n_states,
- *                           iterations, queue length, index of the solved state, error (1 = merge bound too small)
- * rk_astarb_set_merge_bound tells the engine an upper bound of any search's queue length (the launch width of the
- * queue merge); the host raises it from the status it polls (it starts at 12 N + 1 and the queue grows by at most
- * 12 N per iteration). */
+ *                           iterations, open-queue length, index of the solved state, error
+ * h_max_states of rk_astarb_reset: per-search state budgets (null = the capacity). */
 typedef struct rk_astarb rk_astarb_t;
 int rk_astarb_create(rk_astarb_t **out, int n_searches, size_t capacity_per_search, int max_expansions);
 int rk_astarb_destroy(rk_astarb_t *h);
 int rk_astarb_reset(rk_astarb_t *h, const int8_t *h_start_states, const long long *h_max_states, double lambda, void *stream);
-int rk_astarb_set_merge_bound(rk_astarb_t *h, long long bound);
+int rk_astarb_set_values_dtype(rk_astarb_t *h, int dtype, void *stream);
 int rk_astarb_step_expand(rk_astarb_t *h, void *d_onehot, int out_dtype, void *stream);
 int rk_astarb_step_commit(rk_astarb_t *h, const float *d_values, void *stream);
 int rk_astarb_status(rk_astarb_t *h, long long *h_status, void *stream);

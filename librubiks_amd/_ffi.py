@@ -71,7 +71,7 @@ SIGNATURES = {
 	"rk_astarb_create": (_i, [C.POINTER(_vp), _i, _sz, _i]),
 	"rk_astarb_destroy": (_i, [_vp]),
 	"rk_astarb_reset": (_i, [_vp, _vp, _vp, C.c_double, _vp]),
-	"rk_astarb_set_merge_bound": (_i, [_vp, C.c_longlong]),
+	"rk_astarb_set_values_dtype": (_i, [_vp, _i, _vp]),
 	"rk_astarb_step_expand": (_i, [_vp, _vp, _i, _vp]),
 	"rk_astarb_step_commit": (_i, [_vp, _vp, _vp]),
 	"rk_astarb_status": (_i, [_vp, _vp, _vp]),

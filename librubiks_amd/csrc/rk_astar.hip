@@ -42,7 +42,8 @@
 //   * relaxation is two vectorised passes, each reading all of G before writing, the second seeing the first's
 //     writes; duplicate targets in the second pass resolve to the LAST one in batch order  (agents.py:353-367)
 //
-// Hash-sharded mode (one engine per GPU, owner(state) = owner_of(state, world); no counterpart in the reference): see
+// Batched mode (S searches in lock-step: the kb_* wrappers and rk_astarb_* at the end of this file) and
+// hash-sharded mode (one engine per GPU, owner(state) = owner_of(state, world); no counterpart in the reference): see
 // the section "hash-sharded search" below and librubiks_amd/solving/sharded.py.
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -261,8 +262,7 @@ __device__ __forceinline__ void lookup_elect(const AstarDev &d, const uint32_t s
 }
 
 // pop + gather + 12-child fan-out + goal flag + membership / election: one thread per child
-__global__ __launch_bounds__(256)
-void k_expand_lookup(AstarDev d)
+__device__ __forceinline__ void expand_lookup_body(const AstarDev &d)
 {
 	__shared__ u32x4 s_act[36];
 	__shared__ int s_take[QL];
@@ -289,6 +289,18 @@ void k_expand_lookup(AstarDev d)
 	__syncthreads();
 	if (threadIdx.x < QL && s_take[threadIdx.x] > 0) atomicAdd(&qmeta(d.q, Q_TAKE)[threadIdx.x], s_take[threadIdx.x]);
 }
+__global__ __launch_bounds__(256)
+void k_expand_lookup(AstarDev d)
+{
+	expand_lookup_body(d);
+}
+__global__ __launch_bounds__(256)
+void kb_expand_lookup(const AstarDev *__restrict__ devs)
+{
+	const AstarDev d = devs[blockIdx.y];              // search blockIdx.y of the batch (rk_astarb_*)
+	expand_lookup_body(d);
+}
+
 
 // Sharded mode: incoming child slots.  The receive buffer is `world` blocks of {32-byte header, K records of 32 B,
 // K shortcut offers of 16 B}; batch position c = src * K + pos keeps arrival order (grouped by sending rank, each group
@@ -314,8 +326,7 @@ __device__ __forceinline__ bool shard_valid(const uint8_t *buf, int K, int c)
 // workgroups writing 2 MB).  Rows past n_new are left untouched.  ELEM_BYTES = 0: no encoding at all, the rows are the
 // 20-byte states themselves (for a net whose first layer reads states: rk_ohl_forward, librubiks_amd/oh_linear.py).
 template <int ELEM_BYTES, bool SHARDED>
-__global__ __launch_bounds__(256)
-void k_new_rows(AstarDev d, u32x4 *out, uint32_t one_bits, const uint8_t *recv)
+__device__ __forceinline__ void new_rows_body(const AstarDev &d, u32x4 *out, uint32_t one_bits, const uint8_t *recv)
 {
 	// relaxation case 1, write half (agents.py:357-359): first-seen children that found a shorter way to an old node.
 	// It only needs the append kernel's results and touches old nodes, so it rides here, off the critical path after the
@@ -364,6 +375,22 @@ void k_new_rows(AstarDev d, u32x4 *out, uint32_t one_bits, const uint8_t *recv)
 		out[q] = val;
 	}
 }
+template <int ELEM_BYTES, bool SHARDED>
+__global__ __launch_bounds__(256)
+void k_new_rows(AstarDev d, u32x4 *out, uint32_t one_bits, const uint8_t *recv)
+{
+	new_rows_body<ELEM_BYTES, SHARDED>(d, out, one_bits, recv);
+}
+template <int ELEM_BYTES, bool SHARDED>
+__global__ __launch_bounds__(256)
+void kb_new_rows(const AstarDev *__restrict__ devs, u32x4 *out, uint32_t one_bits, const uint8_t *recv)
+{
+	const AstarDev d = devs[blockIdx.y];              // search blockIdx.y of the batch (rk_astarb_*)
+	// this search's K rows of the shared net batch: 480 elements (30 * ELEM_BYTES 16-byte chunks) or 20 bytes (K = 12 N: 15 N chunks) each
+	if (out != nullptr) out += (size_t)blockIdx.y * (ELEM_BYTES == 0 ? (size_t)d.K * 5 / 4 : (size_t)d.K * 30 * ELEM_BYTES);
+	new_rows_body<ELEM_BYTES, SHARDED>(d, out, one_bits, recv);
+}
+
 
 __global__ __launch_bounds__(256)
 void k_shard_lookup(AstarDev d, const uint8_t *recv)
@@ -378,8 +405,7 @@ void k_shard_lookup(AstarDev d, const uint8_t *recv)
 // flags + order-preserving compaction (tickets + look-back) + append + goal test + relaxation case 1 (read half).
 // SHARDED = false: child c belongs to popped node c/12, action c%12.   SHARDED = true: child slots of the receive buffer.
 template <bool SHARDED>
-__global__ __launch_bounds__(ASCAN)
-void k_append(AstarDev d, const uint8_t *recv)
+__device__ __forceinline__ void append_body(const AstarDev &d, const uint8_t *recv)
 {
 	__shared__ int s_wave[4];
 	__shared__ int s_ticket, s_base;
@@ -440,6 +466,20 @@ void k_append(AstarDev d, const uint8_t *recv)
 		d.newway[c] = nw;
 	}
 }
+template <bool SHARDED>
+__global__ __launch_bounds__(ASCAN)
+void k_append(AstarDev d, const uint8_t *recv)
+{
+	append_body<SHARDED>(d, recv);
+}
+template <bool SHARDED>
+__global__ __launch_bounds__(ASCAN)
+void kb_append(const AstarDev *__restrict__ devs, const uint8_t *recv)
+{
+	const AstarDev d = devs[blockIdx.y];              // search blockIdx.y of the batch (rk_astarb_*)
+	append_body<SHARDED>(d, recv);
+}
+
 
 // cost record of new state j: cost = lambda * G + (-value), float64, no fused multiply-add (agents.py:380-383).
 // Padding records carry distinct maximal keys.
@@ -464,8 +504,7 @@ __device__ __forceinline__ Rec cost_record(const AstarDev &d, const float *value
 // A bitonic network over the same chunk needs 66 barrier steps (36 for 256 records), each moving every record through
 // LDS twice: 27.2 us per 2048-record chunk against 16.6 us for this one (9.6 against 8.6 us for 256 records).
 template <int CHUNK>
-__global__ __launch_bounds__(CHUNK / 2)
-void k_records_sort(AstarDev d, const float *values)
+__device__ __forceinline__ void records_sort_body(const AstarDev &d, const float *values)
 {
 	__shared__ Rec s[CHUNK];
 	constexpr int T = CHUNK / 2;
@@ -517,9 +556,24 @@ void k_records_sort(AstarDev d, const float *values)
 	d.rec0[base + tid] = s[tid];
 	d.rec0[base + tid + T] = s[tid + T];
 }
+template <int CHUNK>
+__global__ __launch_bounds__(CHUNK / 2)
+void k_records_sort(AstarDev d, const float *values)
+{
+	records_sort_body<CHUNK>(d, values);
+}
+template <int CHUNK>
+__global__ __launch_bounds__(CHUNK / 2)
+void kb_records_sort(const AstarDev *__restrict__ devs, const float *values)
+{
+	const AstarDev d = devs[blockIdx.y];              // search blockIdx.y of the batch (rk_astarb_*)
+	values = reinterpret_cast<const float *>(reinterpret_cast<const char *>(values) + (size_t)blockIdx.y * d.K * (d.values_bf16 ? 2 : 4));
+	records_sort_body<CHUNK>(d, values);
+}
+
 
 // merge neighbouring sorted runs of length L over the padded new-record array (all records distinct)
-__global__ void k_merge_pass(AstarDev d, int L, int from)
+__device__ __forceinline__ void merge_pass_body(const AstarDev &d, int L, int from)
 {
 	const int e = blockIdx.x * blockDim.x + threadIdx.x;
 	const int n_new = d.ctr[C_NNEW];
@@ -535,6 +589,16 @@ __global__ void k_merge_pass(AstarDev d, int L, int from)
 	const Rec x = src[e];
 	dst[base + i + lower_bound_rec(src + pstart, plen, x)] = x;
 }
+__global__ void k_merge_pass(AstarDev d, int L, int from)
+{
+	merge_pass_body(d, L, from);
+}
+__global__ void kb_merge_pass(const AstarDev *__restrict__ devs, int L, int from)
+{
+	const AstarDev d = devs[blockIdx.y];              // search blockIdx.y of the batch (rk_astarb_*)
+	merge_pass_body(d, L, from);
+}
+
 
 // push (agents.py:316-317): multi-way rank merge of the sorted new records with queue levels 0..t into level t's
 // other buffer; read half of relaxation case 2 (agents.py:362), which also clears the marks this batch set.
@@ -547,8 +611,7 @@ constexpr int POOL_RECS = SORT_CHUNK + 3 * SAMPLES;                     // 45 05
 constexpr int MAX_SAMPLED = POOL_RECS / SAMPLES;
 
 template <bool SHARDED>
-__global__ __launch_bounds__(256)
-void k_queue_insert(AstarDev d, int new_in_rec1)
+__device__ __forceinline__ void queue_insert_body(const AstarDev &d, int new_in_rec1)
 {
 	__shared__ MergePlan s_plan;
 	__shared__ Rec s_pool[POOL_RECS];
@@ -627,13 +690,26 @@ void k_queue_insert(AstarDev d, int new_in_rec1)
 		d.shortcut[c] = sc;
 	}
 }
+template <bool SHARDED>
+__global__ __launch_bounds__(256)
+void k_queue_insert(AstarDev d, int new_in_rec1)
+{
+	queue_insert_body<SHARDED>(d, new_in_rec1);
+}
+template <bool SHARDED>
+__global__ __launch_bounds__(256)
+void kb_queue_insert(const AstarDev *__restrict__ devs, int new_in_rec1)
+{
+	const AstarDev d = devs[blockIdx.y];              // search blockIdx.y of the batch (rk_astarb_*)
+	queue_insert_body<SHARDED>(d, new_in_rec1);
+}
+
 
 // End of an iteration, one workgroup: write half of relaxation case 2 (agents.py:365-367: one thread per expanded
 // parent walks its 12 children in order, so the last shortcut child in batch order wins, as NumPy's fancy assignment
 // with repeated indices does); queue bookkeeping; loop guard of the next iteration (agents.py:236); next pop list.
 template <bool SHARDED>
-__global__ __launch_bounds__(1024)
-void k_end(AstarDev d, int new_in_rec1, int count_iteration)
+__device__ __forceinline__ void end_body(const AstarDev &d, int new_in_rec1, int count_iteration)
 {
 	__shared__ int32_t s_meta[4 * QL], s_old[4 * QL], s_ctr[C_COUNT];
 	__shared__ int s_ncand, s_nexp;
@@ -711,6 +787,20 @@ void k_end(AstarDev d, int new_in_rec1, int count_iteration)
 		for (int i = tid; i < d.N; i += blockDim.x) g[8 + i] = i < s_ncand ? key_to_double(d.cand_key[i]) : INFINITY;
 	}
 }
+template <bool SHARDED>
+__global__ __launch_bounds__(1024)
+void k_end(AstarDev d, int new_in_rec1, int count_iteration)
+{
+	end_body<SHARDED>(d, new_in_rec1, count_iteration);
+}
+template <bool SHARDED>
+__global__ __launch_bounds__(1024)
+void kb_end(const AstarDev *__restrict__ devs, int new_in_rec1, int count_iteration)
+{
+	const AstarDev d = devs[blockIdx.y];              // search blockIdx.y of the batch (rk_astarb_*)
+	end_body<SHARDED>(d, new_in_rec1, count_iteration);
+}
+
 
 // standalone pop selection (only when the host changes the number of expansions between iterations)
 __global__ __launch_bounds__(1024)
@@ -735,14 +825,25 @@ void k_pop_select_only(AstarDev d, int n_exp)
 }
 
 // the pop selection as a grid (single-GPU engines with levels * N > POP_LDS): launched behind k_end / k_pop_select_only
-__global__ __launch_bounds__(256)
-void k_pop_wide(AstarDev d)
+__device__ __forceinline__ void pop_wide_body(const AstarDev &d)
 {
 	__shared__ int32_t s_meta[4 * QL];
 	if (threadIdx.x < 4 * QL) s_meta[threadIdx.x] = d.q.meta[threadIdx.x];
 	__syncthreads();
 	pop_select(d, s_meta, d.ctr[C_NCAND], d.ctr[C_NEXP], nullptr, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
+__global__ __launch_bounds__(256)
+void k_pop_wide(AstarDev d)
+{
+	pop_wide_body(d);
+}
+__global__ __launch_bounds__(256)
+void kb_pop_wide(const AstarDev *__restrict__ devs)
+{
+	const AstarDev d = devs[blockIdx.y];              // search blockIdx.y of the batch (rk_astarb_*)
+	pop_wide_body(d);
+}
+
 
 __global__ void k_set_budget(AstarDev d, int budget)
 {
@@ -1544,6 +1645,185 @@ int rk_astar_shard_parent(rk_astar_t *h, long long index, long long *h_out /* [3
 	RK_HIP(hipStreamSynchronize(st));
 	h_out[0] = r; h_out[1] = p; h_out[2] = a;
 	return RK_OK;
+}
+
+// ================================================================================================================
+// Batched A*: S independent searches in lock-step (rk_astarb_*; AStarBatch in librubiks_amd/solving/agents.py).
+// Every search is a complete single-search engine (its own pool, hash table, queue and counter block: an rk_astar);
+// the batch keeps the S device descriptors in one array and launches the SAME kernels with a second grid dimension
+// (blockIdx.y = search: the kb_* wrappers above), so one iteration of all searches is the six launches of one search,
+// around one net forward on the (S * 12 N, 480) batch.  Round 1 had a separate set of batch kernels that re-merged
+// every search's whole open queue each iteration; this form inherits the log-structured queue and everything else.
+// ================================================================================================================
+struct rk_astarb {
+	int S = 0;
+	std::vector<rk_astar *> eng;
+	std::vector<uint8_t> start_solved;
+	AstarDev *devs = nullptr;                     // device copy of every engine's descriptor
+	bool ready = false, pending = false;
+};
+
+static int astarb_upload(rk_astarb *b, hipStream_t st)
+{
+	std::vector<AstarDev> host((size_t)b->S);
+	for (int s = 0; s < b->S; s++) host[(size_t)s] = b->eng[(size_t)s]->d;
+	RK_HIP(hipMemcpyAsync(b->devs, host.data(), host.size() * sizeof(AstarDev), hipMemcpyHostToDevice, st));
+	RK_HIP(hipStreamSynchronize(st));
+	return RK_OK;
+}
+
+int rk_astarb_create(rk_astarb_t **out, int n_searches, size_t capacity_per_search, int max_expansions)
+{
+	if (!out) return fail(RK_EINVAL, "rk_astarb_create: null out pointer");
+	if (n_searches < 1 || n_searches > 65535) return fail(RK_EINVAL, "rk_astarb_create: n_searches %d out of range", n_searches);
+	if (max_expansions < 1 || max_expansions > (1 << 20)) return fail(RK_EINVAL, "rk_astarb_create: max_expansions %d out of range", max_expansions);
+	if (capacity_per_search < (size_t)12 * max_expansions + 2 || capacity_per_search > 0x3FFFFFF0ull)
+		return fail(RK_EINVAL, "rk_astarb_create: capacity %zu out of range (needs at least 12 * expansions + 2)", capacity_per_search);
+	rk_astarb *b = new rk_astarb();
+	b->S = n_searches;
+	b->start_solved.assign((size_t)n_searches, 0);
+	for (int s = 0; s < n_searches; s++) {
+		rk_astar *e = nullptr;
+		const int rc = astar_create_impl(&e, capacity_per_search, max_expansions, 0, 1);
+		if (rc) { rk_astarb_destroy(b); return rc; }
+		b->eng.push_back(e);
+	}
+	if (hipMalloc((void **)&b->devs, (size_t)n_searches * sizeof(AstarDev)) != hipSuccess) {
+		rk_astarb_destroy(b);
+		return fail(RK_EHIP, "rk_astarb_create: hipMalloc failed");
+	}
+	*out = b;
+	return RK_OK;
+}
+
+int rk_astarb_destroy(rk_astarb_t *b)
+{
+	if (!b) return RK_OK;
+	for (rk_astar *e : b->eng) rk_astar_destroy(e);
+	(void)hipFree(b->devs);
+	delete b;
+	return RK_OK;
+}
+
+int rk_astarb_reset(rk_astarb_t *b, const int8_t *h_start_states, const long long *h_max_states, double lambda, void *stream)
+{
+	if (!b || !h_start_states) return fail(RK_EINVAL, "rk_astarb_reset: null argument");
+	hipStream_t st = (hipStream_t)stream;
+	uint32_t solved5[5];
+	{
+		int8_t tmp[STATE_BYTES];
+		rk_solved(RK_REPR_2024, tmp);
+		memcpy(solved5, tmp, STATE_BYTES);
+	}
+	for (int s = 0; s < b->S; s++) {
+		rk_astar *e = b->eng[(size_t)s];
+		const int8_t *start = h_start_states + (size_t)s * STATE_BYTES;
+		int rc = astar_reset_impl(e, start, lambda, 1, st);
+		if (rc) return rc;
+		b->start_solved[(size_t)s] = memcmp(start, solved5, STATE_BYTES) == 0 ? 1 : 0;      // agents.py:225: nothing to search
+		long long budget = h_max_states ? h_max_states[s] : (long long)e->cap;
+		if (b->start_solved[(size_t)s]) budget = 0;
+		rc = rk_astar_set_budget(e, budget, stream);
+		if (rc) return rc;
+	}
+	const int rc = astarb_upload(b, st);
+	if (rc) return rc;
+	b->ready = true;
+	b->pending = false;
+	return RK_OK;
+}
+
+int rk_astarb_set_values_dtype(rk_astarb_t *b, int dtype, void *stream)
+{
+	if (!b) return fail(RK_EINVAL, "rk_astarb_set_values_dtype: null handle");
+	if (dtype != RK_OH_F32 && dtype != RK_OH_BF16) return fail(RK_EINVAL, "rk_astarb_set_values_dtype: float32 or bfloat16");
+	const int flag = dtype == RK_OH_BF16 ? 1 : 0;
+	if (b->eng[0]->d.values_bf16 == flag) return RK_OK;
+	for (rk_astar *e : b->eng) e->d.values_bf16 = flag;
+	return astarb_upload(b, (hipStream_t)stream);
+}
+
+int rk_astarb_step_expand(rk_astarb_t *b, void *d_onehot, int out_dtype, void *stream)
+{
+	if (!b || !b->ready) return fail(RK_ESTATE, "rk_astarb_step_expand: reset the engine first");
+	if (b->pending) return fail(RK_ESTATE, "rk_astarb_step_expand: previous step not committed");
+	if (!d_onehot || (reinterpret_cast<uintptr_t>(d_onehot) & 15)) return fail(RK_EINVAL, "rk_astarb_step_expand: one-hot buffer must be 16-byte aligned");
+	if (out_dtype < RK_OH_F32 || out_dtype > RK_OH_STATES) return fail(RK_EINVAL, "rk_astarb_step_expand: unknown dtype %d", out_dtype);
+	hipStream_t st = (hipStream_t)stream;
+	const AstarDev &d = b->eng[0]->d;                 // shapes are the same for every search
+	const unsigned S = (unsigned)b->S;
+	hipLaunchKernelGGL(kb_expand_lookup, dim3(blocks((size_t)d.K), S), dim3(256), 0, st, b->devs);
+	hipLaunchKernelGGL((kb_append<false>), dim3(blocks((size_t)d.K, ASCAN), S), dim3(ASCAN), 0, st, b->devs, (const uint8_t *)nullptr);
+	const size_t chunks = (size_t)d.K * (out_dtype == RK_OH_F32 ? 120 : out_dtype == RK_OH_STATES ? 2 : 60);
+	const unsigned grid = std::min<unsigned>(blocks(chunks), 8192u);
+	if (out_dtype == RK_OH_F32)
+		hipLaunchKernelGGL((kb_new_rows<4, false>), dim3(grid, S), dim3(256), 0, st, b->devs, (u32x4 *)d_onehot, 0x3F800000u, (const uint8_t *)nullptr);
+	else if (out_dtype == RK_OH_STATES)
+		hipLaunchKernelGGL((kb_new_rows<0, false>), dim3(grid, S), dim3(256), 0, st, b->devs, (u32x4 *)d_onehot, 0u, (const uint8_t *)nullptr);
+	else
+		hipLaunchKernelGGL((kb_new_rows<2, false>), dim3(grid, S), dim3(256), 0, st, b->devs, (u32x4 *)d_onehot, out_dtype == RK_OH_F16 ? 0x3C00u : 0x3F80u, (const uint8_t *)nullptr);
+	RK_HIP(hipGetLastError());
+	b->pending = true;
+	return RK_OK;
+}
+
+int rk_astarb_step_commit(rk_astarb_t *b, const float *d_values, void *stream)
+{
+	if (!b || !b->pending) return fail(RK_ESTATE, "rk_astarb_step_commit: no pending step");
+	if (!d_values) return fail(RK_EINVAL, "rk_astarb_step_commit: null values");
+	hipStream_t st = (hipStream_t)stream;
+	const AstarDev &d = b->eng[0]->d;
+	const unsigned S = (unsigned)b->S;
+	int from = 0;
+	if (d.chunk == SMALL_CHUNK) {
+		hipLaunchKernelGGL((kb_records_sort<SMALL_CHUNK>), dim3(d.Kpad / SMALL_CHUNK, S), dim3(SMALL_CHUNK / 2), 0, st, b->devs, d_values);
+	} else {
+		hipLaunchKernelGGL((kb_records_sort<SORT_CHUNK>), dim3(d.Kpad / SORT_CHUNK, S), dim3(SORT_CHUNK / 2), 0, st, b->devs, d_values);
+		for (int L = SORT_CHUNK; L < d.Kpad && new_chunk_of(d.chunk, d.Kpad) == 0; L <<= 1) {
+			hipLaunchKernelGGL(kb_merge_pass, dim3(blocks(d.Kpad), S), dim3(256), 0, st, b->devs, L, from);
+			from ^= 1;
+		}
+	}
+	const unsigned grid = std::min<unsigned>(1024u, std::max<unsigned>(blocks((size_t)d.Kpad * 4), 8u));
+	hipLaunchKernelGGL((kb_queue_insert<false>), dim3(grid, S), dim3(256), 0, st, b->devs, from);
+	hipLaunchKernelGGL((kb_end<false>), dim3(1, S), dim3(1024), 0, st, b->devs, from, 1);
+	if (pop_is_wide_host(d)) hipLaunchKernelGGL(kb_pop_wide, dim3(blocks((size_t)d.q.levels * d.N), S), dim3(256), 0, st, b->devs);
+	RK_HIP(hipGetLastError());
+	b->pending = false;
+	return RK_OK;
+}
+
+int rk_astarb_status(rk_astarb_t *b, long long *h_status, void *stream)
+{
+	if (!b || !b->ready || !h_status) return fail(RK_EINVAL, "rk_astarb_status: bad argument");
+	hipStream_t st = (hipStream_t)stream;
+	std::vector<int32_t> c((size_t)b->S * C_COUNT);
+	for (int s = 0; s < b->S; s++)
+		RK_HIP(hipMemcpyAsync(c.data() + (size_t)s * C_COUNT, b->eng[(size_t)s]->d.ctr, C_COUNT * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+	RK_HIP(hipStreamSynchronize(st));
+	for (int s = 0; s < b->S; s++) {
+		const int32_t *k = c.data() + (size_t)s * C_COUNT;
+		long long *o = h_status + (size_t)s * 7;
+		const bool ss = b->start_solved[(size_t)s] != 0;
+		o[0] = ss ? 1 : k[C_DONE]; o[1] = ss ? 2 : k[C_WON]; o[2] = k[C_NSTATES]; o[3] = k[C_ITERS]; o[4] = k[C_OPEN];
+		o[5] = k[C_SOLVED]; o[6] = k[C_ERROR];
+	}
+	return RK_OK;
+}
+
+int rk_astarb_export(rk_astarb_t *b, int search, size_t first, size_t count, int8_t *h_states, double *h_G,
+                     long long *h_parents, long long *h_parent_actions, void *stream)
+{
+	if (!b || !b->ready) return fail(RK_ESTATE, "rk_astarb_export: reset the engine first");
+	if (search < 0 || search >= b->S) return fail(RK_EINVAL, "rk_astarb_export: search %d out of range", search);
+	return rk_astar_export(b->eng[(size_t)search], first, count, h_states, h_G, h_parents, h_parent_actions, stream);
+}
+
+long long rk_astarb_path(rk_astarb_t *b, int search, long long index, long long *h_actions, size_t max_len, void *stream)
+{
+	if (!b || !b->ready) return fail(RK_ESTATE, "rk_astarb_path: reset the engine first");
+	if (search < 0 || search >= b->S) return fail(RK_EINVAL, "rk_astarb_path: search %d out of range", search);
+	return rk_astar_path(b->eng[(size_t)search], index, h_actions, max_len, stream);
 }
 
 }  // extern "C"

@@ -848,10 +848,14 @@ class AStarBatch(DeepAgent):
 	Evaluator runs its games one after the other.
 	"""
 
-	def __init__(self, net, lambda_: float, expansions: int, n_searches: int, capacity: int = 200_000):
+	def __init__(self, net, lambda_: float, expansions: int, n_searches: int, capacity: int = 200_000, fused_first_layer=False):
 		super().__init__(net)
 		self.lambda_, self.expansions, self.n_searches = float(lambda_), int(expansions), int(n_searches)
 		self.capacity = max(int(capacity), 12 * self.expansions + 2)
+		self._from_states = None
+		if fused_first_layer:                              # the net's first Linear reads the new nodes' 20-byte states
+			from librubiks_amd.oh_linear import fused_net
+			self._from_states = fused_net(net, fused_first_layer)
 		self._h = None
 		self.status = None
 		self.iterations = 0
@@ -875,14 +879,22 @@ class AStarBatch(DeepAgent):
 		st = np.zeros((self.n_searches, 7), np.int64)
 		_ffi.check(_ffi.lib().rk_astarb_status(self._h, st.ctypes.data, _ffi.stream_ptr()))
 		if st[:, 6].any():
-			raise _ffi.RubiksHipError(f"batched A* engine error codes {st[:, 6].tolist()} (queue-length bound too small)")
+			raise _ffi.RubiksHipError(f"batched A* engine error codes {st[:, 6].tolist()}")
 		self.status = st
 		return st
 
 	def _step(self, oh, code):
 		lib, h = _ffi.lib(), self._h
 		_ffi.check(lib.rk_astarb_step_expand(h, oh.data_ptr(), code, _ffi.stream_ptr()))
-		values = _value_f32(self.net(oh, policy=False, value=True))
+		v = (self._from_states or self.net)(oh, policy=False, value=True)
+		v = v[-1] if isinstance(v, (list, tuple)) else v
+		if isinstance(v, torch.Tensor) and v.is_cuda and v.dtype == torch.bfloat16 and v.is_contiguous():
+			values, vcode = v.detach().reshape(-1), _ffi.OH_BF16        # a bf16 net's values go in as they are
+		else:
+			values, vcode = _value_f32(v), _ffi.OH_F32
+		if vcode != self._vcode:
+			_ffi.check(lib.rk_astarb_set_values_dtype(h, vcode, _ffi.stream_ptr()))
+			self._vcode = vcode
 		self._keep = values
 		_ffi.check(lib.rk_astarb_step_commit(h, values.data_ptr(), _ffi.stream_ptr()))
 
@@ -900,36 +912,34 @@ class AStarBatch(DeepAgent):
 		                    self.capacity).copy()
 		h, lib = self._engine(), _ffi.lib()
 		_ffi.check(lib.rk_astarb_reset(h, states.ctypes.data, budget.ctypes.data, self.lambda_, _ffi.stream_ptr()))
-		oh_dtype = _oh_dtype(self.net)
-		oh = torch.empty((S * K, 480), dtype=oh_dtype, device=gpu)
-		code = _OH_CODES[oh_dtype]
+		self._vcode = _ffi.OH_F32
+		_ffi.check(lib.rk_astarb_set_values_dtype(h, self._vcode, _ffi.stream_ptr()))
+		if self._from_states is not None:
+			oh, code = torch.from_numpy(cube.repeat_state(cube.get_solved(), S * K)).to(gpu), _ffi.OH_STATES
+		else:
+			oh_dtype = _oh_dtype(self.net)
+			oh = torch.zeros((S * K, 480), dtype=oh_dtype, device=gpu)
+			code = _OH_CODES[oh_dtype]
 		self.iterations = 0
-		graph, graph_bound = None, 0
-		longest = 1                                                     # longest queue seen at the last poll
+		graph = None
+		if use_graph:
+			side = torch.cuda.Stream()
+			side.wait_stream(torch.cuda.current_stream())
+			with torch.cuda.stream(side):
+				self._step(oh, code)                                    # a real iteration; also warms the allocator and fixes the values' dtype
+			torch.cuda.current_stream().wait_stream(side)
+			self.iterations += 1
+			graph = torch.cuda.CUDAGraph()
+			with torch.cuda.graph(graph):
+				self._step(oh, code)
 		while time.perf_counter() - t0 < time_limit:
-			bound = longest + poll * K                                  # a queue grows by at most 12 N per iteration
-			_ffi.check(lib.rk_astarb_set_merge_bound(h, bound))
-			if use_graph and (graph is None or bound > graph_bound):
-				graph_bound = min(2 * bound, self.capacity)
-				_ffi.check(lib.rk_astarb_set_merge_bound(h, graph_bound))
-				side = torch.cuda.Stream()
-				side.wait_stream(torch.cuda.current_stream())
-				with torch.cuda.stream(side):
-					self._step(oh, code)                                # a real iteration; also warms the allocator
-				torch.cuda.current_stream().wait_stream(side)
-				self.iterations += 1
-				graph = torch.cuda.CUDAGraph()
-				with torch.cuda.graph(graph):
-					self._step(oh, code)
 			for _ in range(poll):
 				if graph is not None:
 					graph.replay()
 				else:
 					self._step(oh, code)
 			self.iterations += poll
-			st = self._poll()
-			longest = int(st[:, 4].max())
-			if st[:, 0].all():
+			if self._poll()[:, 0].all():
 				break
 		return self._poll()[:, 1] != 0
 

@@ -75,7 +75,7 @@ def test_mcts_budget_and_done_trees_are_frozen():
 		assert (snap[k] == alone[k]).all(), k
 
 
-def test_astar_batch_argument_and_bound_errors():
+def test_astar_batch_argument_and_state_errors():
 	lib = _ffi.lib()
 	h = C.c_void_p()
 	assert lib.rk_astarb_create(C.byref(h), 0, 1000, 10) == -1
@@ -88,15 +88,14 @@ def test_astar_batch_argument_and_bound_errors():
 	_ffi.check(lib.rk_astarb_reset(h, starts.ctypes.data, None, 0.5, None))
 	vals = torch.zeros(240, dtype=torch.float32, device="cuda")
 	assert lib.rk_astarb_step_commit(h, vals.data_ptr(), None) == -4               # nothing pending
-	# a deliberately wrong (too small) queue bound must be reported, not silently truncate the queue
 	for it in range(8):
-		_ffi.check(lib.rk_astarb_set_merge_bound(h, 1))
 		_ffi.check(lib.rk_astarb_step_expand(h, oh.data_ptr(), 0, None))
 		assert lib.rk_astarb_step_expand(h, oh.data_ptr(), 0, None) == -4          # pending
 		_ffi.check(lib.rk_astarb_step_commit(h, vals.data_ptr(), None))
 	st = np.zeros((2, 7), np.int64)
 	_ffi.check(lib.rk_astarb_status(h, st.ctypes.data, None))
-	assert st[:, 6].all() and st[:, 0].all(), st
+	assert (st[:, 3] == 8).all() and (st[:, 2] > 8 * 60).all() and not st[:, 6].any(), st     # eight iterations each, no error
+	assert lib.rk_astarb_set_values_dtype(h, 1, None) == -1 and lib.rk_astarb_export(h, 5, 1, 1, None, None, None, None, None) == -1
 	_ffi.check(lib.rk_astarb_destroy(h))
 
 
