@@ -65,29 +65,6 @@ __device__ __forceinline__ bool equal5(const uint32_t a[5], const uint32_t *p)
 	return ((a[0] ^ p[0]) | (a[1] ^ p[1]) | (a[2] ^ p[2]) | (a[3] ^ p[3]) | (a[4] ^ p[4])) == 0;
 }
 
-// ---- order-preserving compaction across many workgroups ---------------------------------------------------------
-constexpr int SCAN_BLOCK = 1024;
-
-// exclusive prefix of a 0/1 predicate inside a 1024-thread workgroup; *total = number of set predicates
-__device__ __forceinline__ int block_rank(bool pred, int *s_wave /* [16] */, int *total)
-{
-	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	const unsigned long long b = __ballot(pred);
-	const int in_wave = __popcll(b & ((1ull << lane) - 1ull));
-	__syncthreads();                                  // s_wave may still be read from a previous call
-	if (lane == 0) s_wave[wv] = __popcll(b);
-	__syncthreads();
-	int before = 0, tot = 0;
-	#pragma unroll
-	for (int w = 0; w < 16; w++) {
-		const int v = s_wave[w];
-		before += w < wv ? v : 0;
-		tot += v;
-	}
-	*total = tot;
-	return before + in_wave;
-}
-
 // ---- order-preserving compaction across workgroups in ONE launch: tickets + look-back --------------------------------
 // Every workgroup draws a ticket (so that "predecessor" means "started earlier": no deadlock whatever the dispatch
 // order), publishes its local total at once and then sums the totals of ALL its predecessors, 64 at a time with one wave
