@@ -22,12 +22,12 @@ bn = torch.nn.BatchNorm1d(H).cuda().eval()
 layer = OhLinear(lin).set_epilogue(torch.nn.ELU(), bn)
 g = torch.Generator(device="cuda")
 g.manual_seed(0)
-for n in (768, 3072, 12_000, 36_000, 120_000):
+for n in (768, 3072, 12_000, 36_000, 120_000, 337_500, 2_700_000):
 	states = cube.device.apply_sequences(torch.randint(0, 12, (20, n), device="cuda", dtype=torch.uint8, generator=g), False, True)
 	y = torch.empty((n, H), dtype=torch.bfloat16, device="cuda")
 	os.environ.pop("RK_OHL_GROUPS", None)
 	ref = layer(states).clone()
-	for groups in (0, 1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48):
+	for groups in ((0,) if os.environ.get("RK_OHL_RT") else (0, 1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48)):
 		if groups:
 			os.environ["RK_OHL_GROUPS"] = str(groups)
 		else:

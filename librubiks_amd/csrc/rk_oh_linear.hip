@@ -156,7 +156,7 @@ void k_ohl_gather(const uint32_t *__restrict__ states, const float *__restrict__
 constexpr int OHL_WROW = 976;                // bytes per LDS row of the W tile (480 bf16 + 16 B pad)
 constexpr int OHL_DROW = 144;                // bytes per LDS row of a wave's output staging (64 bf16 + 16 B pad)
 
-template <int ACT, bool AFFINE>
+template <int RT, int ACT, bool AFFINE>
 __global__ __launch_bounds__(256, 2)
 void k_ohl_mfma(const uint32_t *__restrict__ states, const uint16_t *__restrict__ wb, const float *__restrict__ bias, uint16_t *__restrict__ out,
                 size_t n, int H, size_t rows_per_group, float alpha, const float *__restrict__ scale, const float *__restrict__ shift)
@@ -185,30 +185,27 @@ void k_ohl_mfma(const uint32_t *__restrict__ states, const uint16_t *__restrict_
 	uint8_t *stage = s_d[wv];
 	const size_t r_begin = (size_t)blockIdx.y * rows_per_group;
 	const size_t r_end = r_begin + rows_per_group < n ? r_begin + rows_per_group : n;
-	// A wave multiplies TWO 32-row tiles per pass (rows m0 .. m0+63): the B fragments it reads from LDS serve both (the
-	// LDS pipe, at 78 % busy with one tile per pass, was co-limiting with the matrix pipe) and four independent
-	// accumulator chains keep the MFMAs issuing back to back.  The states of the NEXT pass are requested before the current
-	// one is multiplied: with two waves per SIMD nothing else would hide that load latency.
-	uint32_t nxt[2][5] = {{0u, 0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u, 0u}};
+	// A wave multiplies RT 32-row tiles per pass (rows m0 .. m0 + 32 RT - 1): the B fragments it reads from LDS serve all
+	// of them (per k-step RT + 2 LDS reads feed 2 RT MFMAs; with one tile per pass the LDS pipe was co-limiting with the
+	// matrix pipe) and 2 RT independent accumulator chains keep the MFMAs issuing back to back.  The states of the NEXT pass
+	// are requested as soon as the multiplication is done with the current ones, so they land during the epilogue.
+	uint32_t s5[RT][5];
 	auto request = [&](size_t m0) {
 		#pragma unroll
-		for (int t = 0; t < 2; t++) {
+		for (int t = 0; t < RT; t++) {
 			const size_t row = m0 + 32 * t + r < r_end ? m0 + 32 * t + r : r_end - 1;       // tail rows repeat the last row (never stored)
 			#pragma unroll
-			for (int j = 0; j < 5; j++) nxt[t][j] = states[row * 5 + j];
+			for (int j = 0; j < 5; j++) s5[t][j] = states[row * 5 + j];
 		}
 	};
-	if (r_begin + (size_t)wv * 64 < r_end) request(r_begin + (size_t)wv * 64);
-	for (size_t m0 = r_begin + (size_t)wv * 64; m0 < r_end; m0 += 256) {
-		uint32_t s5[2][5];
+	constexpr int WROWS = 32 * RT, PASS = 4 * WROWS;                     // rows per wave and per workgroup pass
+	if (r_begin + (size_t)wv * WROWS < r_end) request(r_begin + (size_t)wv * WROWS);
+	for (size_t m0 = r_begin + (size_t)wv * WROWS; m0 < r_end; m0 += PASS) {
+		f32x16 acc[RT][2];
 		#pragma unroll
-		for (int t = 0; t < 2; t++)
+		for (int t = 0; t < RT; t++)
 			#pragma unroll
-			for (int j = 0; j < 5; j++) s5[t][j] = nxt[t][j];
-		if (m0 + 256 < r_end) request(m0 + 256);
-		f32x16 acc[2][2];
-		#pragma unroll
-		for (int v = 0; v < 16; v++) { acc[0][0][v] = bias0; acc[0][1][v] = bias1; acc[1][0][v] = bias0; acc[1][1][v] = bias1; }
+			for (int v = 0; v < 16; v++) { acc[t][0][v] = bias0; acc[t][1][v] = bias1; }
 		#pragma unroll
 		for (int ks = 0; ks < OHL_K / 16; ks++) {
 			// This lane's eight one-hot columns start at 16 ks + 8 h: inside cubie (16 ks + 8 h) / 24 at offset 0, 8 or 16.
@@ -217,9 +214,9 @@ void k_ohl_mfma(const uint32_t *__restrict__ states, const uint16_t *__restrict_
 			// different banks).  Built from compares on the VALU it took ~20 operations per k-step and, with the bf16
 			// rounding of the epilogue done by hand, made the kernel VALU-bound (37 % of the MFMA rate).
 			const int k_lo = 16 * ks, k_hi = 16 * ks + 8;
-			bf16x8 A[2];
+			bf16x8 A[RT];
 			#pragma unroll
-			for (int t = 0; t < 2; t++) {
+			for (int t = 0; t < RT; t++) {
 				const uint32_t c_lo = (s5[t][(k_lo / 24) >> 2] >> (8 * ((k_lo / 24) & 3))) & 0xFFu;
 				const uint32_t c_hi = (s5[t][(k_hi / 24) >> 2] >> (8 * ((k_hi / 24) & 3))) & 0xFFu;
 				uint32_t rel = (h ? c_hi : c_lo) - off3[ks % 3];         // wraps to a huge value when the code is below the offset
@@ -228,16 +225,17 @@ void k_ohl_mfma(const uint32_t *__restrict__ states, const uint16_t *__restrict_
 			}
 			const bf16x8 B0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(wrow0 + 32 * ks));
 			const bf16x8 B1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(wrow1 + 32 * ks));
-			acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B0, acc[0][0], 0, 0, 0);
-			acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B0, acc[1][0], 0, 0, 0);
-			acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B1, acc[0][1], 0, 0, 0);
-			acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B1, acc[1][1], 0, 0, 0);
+			#pragma unroll
+			for (int t = 0; t < RT; t++) acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[t], B0, acc[t][0], 0, 0, 0);
+			#pragma unroll
+			for (int t = 0; t < RT; t++) acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[t], B1, acc[t][1], 0, 0, 0);
 		}
+		if (m0 + PASS < r_end) request(m0 + PASS);
 		// epilogue, one 32-row tile after the other through the wave's staging area: C/D element v of lane (r, h) is row
 		// (v & 3) + 8 (v >> 2) + 4 h, column r; v_cvt_pk_bf16_f32 rounds two values per instruction (nearest even), the
 		// halves go to LDS as 16-bit stores and leave as whole 128-byte rows
 		#pragma unroll
-		for (int t = 0; t < 2; t++) {
+		for (int t = 0; t < RT; t++) {
 			#pragma unroll
 			for (int v = 0; v < 16; v++) {
 				const int i = (v & 3) + 8 * (v >> 2) + 4 * h;
@@ -264,6 +262,18 @@ void k_ohl_mfma(const uint32_t *__restrict__ states, const uint16_t *__restrict_
 }  // namespace rk
 
 using namespace rk;
+
+// Two 32-row tiles per wave pass ship.  Four (0.75 instead of 1 KB of LDS reads per MFMA, 254 VGPRs, no spills) measure
+// the same at every batch size (2.7 M rows: 10.63 vs 10.54 ms): neither LDS nor registers bound the loop -- per MFMA a SIMD
+// spends 64 cycles of a 2.4 GHz clock where the instruction issues in 32, which is what hipBLASLt's best GEMMs sustain on
+// this chip too (1.2-1.4 PFLOP/s of the 2.5 PFLOP/s peak).  The variant stays in the tuning build (RK_OHL_RT=4).
+static bool ohl_rt4(size_t)
+{
+#ifdef RK_TUNING
+	if (const char *e = getenv("RK_OHL_RT")) return atoi(e) == 4;
+#endif
+	return false;
+}
 
 struct rk_ohl {
 	int H = 0;
@@ -341,7 +351,8 @@ int rk_ohl_forward(rk_ohl_t *h, const int8_t *d_states, void *d_out, int out_dty
 	hipStream_t st = (hipStream_t)stream;
 	const unsigned col_tiles = (unsigned)(h->H / OHL_TN);
 	// about one workgroup per CU (gather: 120 KB of LDS each) or two (MFMA): the weight slice is loaded once per workgroup
-	const size_t quantum = route == RK_OHL_MFMA ? 256 : OHL_GATHER_ROWS;
+	const bool wide = route == RK_OHL_MFMA && ohl_rt4(n);
+	const size_t quantum = route == RK_OHL_MFMA ? (wide ? 512 : 256) : OHL_GATHER_ROWS;
 	size_t groups = (route == RK_OHL_MFMA ? 512u : 256u) / col_tiles;
 	if (groups < 1) groups = 1;
 #ifdef RK_TUNING
@@ -359,8 +370,14 @@ int rk_ohl_forward(rk_ohl_t *h, const int8_t *d_states, void *d_out, int out_dty
 	// the epilogue is a compile-time variant: {none, ELU, ReLU} x {no affine, affine}
 	#define RK_OHL_GATHER_GO(BF, ACT, AFF) hipLaunchKernelGGL((k_ohl_gather<BF, ACT, AFF>), grid, dim3(OHL_GATHER_THREADS), 0, st, \
 		(const uint32_t *)d_states, h->wt_f32, h->bias, d_out, n, h->H, rows, alpha, scale, shift)
-	#define RK_OHL_MFMA_GO(ACT, AFF) hipLaunchKernelGGL((k_ohl_mfma<ACT, AFF>), grid, dim3(256), 0, st, \
-		(const uint32_t *)d_states, h->w_bf16, h->bias, (uint16_t *)d_out, n, h->H, rows, alpha, scale, shift)
+#ifdef RK_TUNING
+	#define RK_OHL_MFMA_WIDE(ACT, AFF) if (wide) hipLaunchKernelGGL((k_ohl_mfma<4, ACT, AFF>), grid, dim3(256), 0, st, \
+		(const uint32_t *)d_states, h->w_bf16, h->bias, (uint16_t *)d_out, n, h->H, rows, alpha, scale, shift); else
+#else
+	#define RK_OHL_MFMA_WIDE(ACT, AFF)
+#endif
+	#define RK_OHL_MFMA_GO(ACT, AFF) do { RK_OHL_MFMA_WIDE(ACT, AFF) hipLaunchKernelGGL((k_ohl_mfma<2, ACT, AFF>), grid, dim3(256), 0, st, \
+		(const uint32_t *)d_states, h->w_bf16, h->bias, (uint16_t *)d_out, n, h->H, rows, alpha, scale, shift); } while (0)
 	#define RK_OHL_BY_EPILOGUE(GO, ...) do { \
 		if (scale) { if (h->act == RK_OHL_ACT_ELU) GO(__VA_ARGS__ 1, true); else if (h->act == RK_OHL_ACT_RELU) GO(__VA_ARGS__ 2, true); else GO(__VA_ARGS__ 0, true); } \
 		else       { if (h->act == RK_OHL_ACT_ELU) GO(__VA_ARGS__ 1, false); else if (h->act == RK_OHL_ACT_RELU) GO(__VA_ARGS__ 2, false); else GO(__VA_ARGS__ 0, false); } } while (0)
@@ -372,6 +389,7 @@ int rk_ohl_forward(rk_ohl_t *h, const int8_t *d_states, void *d_out, int out_dty
 	}
 	#undef RK_OHL_BY_EPILOGUE
 	#undef RK_OHL_MFMA_GO
+	#undef RK_OHL_MFMA_WIDE
 	#undef RK_OHL_GATHER_GO
 	RK_HIP(hipGetLastError());
 	return RK_OK;
