@@ -55,3 +55,36 @@ def test_batch_equals_oracle_per_search(use_graph, n):
 			assert int(agent.status[i, 3]) == len(ref.pops), i
 		n_solved += ref_solved
 	assert n_solved >= 3
+
+
+@pytest.mark.parametrize("fused", [False, "folded"])
+def test_batch_with_a_bf16_net(fused):
+	"""The batch with a real bfloat16 net (values enter as bf16: rk_astarb_set_values_dtype; optionally the first layer reads
+	the states): not comparable bit for bit with single runs (the GEMMs see another batch shape), so the reference's
+	invariants (tests/test_agents.py:100-145) per search: budgets kept, root first, every node one move from its parent,
+	G = G[parent] + 1 at insertion or better, found paths solve the cube."""
+	from benchmarks.nets import FcSmall
+	net = FcSmall(seed=11).cuda().eval().to(torch.bfloat16)
+	S, n = 5, 30
+	starts = []
+	for i in range(S):
+		np.random.seed(900 + i)
+		starts.append(orc.scramble(2 + i, True)[0])
+	starts = np.array(starts)
+	budgets = np.array([4000 + 1000 * i for i in range(S)])
+	agent = AStarBatch(net, 0.3, n, S, capacity=int(budgets.max()), fused_first_layer=fused)
+	solved = agent.search(starts, max_states=budgets, use_graph=True, poll=4)
+	assert solved[:2].all()                                              # two and three moves from solved
+	for i in range(S):
+		states, G, parents, pact = agent.arrays_of(i)
+		m = len(states) - 1
+		assert 1 <= m <= budgets[i] and (states[1] == starts[i]).all() and G[1] == 0
+		kids = np.arange(2, m + 1)
+		moved = orc.multi_rotate(states[parents[kids]], pact[kids] // 2, 1 - pact[kids] % 2)
+		assert (moved == states[kids]).all() and (G[kids] == G[parents[kids]] + 1).all()
+		assert len({s.tobytes() for s in states[1:]}) == m
+		if solved[i]:
+			s = starts[i]
+			for a in agent.action_queue_of(i):
+				s = orc.rotate(s, a // 2, 1 - a % 2)
+			assert orc.is_solved(s)
