@@ -28,9 +28,11 @@
 //                     grid as wide as the batch; write half of relaxation case 1 (:357-359)
 //   [net forward on the fixed (12 N, 480) batch -- PyTorch]
 //   k_records_sort    cost = lambda*G + (-value) in float64 (agents.py:383); merge sort by rank in LDS, one workgroup per chunk:
-//                     runs of 256 (K <= 2048) or chunks of 2048 followed by log2(K/2048) merge passes
+//                     runs of 256 (K <= 2048) or chunks of 2048 (which k_merge_pass merges into one run only when there
+//                     are more than eight of them: K > 16 384)
 //   k_queue_insert    the multi-way rank merge described above (heappush, :316-317); read half of case 2 (:362)
 //   k_end             write half of case 2 (:365-367), queue bookkeeping, loop guard (:236), and the NEXT pop list
+//                     (with levels * N candidates beyond one workgroup's reach the list comes from k_pop_wide, a grid)
 // All shapes are fixed by N, so an iteration can be captured in a hipGraph and replayed; the host polls `ctr` now and
 // then (rk_astar_status).  Kernels are no-ops once `done` is set (won, out of budget, queue empty).
 //
