@@ -121,16 +121,30 @@ __device__ __forceinline__ float row_max_f(float v)
 	#undef RK_STEP
 	return v;
 }
-// first arg-max (np.argmax: the smallest index among equal maxima) of (x, a) over a row
-__device__ __forceinline__ int row_argmax_first(double x, int a)
+// Maximum over a row of 16 lanes, on the descent's critical path once per tree level: the rotated copy comes from
+// v_mov_b32_dpp with no "old" operand (every lane is written, so there is nothing to preserve: no register copies in front
+// of the DPP pair) and the maximum is the bare v_max_f64 (fmax() first canonicalises a value the compiler cannot prove
+// quiet -- one more dependent f64 instruction per step; the scores are never NaN).  3 instead of 7 instructions per step.
+template <int N> __device__ __forceinline__ double dpp_ror_d_fresh(double v)
 {
-	#define RK_STEP(N) do { const double ox = dpp_ror_d<N>(x); const int oa = dpp_ror_i<N>(a); \
-		if (ox > x || (ox == x && oa < a)) { x = ox; a = oa; } } while (0)
+	const long long b = __double_as_longlong(v);
+	const int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xFFFFFFFFll), 0x120 + N, 0xF, 0xF, false);
+	const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), 0x120 + N, 0xF, 0xF, false);
+	return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double max_f64_raw(double a, double b)
+{
+	double r;
+	asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+__device__ __forceinline__ double row_max_d(double v)
+{
+	#define RK_STEP(N) v = max_f64_raw(v, dpp_ror_d_fresh<N>(v))
 	RK_STEP(8); RK_STEP(4); RK_STEP(2); RK_STEP(1);
 	#undef RK_STEP
-	return a;
+	return v;
 }
-
 __device__ __forceinline__ void fence_wave_to_wave()
 {
 	// later loads of this wave (other lanes) must see earlier stores of this wave
@@ -371,7 +385,7 @@ void k_mcts_backup_select(MctsDev d, const void *probs, const void *values, int 
 		if (lane == owed_lane) { lval += d.nu; nd.L()[col] = lval; }       // agents.py:591
 		if (!expanded) break;
 		double x = -INFINITY;
-		int best_a = lane;
+		int best_a;
 		{
 			double U = d.c * pA;                                           // U = c * P * sqrt(sum N) / (1 + N), left to right
 			U = U * sqrtN;
@@ -379,7 +393,10 @@ void k_mcts_backup_select(MctsDev d, const void *probs, const void *values, int 
 			const double Q = wA - lval;
 			x = active ? U + Q : -INFINITY;
 		}
-		best_a = __builtin_amdgcn_readfirstlane(row_argmax_first(x, best_a));   // first arg-max (np.argmax), wave-uniform
+		// first arg-max (np.argmax), wave-uniform: the row's maximum by four DPP steps, then the first lane that holds it
+		// (a third of the instructions of carrying (value, index) pairs through the reduction)
+		const double mx = row_max_d(x);
+		best_a = __ffsll((long long)(__ballot(x == mx) & 0xFFFull)) - 1;
 		const int next = __builtin_amdgcn_readlane(nb, best_a);
 		if (lane == best_a) nd.L()[col] = lval + d.nu;                         // agents.py:589
 		owed_lane = best_a ^ 1;
