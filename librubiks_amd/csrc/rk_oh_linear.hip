@@ -267,6 +267,9 @@ using namespace rk;
 // the same at every batch size (2.7 M rows: 10.63 vs 10.54 ms): neither LDS nor registers bound the loop -- per MFMA a SIMD
 // spends 64 cycles of a 2.4 GHz clock where the instruction issues in 32, which is what hipBLASLt's best GEMMs sustain on
 // this chip too (1.2-1.4 PFLOP/s of the 2.5 PFLOP/s peak).  The variant stays in the tuning build (RK_OHL_RT=4).
+// Requesting the fragments of k-step ks + 1 before the MFMAs of k-step ks (scheduling barriers; the compiler puts every
+// ds_read a few instructions in front of its MFMA) does not move it either (8.64 vs 8.5-8.7 ms): with two waves per SIMD
+// the LDS latency was already covered.
 static bool ohl_rt4(size_t)
 {
 #ifdef RK_TUNING
