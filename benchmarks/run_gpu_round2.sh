@@ -39,6 +39,7 @@ rm -f $O/sharded.json
 timeout -k 10 200 python benchmarks/sharded.py --depth 14 --expansions 100 --max-states 300000 --games 2 --net stub 2>/dev/null | grep '^{' >> $O/sharded.json
 RK_BENCH_BACKEND=gloo timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 benchmarks/sharded.py --depth 14 --expansions 100 --max-states 300000 --games 2 --net stub 2>/dev/null | grep '^{' >> $O/sharded.json
 timeout -k 10 200 python benchmarks/sharded.py --depth 20 --expansions 700 --max-states 2000000 --games 2 --net fc_small_bf16 --time-limit 30 2>/dev/null | grep '^{' >> $O/sharded.json
+timeout -k 10 200 python benchmarks/sharded.py --depth 20 --expansions 700 --max-states 2000000 --games 2 --net fc_small_bf16 --fused folded --time-limit 30 2>/dev/null | grep '^{' >> $O/sharded.json
 # configs[3] across ranks: trees partitioned (world 1, and two ranks over gloo sharing the GPU)
 timeout -k 10 300 python benchmarks/sharded.py --mcts 256 --net fc_small_bf16 --fused folded 2>/dev/null | grep '^{' >> $O/sharded.json
 RK_BENCH_BACKEND=gloo timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29535 benchmarks/sharded.py --mcts 128 --net fc_small_bf16 --fused folded 2>/dev/null | grep '^{' >> $O/sharded.json

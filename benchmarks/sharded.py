@@ -37,7 +37,7 @@ def main():
 	ap.add_argument("--mcts", type=int, default=0, help="instead of A*: configs[3] with this many trees PER RANK (weak scaling), partitioned "
 	                "over the ranks (PartitionedMCTS: no collective in the loop, one all-gather of results at the end)")
 	ap.add_argument("--sims", type=int, default=4096)
-	ap.add_argument("--fused", default="", choices=["", "epilogue", "folded"], help="--mcts: fused first layer mode")
+	ap.add_argument("--fused", default="", choices=["", "epilogue", "folded"], help="fused first layer mode of the net (not for the stub)")
 	args = ap.parse_args()
 
 	rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -92,7 +92,8 @@ def main():
 			dist.destroy_process_group()
 		return
 	cap = args.capacity or int(args.max_states / world * 1.5) + 12 * args.expansions * world + 1024
-	agent = ShardedAStar(net, args.lam, args.expansions, capacity=cap, poll=args.poll, profile=True)
+	agent = ShardedAStar(net, args.lam, args.expansions, capacity=cap, poll=args.poll, profile=True,
+	                     fused_first_layer=(args.fused or False) if args.net != "stub" else False)
 	# one-time costs (pool allocation, GEMM kernel selection, process-group warm-up) stay out of the timed games
 	np.random.seed(12345)
 	warm, _, _ = cube.scramble(args.depth, True)
@@ -119,7 +120,7 @@ def main():
 	if rank == 0:
 		it = sum(r["iterations"] for r in rows)
 		print(json.dumps({"bench": "sharded_astar summary", "config": f"configs[4]: depth-{args.depth} scrambles, lambda={args.lam}, N={args.expansions}, "
-		                  f"max_states={args.max_states}, net={args.net}, world={world}", "games": len(rows), "solved": sum(r["solved"] for r in rows),
+		                  f"max_states={args.max_states}, net={args.net}{', fused ' + args.fused if args.fused else ''}, world={world}", "games": len(rows), "solved": sum(r["solved"] for r in rows),
 		                  "states_per_s": sum(r["total_states"] for r in rows) / sum(r["seconds"] for r in rows),
 		                  "ms_per_iteration": sum(r["seconds"] for r in rows) / max(it, 1) * 1e3,
 		                  "collectives_per_iteration": rows[-1]["collectives"] / max(sum(r["iterations"] for r in rows), 1)}), flush=True)
