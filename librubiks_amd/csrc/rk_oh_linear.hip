@@ -264,9 +264,10 @@ void k_ohl_mfma(const uint32_t *__restrict__ states, const uint16_t *__restrict_
 using namespace rk;
 
 // Two 32-row tiles per wave pass ship.  Four (0.75 instead of 1 KB of LDS reads per MFMA, 254 VGPRs, no spills) measure
-// the same at every batch size (2.7 M rows: 10.63 vs 10.54 ms): neither LDS nor registers bound the loop -- per MFMA a SIMD
-// spends 64 cycles of a 2.4 GHz clock where the instruction issues in 32, which is what hipBLASLt's best GEMMs sustain on
-// this chip too (1.2-1.4 PFLOP/s of the 2.5 PFLOP/s peak).  The variant stays in the tuning build (RK_OHL_RT=4).
+// the same at every batch size (2.7 M rows: 10.63 vs 10.54 ms): neither LDS nor registers bound the loop.  PMC passes
+// (profiles/r02_oh_linear_pmc.json): the chip runs this kernel at an effective 1.82 GHz (DVFS under matrix load) and the
+// matrix pipes are busy 66 % of the elapsed cycles -- 1.26 of the 1.9 PFLOP/s available at that clock, where the guide's
+// tuned GEMM (63 %) and hipBLASLt's best GEMMs sit too.  The variant stays in the tuning build (RK_OHL_RT=4).
 // Requesting the fragments of k-step ks + 1 before the MFMAs of k-step ks (scheduling barriers; the compiler puts every
 // ds_read a few instructions in front of its MFMA) does not move it either (8.64 vs 8.5-8.7 ms): with two waves per SIMD
 // the LDS latency was already covered.
