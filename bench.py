@@ -10,10 +10,12 @@ flags.  Inputs are in HBM before the timed region; nothing is copied over PCIe i
 expands its own 1 M-state batch (independent units, no data-path collective): weak scaling, value = all ranks'
 expansions / max-over-ranks time.
 
-The timed loop is CACHE-NEUTRAL: step i reads parent set i % 4 and writes children/flag set i % 4.  Every set is
-20 MB in + 252 MB out, so 816 MB of other traffic passes between two uses of any line -- more than three times the
-256 MiB Infinity Cache -- and neither the input nor the output can be served from it (MI355X_MICROARCH.md, Infinity
-Cache residency rule).
+The timed loop is CACHE-NEUTRAL BY CONSTRUCTION: step i reads parent set i % 32 and writes children/flag set i % 4.
+The 32 parent sets are 640 MB of DISTINCT input -- more than twice the 256 MiB Infinity Cache -- so a parent line
+cannot still be cached when its set comes round again, whatever the (non-temporal) stores do or do not allocate; the
+four output sets are 1 GB, and 756 MB of other stores pass between two writes of a line (MI355X_MICROARCH.md, Infinity
+Cache residency rule).  Round 2 rotated the inputs over 4 sets only (80 MB: they could stay cache-resident if the
+non-temporal stores bypass the cache); that figure is printed once beside the new one as `kernel_ms_4_input_sets`.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
   roofline      algorithmic bytes (272 B per parent) / measured kernel time vs the 8 TB/s HBM peak; `frac` is
@@ -39,8 +41,9 @@ if ROOT not in sys.path:
 N_PARENTS = 1_000_000
 BYTES_PER_PARENT = 20 + 240 + 12          # read parent, write 12 children, write 12 solved flags
 READ_BYTES_PER_PARENT = 20
-N_SETS = 4                                # rotating buffer sets: 3 x 272 MB pass between two uses of a set (> 2 x 256 MiB)
-KERNEL = "rk::k_expand12<true, 1, true, 4, true, 1>"       # the instantiation launch_expand12 picks at 1 M parents
+N_IN_SETS = 32                            # rotating parent sets: 32 x 20 MB = 640 MB of distinct input (> 2 x 256 MiB)
+N_OUT_SETS = 4                            # rotating children/flag sets: 3 x 252 MB pass between two writes of a line
+KERNEL = "rk::k_expand12r<true, 2, true, false>"           # the instantiation launch_expand12 picks at 1 M parents
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8.0 TB/s spec (about 6.3 TB/s achievable)
 
 
@@ -122,7 +125,7 @@ def cpu_baseline(sample: int = 1_000_000, numpy_reps: int = 5, native_reps: int 
 	}
 
 
-PMC_FILE = os.path.join("profiles", "r02_expand12_pmc.json")
+PMC_FILE = os.path.join("profiles", "r03_expand12_pmc.json")
 
 
 def pmc_traffic():
@@ -182,18 +185,20 @@ def main():
 	from librubiks_amd import _ffi, cube
 	_ffi.check(_ffi.lib().rk_init(device_index))
 
-	sets = []
-	for k in range(N_SETS):
-		sets.append((make_parents(N_PARENTS, seed=1000 + 16 * rank + k),
-		             torch.empty((12 * N_PARENTS, 20), dtype=torch.int8, device="cuda"),
-		             torch.empty(12 * N_PARENTS, dtype=torch.uint8, device="cuda")))
+	ins = [make_parents(N_PARENTS, seed=1000 + 64 * rank + k) for k in range(N_IN_SETS)]
+	outs = [(torch.empty((12 * N_PARENTS, 20), dtype=torch.int8, device="cuda"),
+	         torch.empty(12 * N_PARENTS, dtype=torch.uint8, device="cuda")) for _ in range(N_OUT_SETS)]
 	stats = torch.tensor([0, _ffi.INT64_MAX], dtype=torch.int64, device="cuda")
 	counter = [0]
+	last_in = {}                               # output set -> parent set last expanded into it (for the sanity check)
+	in_sets = [N_IN_SETS]                      # the comparison pass after the timed region narrows the rotation to round 2's 4 sets
 
 	def step():
-		parents, children, solved = sets[counter[0] % N_SETS]
+		i = counter[0]
 		counter[0] += 1
-		cube.device.expand12(parents, children, solved, stats)
+		children, solved = outs[i % N_OUT_SETS]
+		last_in[i % N_OUT_SETS] = i % in_sets[0]
+		cube.device.expand12(ins[i % in_sets[0]], children, solved, stats)
 
 	def fence():
 		if dist is not None:
@@ -215,6 +220,22 @@ def main():
 	elapsed_max = max_over_ranks(elapsed, dist, reduce_device)
 	kernel_ms = ev0.elapsed_time(ev1) / args.steps          # HIP events on the launch stream: back-to-back launches
 
+	def back_to_back(n_launches):
+		e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+		torch.cuda.synchronize()
+		e0.record()
+		for _ in range(n_launches):
+			step()
+		e1.record()
+		torch.cuda.synchronize()
+		return e0.elapsed_time(e1) / n_launches
+
+	# for the record (outside the timed region): round 2's rotation -- 4 parent sets = 80 MB, which the Infinity Cache could hold
+	in_sets[0] = 4
+	back_to_back(8)
+	kernel_ms_4in = back_to_back(max(40, min(args.steps, 300)))
+	in_sets[0] = N_IN_SETS
+
 	# per-launch distribution (outside the timed region): one event pair per launch, same rotation
 	per = []
 	evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(args.steps, 200))]
@@ -225,11 +246,14 @@ def main():
 	torch.cuda.synchronize()
 	per = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
 
-	# sanity of the timed work: every set's children are a real fan-out of its parents (spot check on the device)
+	# sanity of the timed work: an output set's children are a real fan-out of the parents last expanded into it (spot check
+	# on the device, head and tail of the batch)
 	undo = torch.arange(12, dtype=torch.uint8, device="cuda").bitwise_xor(1).repeat(4096)
-	for parents, children, solved in sets:
-		probe = cube.device.multi_rotate(children[:12 * 4096].contiguous(), undo)
-		assert torch.equal(probe.view(4096, 12, 20), parents[:4096].view(4096, 1, 20).expand(4096, 12, 20))
+	for o, k in last_in.items():
+		parents, (children, solved) = ins[k], outs[o]
+		for lo in (0, N_PARENTS - 4096):
+			probe = cube.device.multi_rotate(children[12 * lo:12 * (lo + 4096)].contiguous(), undo)
+			assert torch.equal(probe.view(4096, 12, 20), parents[lo:lo + 4096].view(4096, 1, 20).expand(4096, 12, 20))
 	assert int(stats[0]) == 0 or int(stats[1]) < 12 * N_PARENTS
 
 	if rank == 0:
@@ -245,16 +269,19 @@ def main():
 			"higher_is_better": True, "scaling": "weak", "vs_baseline": None,
 			"dtype": "u8", "data": "synthetic",
 			"config": {"workload": f"configs[1]: {world}xMI355X fan-out (12 moves) + is_solved on 1M depth-20 scrambles per GPU, "
-			                       "device-resident, one rk_expand12 launch per step, inputs and outputs rotating over "
-			                       f"{N_SETS} buffer sets ({N_SETS * BYTES_PER_PARENT * N_PARENTS // 1_000_000} MB) so that nothing is served by the 256 MiB Infinity Cache",
-			           "parents_per_gpu": N_PARENTS, "children_per_step": 12 * N_PARENTS * world, "buffer_sets": N_SETS,
+			                       f"device-resident, one rk_expand12 launch per step, parents rotating over {N_IN_SETS} sets "
+			                       f"({N_IN_SETS * READ_BYTES_PER_PARENT * N_PARENTS // 1_000_000} MB of distinct input, > 2 x the 256 MiB Infinity Cache) and "
+			                       f"children/flags over {N_OUT_SETS} sets ({N_OUT_SETS * (BYTES_PER_PARENT - READ_BYTES_PER_PARENT) * N_PARENTS // 1_000_000} MB)",
+			           "parents_per_gpu": N_PARENTS, "children_per_step": 12 * N_PARENTS * world,
+			           "input_sets": N_IN_SETS, "output_sets": N_OUT_SETS,
 			           "parallelism": f"independent batches x{world}"},
 			"transitions_per_s": 12 * value,
 			"roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
 			             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_provenance": traffic_src,
 			             "achieved_read": achieved_read, "frac_read": achieved_read / HBM_PEAK_GBS,
-			             "kernel": KERNEL, "kernel_ms": kernel_ms,
-			             "kernel_ms_min": per[0], "kernel_ms_median": per[len(per) // 2], "kernel_ms_mean": sum(per) / len(per),
+			             "kernel": KERNEL, "kernel_ms_back_to_back": kernel_ms,
+			             "per_launch_event_pairs_ms": {"min": per[0], "median": per[len(per) // 2], "mean": sum(per) / len(per)},
+			             "kernel_ms_4_input_sets": kernel_ms_4in, "frac_4_input_sets": BYTES_PER_PARENT * N_PARENTS / (kernel_ms_4in * 1e-3) / 1e9 / HBM_PEAK_GBS,
 			             "algorithmic_bytes_per_launch": BYTES_PER_PARENT * N_PARENTS,
 			             "algorithmic_read_bytes_per_launch": READ_BYTES_PER_PARENT * N_PARENTS,
 			             "cache_neutral": True},

@@ -102,7 +102,7 @@ def main():
 			"WRITE_SIZE_KiB_mean": statistics.fmean(wv), "WRITE_SIZE_dispatches": len(wv),
 			"fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
 			"algorithmic_bytes_per_launch": args.algorithmic, "traffic_over_algorithmic": (fetch + write) / args.algorithmic,
-			"note": "the bench rotates inputs and outputs over 4 buffer sets (1.09 GB), so these fabric-side bytes cannot be Infinity-Cache hits of a previous launch",
+			"note": "the bench rotates the parents over 32 sets (640 MB of distinct input) and the outputs over 4 sets (1 GB), so these fabric-side bytes cannot be Infinity-Cache hits of a previous launch",
 		}
 		with open(args.out_pmc, "w") as f:
 			json.dump(rec, f, indent=1)

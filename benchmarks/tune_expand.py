@@ -41,7 +41,14 @@ NAMES = {0: "nt, tile256", 1: "plain, tile256", 3: "plain, tile64",
          70: "GEOMETRY ONLY: one 1 KiB store per wave (16-wave workgroup per 64 parents: 15 chunk waves + 1 flag wave), nt",
          71: "GEOMETRY ONLY: one 1 KiB store per wave, plain",
          42: "GEOMETRY ONLY: plain stores from registers", 43: "GEOMETRY ONLY: LDS round trip + plain stores",
-         28: "nt, tile64, 4 waves/WG, half-round staging (16 waves/CU)", 29: "nt, tile64, 4 waves/WG, half-round staging, pipelined input"}
+         28: "nt, tile64, 4 waves/WG, half-round staging (16 waves/CU)", 29: "nt, tile64, 4 waves/WG, half-round staging, pipelined input",
+         100: "RING form, depth 0 (load, wait, expand; unconditional accesses)", 101: "RING form, 1 tile of parents in flight",
+         102: "RING form, 2 tiles in flight", 104: "RING form, 4 tiles in flight", 108: "RING form, 8 tiles in flight",
+         121: "RING form, 1 tile in flight, non-temporal parent loads", 122: "RING form, 2 tiles in flight, non-temporal parent loads",
+         124: "RING form, 4 tiles in flight, non-temporal parent loads", 128: "RING form, 8 tiles in flight, non-temporal parent loads",
+         200: "READ PHASE THEN WRITE PHASE: touch <= 8 M parents (pure read stream into the Infinity Cache), then one-shot ring-0 expand of them",
+         202: "READ PHASE THEN WRITE PHASE: touch <= 8 M parents, then persistent ring-2 expand of them",
+         141: "RING form, 1 tile in flight, plain stores", 142: "RING form, 2 tiles in flight, plain stores", 144: "RING form, 4 tiles in flight, plain stores"}
 # (dropped from the code after losing clearly, results kept in profiles/r01_tune_expand*.json: atomic tile counter on a
 #  persistent grid, per-lane strided input loads)
 
@@ -55,9 +62,12 @@ def main(variants):
 	ref_c, ref_f = cube.device.expand12(parents)
 	counter = torch.zeros(4, dtype=torch.int32, device="cuda")
 	bufs = [(torch.empty_like(ref_c), torch.empty_like(ref_f)) for _ in range(6 if N <= 2_000_000 else 2)]
-	# inputs rotate too (round 2): set 0 is `parents` (checked against the shipping kernel), the others are further walks
+	# inputs rotate too.  Round 3: over MORE than twice the 256 MiB Infinity Cache of distinct parents (RK_TUNE_IN_MB, default
+	# 640 MB), so that a parent line cannot be a cache hit whatever the stores do to the cache; set 0 is `parents` (checked
+	# against the shipping kernel), the others are further walks.
+	n_in = max(2, -(-int(os.environ.get("RK_TUNE_IN_MB", "640")) * 1_000_000 // (20 * N)))
 	ins = [parents] + [cube.device.apply_sequences(torch.randint(0, 12, (20, N), device="cuda", dtype=torch.uint8, generator=g), False, True)
-	                   for _ in range(len(bufs) - 1)]
+	                   for _ in range(n_in - 1)]
 
 	def run(vg, i):
 		v, gb = vg
@@ -68,19 +78,21 @@ def main(variants):
 	for v in variants:
 		bufs[0][0].zero_(); bufs[0][1].fill_(9)
 		run(v, 0)
-		ok = bool(torch.equal(bufs[0][0], ref_c) and torch.equal(bufs[0][1], ref_f)) if v[0] < 40 else "n/a (diagnostic)"
-		res[v] = {"variant": NAMES[v[0]], "grid_blocks": v[1] or "one tile per wave", "correct": ok, "ms": []}
+		ok = bool(torch.equal(bufs[0][0], ref_c) and torch.equal(bufs[0][1], ref_f)) if (v[0] < 40 or v[0] >= 100) else "n/a (diagnostic)"
+		res[v] = {"variant": NAMES[v[0]], "id": v[0], "grid_blocks": v[1] or "default", "parents": N, "input_sets": len(ins), "output_sets": len(bufs),
+		          "correct": ok, "ms": []}
+	launches = 3 * len(ins) if N <= 2_000_000 else 12
 	for rep in range(7):
 		for v in variants:
 			for i in range(6):
 				run(v, i)
 			e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 			e0.record()
-			for i in range(42):
+			for i in range(launches):
 				run(v, i)
 			e1.record()
 			torch.cuda.synchronize()
-			res[v]["ms"].append(round(e0.elapsed_time(e1) / 42, 5))
+			res[v]["ms"].append(round(e0.elapsed_time(e1) / launches, 5))
 	for v in variants:
 		r = res[v]
 		ms = sorted(r["ms"])[len(r["ms"]) // 2]

@@ -244,7 +244,7 @@ long long rk_astarb_path(rk_astarb_t *h, int search, long long index, long long 
  *                12 N records of 32 B; 12 N shortcut offers of 16 B} -- counts travel inside the blocks
  *   rk_astar_shard_insert (d_recv)  applies the offers received (relaxation case 2 of the PREVIOUS iteration on the
  *                parents' owner), then membership / first-occurrence / append / goal test / relaxation case 1 in arrival
- *                order and the one-hot rows of the new states (world * 12 N rows at most)
+ *                order and the one-hot rows of the new states (12 N rows at most: all ranks together pop N nodes)
  *   rk_astar_shard_push  values -> cost, push; builds this iteration's offers into d_send for the next all-to-all;
  *                bookkeeping, next candidates, next all-gather contribution
  * rk_astar_shard_decision (synchronises) lets the host learn the stop decision -- every iteration or every few.
@@ -264,6 +264,10 @@ int rk_astar_shard_select(rk_astar_t *h, const void *d_gathered, double time_lim
  * index, total states, this rank's pops, iterations, this rank's states, 0}. */
 int rk_astar_shard_decision(rk_astar_t *h, long long *h_out, void *stream);
 int rk_astar_shard_insert(rk_astar_t *h, const void *d_recv, void *d_send, void *d_onehot, int out_dtype, void *stream);
+/* Between insert and push: asynchronous copy of this iteration's new-state count (<= 12 N: all ranks together pop at most N
+ * nodes) into (pinned) host memory; does not synchronise.  Lets the driver run the net on the rows that exist instead of
+ * on the whole padded batch (librubiks_amd/solving/sharded.py). */
+int rk_astar_shard_new_count(rk_astar_t *h, int *h_out, void *stream);
 int rk_astar_shard_push(rk_astar_t *h, const float *d_values, const void *d_recv, void *d_send, void *stream);
 int rk_astar_shard_flush(rk_astar_t *h, const void *d_recv, void *stream);
 int rk_astar_shard_clear_send(rk_astar_t *h, void *d_send, int records, int offers, void *stream);

@@ -87,6 +87,7 @@ SIGNATURES = {
 	"rk_astar_shard_select": (_i, [_vp, _vp, C.c_double, C.c_double, _vp, _vp]),
 	"rk_astar_shard_decision": (_i, [_vp, _vp, _vp]),
 	"rk_astar_shard_insert": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+	"rk_astar_shard_new_count": (_i, [_vp, _vp, _vp]),
 	"rk_astar_shard_push": (_i, [_vp, _vp, _vp, _vp, _vp]),
 	"rk_astar_shard_flush": (_i, [_vp, _vp, _vp]),
 	"rk_astar_shard_clear_send": (_i, [_vp, _vp, _i, _i, _vp]),

@@ -932,8 +932,10 @@ void k_shard_decide(AstarDev d, const double *gathered, double time_limit, doubl
 		if (any_err != 0.0) stop = STOP_ERROR;
 		else if (winner >= 0) stop = STOP_WON;
 		else if (gathered[5] >= time_limit) stop = STOP_TIME;
-		else if (total + (double)(12 * N) * W > max_states) stop = STOP_BUDGET;                 // agents.py:236, collectively
-		else if (biggest + (double)(12 * N) * W > (double)(d.cap1 - 1)) stop = STOP_CAPACITY;   // a rank's pool could overflow
+		// All ranks together pop at most N nodes per iteration (grank < N below), so the search as a whole -- and therefore
+		// any one rank's pool -- grows by at most 12 N states: the reference's own guard (agents.py:236), not W times it.
+		else if (total + (double)(12 * N) > max_states) stop = STOP_BUDGET;
+		else if (biggest + (double)(12 * N) > (double)(d.cap1 - 1)) stop = STOP_CAPACITY;       // a rank's pool could overflow
 		else if (cands == 0) stop = STOP_EMPTY;
 		s_stop = stop;
 		decision[D_STOP] = stop;
@@ -1596,6 +1598,16 @@ int rk_astar_shard_insert(rk_astar_t *h, const void *d_recv, void *d_send, void 
 	launch_append<true>(h, recv, d_onehot, out_dtype, st);
 	RK_HIP(hipGetLastError());
 	h->pending = true;
+	return RK_OK;
+}
+
+/* Between insert and push: start an asynchronous copy of this iteration's new-state count (an int) into host memory and
+ * return at once.  With pinned host memory the caller can enqueue the net on the first rows, wait for an event recorded
+ * behind this call and then size the rest of the net batch exactly -- the count is never larger than 12 N. */
+int rk_astar_shard_new_count(rk_astar_t *h, int *h_out, void *stream)
+{
+	if (!h || !h->pending || !h_out) return fail(RK_ESTATE, "rk_astar_shard_new_count: needs a pending insert and a host pointer");
+	RK_HIP(hipMemcpyAsync(h_out, &h->d.ctr[C_NNEW], sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
 	return RK_OK;
 }
 

@@ -16,9 +16,8 @@ namespace rk {
 //                                                                                cube.py:256-263, cube.py:88-89
 // Algorithmic HBM bytes per parent: 20 read + 240 + 12 written = 272.
 //
-// A wave owns a tile of 64 parents (one per lane; a 256-parent shape with four rounds and 16 B/lane loads is kept as a
-// template variant): coalesced loads bring the tile's 1 280 B in, the wave re-reads them one state per lane through
-// LDS (stride 5 dwords: conflict-free).  Then each lane
+// A wave owns a tile of 64 parents (one per lane): coalesced loads bring the tile's 1 280 B in, the wave re-reads them
+// one state per lane through LDS (stride 5 dwords: conflict-free).  Then each lane
 //   1. fetches, for each of its 20 cubies, the 16-byte row rows[kind][code] = that cubie's code in all 12
 //      children (20 ds_read_b128; the table is 768 B, codes differing by 16 share a bank: at most 2-way),
 //   2. turns the 20x12 byte matrix into 12 children x 5 dwords with 15 4x4 byte transposes (120 v_perm_b32),
@@ -36,6 +35,7 @@ struct ExpandWaveLdsT {
 	uint32_t flags[EXP_ROUND * 3];             // 768 B: 12 solved bytes per parent
 };
 
+#ifdef RK_TUNING   // rounds 1-2 kernel, kept in the tuning build only as the A/B reference of the ring form below
 // The kernel's shape is a set of compile-time knobs; benchmarks/tune_expand.py A/Bs them (profiles/r01_tune_expand*.json,
 // profiles/r02_tune_expand.json).  Two shapes ship (launch_expand12): <ROUNDS 1, NT, 4 waves> with one tile per wave for
 // small batches, and the same with PRELOAD on a persistent grid of 3 072 workgroups from about half a million parents on --
@@ -224,6 +224,222 @@ void k_expand12(const uint32_t *__restrict__ parents, u32x4 *__restrict__ childr
 			wave_lds_fence();
 		}
 	}
+}
+#endif  // RK_TUNING (rounds 1-2 kernel)
+
+// ================================================================================================================
+// expand12, ring form (round 3).  Same tile work as k_expand12<., 1, true, 4>, restructured around what the ISA of that
+// kernel showed: (i) its predicated loads and stores compile to one exec-branch per access and `s_waitcnt vmcnt(0)` in
+// front of every use -- a wave drains all sixteen stores of a tile before it may touch the parents of the next one --;
+// (ii) only ONE tile's parents are ever in flight per wave.  Here the main loop runs over FULL tiles only (every load
+// and store unconditional, so the compiler counts vmcnt exactly and a wave never waits for its own stores), the parents
+// of the next DEPTH tiles of the wave are in flight in registers (a ring, the loop unrolled DEPTH times so that the
+// ring index is static), and the ragged last tile takes a separate predicated path after the loop.
+// ================================================================================================================
+struct ExpandCtx {
+	const u32x4 *rows;            // LDS: 48 rows of the per-cubie table
+	u32x4       *stage;           // LDS: this wave's 15 360-byte staging area (head doubles as input staging)
+	uint32_t    *flags;           // LDS: this wave's 768 flag bytes
+	int          lane;
+};
+
+// the twelve children of the state held in par[5] (one state per lane) -> out[a*5 + j], solved bytes -> fl[3]
+template <bool WITH_FLAGS>
+__device__ __forceinline__ void expand_lane(const ExpandCtx &c, const uint32_t par[5], uint32_t out[60], uint32_t fl[3])
+{
+	#pragma unroll
+	for (int j = 0; j < 5; j++) {
+		const uint32_t x = par[j];
+		const int kind_base = (j < 2) ? 0 : 24;
+		const u32x4 r0 = c.rows[kind_base + (x & 0xFF)];
+		const u32x4 r1 = c.rows[kind_base + ((x >> 8) & 0xFF)];
+		const u32x4 r2 = c.rows[kind_base + ((x >> 16) & 0xFF)];
+		const u32x4 r3 = c.rows[kind_base + (x >> 24)];
+		transpose4x4(r0.x, r1.x, r2.x, r3.x, out[0 * 5 + j], out[1 * 5 + j], out[2 * 5 + j], out[3 * 5 + j]);
+		transpose4x4(r0.y, r1.y, r2.y, r3.y, out[4 * 5 + j], out[5 * 5 + j], out[6 * 5 + j], out[7 * 5 + j]);
+		transpose4x4(r0.z, r1.z, r2.z, r3.z, out[8 * 5 + j], out[9 * 5 + j], out[10 * 5 + j], out[11 * 5 + j]);
+	}
+	fl[0] = fl[1] = fl[2] = 0u;
+	if (WITH_FLAGS) {
+		#pragma unroll
+		for (int a = 0; a < 12; a++)
+			if (is_solved5(&out[a * 5])) fl[a >> 2] |= 1u << (8 * (a & 3));
+	}
+}
+
+template <bool WITH_FLAGS>
+__device__ __forceinline__ void report_solved(const uint32_t fl[3], bool lane_valid, size_t first_child, long long *stats)
+{
+	// solved children are rare: one ballot decides whether anybody reports
+	const bool any = (fl[0] | fl[1] | fl[2]) != 0u && lane_valid;
+	if (WITH_FLAGS && stats != nullptr && __ballot(any) != 0ull && any) {
+		const int cnt = __popc(fl[0]) + __popc(fl[1]) + __popc(fl[2]);
+		int first = 0;
+		#pragma unroll
+		for (int a = 11; a >= 0; a--)
+			if (fl[a >> 2] & (1u << (8 * (a & 3)))) first = a;
+		atomicAdd(reinterpret_cast<unsigned long long *>(&stats[0]), (unsigned long long)cnt);
+		atomicMin(&stats[1], (long long)(first_child + first));
+	}
+}
+
+// One FULL tile: raw[k] = dword k*64+lane of the tile's 1 280 bytes (already in registers).  No predicate anywhere.
+template <bool WITH_FLAGS, bool NT>
+__device__ __forceinline__ void expand_full_tile(const ExpandCtx &c, const uint32_t raw[5], size_t p0, u32x4 *__restrict__ children,
+                                                 uint32_t *__restrict__ solved, long long *__restrict__ stats)
+{
+	uint32_t *stage_dw = reinterpret_cast<uint32_t *>(c.stage);
+	#pragma unroll
+	for (int k = 0; k < 5; k++) stage_dw[k * 64 + c.lane] = raw[k];
+	wave_lds_fence();
+	uint32_t par[5];
+	#pragma unroll
+	for (int j = 0; j < 5; j++) par[j] = stage_dw[c.lane * 5 + j];
+	wave_lds_fence();
+	uint32_t out[60], fl[3];
+	expand_lane<WITH_FLAGS>(c, par, out, fl);
+	if (WITH_FLAGS) {
+		c.flags[c.lane * 3 + 0] = fl[0];
+		c.flags[c.lane * 3 + 1] = fl[1];
+		c.flags[c.lane * 3 + 2] = fl[2];
+	}
+	#pragma unroll
+	for (int v = 0; v < 15; v++)
+		c.stage[c.lane * 15 + v] = u32x4{out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]};
+	wave_lds_fence();
+	u32x4 *dst = children + p0 * 15;
+	#pragma unroll
+	for (int v = 0; v < 15; v++) {
+		const u32x4 val = c.stage[v * 64 + c.lane];
+		if (NT) __builtin_nontemporal_store(val, dst + v * 64 + c.lane);
+		else dst[v * 64 + c.lane] = val;
+	}
+	if (WITH_FLAGS) {
+		uint32_t *fdst = solved + p0 * 3;                  // p0 is a multiple of 64 -> 768-byte blocks, 16-byte aligned if the base is
+		if ((reinterpret_cast<uintptr_t>(fdst) & 15) == 0) {
+			if (c.lane < 48) {
+				const u32x4 val = reinterpret_cast<const u32x4 *>(c.flags)[c.lane];
+				if (NT) __builtin_nontemporal_store(val, reinterpret_cast<u32x4 *>(fdst) + c.lane);
+				else reinterpret_cast<u32x4 *>(fdst)[c.lane] = val;
+			}
+		} else {
+			#pragma unroll
+			for (int k = 0; k < 3; k++) fdst[k * 64 + c.lane] = c.flags[k * 64 + c.lane];
+		}
+		report_solved<WITH_FLAGS>(fl, true, (p0 + c.lane) * 12, stats);
+	}
+	wave_lds_fence();
+}
+
+// The ragged last tile (np < 64 parents): predicated, not pipelined.
+template <bool WITH_FLAGS, bool NT>
+__device__ __forceinline__ void expand_ragged_tile(const ExpandCtx &c, const uint32_t *__restrict__ parents, size_t p0, int np,
+                                                   u32x4 *__restrict__ children, uint32_t *__restrict__ solved, long long *__restrict__ stats)
+{
+	uint32_t *stage_dw = reinterpret_cast<uint32_t *>(c.stage);
+	const uint32_t *src = parents + p0 * STATE_DWORDS;
+	const int ndw = np * STATE_DWORDS;
+	#pragma unroll
+	for (int k = 0; k < 5; k++) {
+		const int idx = k * 64 + c.lane;
+		stage_dw[idx] = src[idx < ndw ? idx : ndw - 1];    // clamped: always a valid address, lanes past np are never stored
+	}
+	wave_lds_fence();
+	uint32_t par[5];
+	#pragma unroll
+	for (int j = 0; j < 5; j++) par[j] = stage_dw[c.lane * 5 + j];
+	wave_lds_fence();
+	uint32_t out[60], fl[3];
+	expand_lane<WITH_FLAGS>(c, par, out, fl);
+	if (WITH_FLAGS) {
+		c.flags[c.lane * 3 + 0] = fl[0];
+		c.flags[c.lane * 3 + 1] = fl[1];
+		c.flags[c.lane * 3 + 2] = fl[2];
+	}
+	#pragma unroll
+	for (int v = 0; v < 15; v++)
+		c.stage[c.lane * 15 + v] = u32x4{out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]};
+	wave_lds_fence();
+	u32x4 *dst = children + p0 * 15;
+	const int nvec = np * 15;
+	#pragma unroll
+	for (int v = 0; v < 15; v++) {
+		const int idx = v * 64 + c.lane;
+		if (idx < nvec) {
+			const u32x4 val = c.stage[idx];
+			if (NT) __builtin_nontemporal_store(val, dst + idx);
+			else dst[idx] = val;
+		}
+	}
+	if (WITH_FLAGS) {
+		uint32_t *fdst = solved + p0 * 3;
+		#pragma unroll
+		for (int k = 0; k < 3; k++) {
+			const int idx = k * 64 + c.lane;
+			if (idx < np * 3) fdst[idx] = c.flags[idx];
+		}
+		report_solved<WITH_FLAGS>(fl, c.lane < np, (p0 + c.lane) * 12, stats);
+	}
+	wave_lds_fence();
+}
+
+// DEPTH = tiles of parents a wave keeps in flight (0: load, wait, expand -- for batches with one tile per wave).
+// NTL = non-temporal parent loads.
+template <bool WITH_FLAGS, int DEPTH, bool NT = true, bool NTL = false>
+__global__ __launch_bounds__(EXP_WAVES * WAVE)
+void k_expand12r(const uint32_t *__restrict__ parents, u32x4 *__restrict__ children, uint32_t *__restrict__ solved,
+                 long long *__restrict__ stats, size_t n)
+{
+	__shared__ u32x4 s_rows[48];
+	__shared__ ExpandWaveLdsT<1> s_wave[EXP_WAVES];
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const size_t n_full = n / EXP_ROUND;                               // tiles without a predicate
+	const size_t stride = (size_t)gridDim.x * EXP_WAVES;
+	const size_t first = (size_t)blockIdx.x * EXP_WAVES + wv;
+	constexpr int D = DEPTH > 0 ? DEPTH : 1;
+	uint32_t ring[D][5];
+
+	auto load_tile = [&](uint32_t (&dst)[5], size_t t) {
+		const uint32_t *src = parents + t * (EXP_ROUND * STATE_DWORDS) + lane;
+		#pragma unroll
+		for (int k = 0; k < 5; k++) dst[k] = NTL ? __builtin_nontemporal_load(src + k * 64) : src[k * 64];
+	};
+
+	// the first DEPTH tiles' parents are requested before the table is staged
+	#pragma unroll
+	for (int d = 0; d < DEPTH; d++)
+		if (first + d * stride < n_full) load_tile(ring[d], first + d * stride);
+
+	if (tid < 48) {
+		const uint32_t *src = reinterpret_cast<const uint32_t *>(D_TAB.rows) + 4 * tid;
+		s_rows[tid] = u32x4{src[0], src[1], src[2], src[3]};
+	}
+	__syncthreads();
+	const ExpandCtx c{s_rows, s_wave[wv].stage, s_wave[wv].flags, lane};
+
+	if (DEPTH == 0) {
+		for (size_t t = first; t < n_full; t += stride) {
+			load_tile(ring[0], t);
+			expand_full_tile<WITH_FLAGS, NT>(c, ring[0], t * EXP_ROUND, children, solved, stats);
+		}
+	} else {
+		for (size_t base = first; base < n_full; base += (size_t)DEPTH * stride) {
+			#pragma unroll
+			for (int d = 0; d < DEPTH; d++) {
+				const size_t t = base + d * stride;
+				if (t >= n_full) break;                                   // wave-uniform
+				uint32_t raw[5];
+				#pragma unroll
+				for (int k = 0; k < 5; k++) raw[k] = ring[d][k];
+				const size_t nx = t + (size_t)DEPTH * stride;
+				if (nx < n_full) load_tile(ring[d], nx);                  // refill the slot: lands DEPTH tiles from now
+				expand_full_tile<WITH_FLAGS, NT>(c, raw, t * EXP_ROUND, children, solved, stats);
+			}
+		}
+	}
+	// ragged tail: the wave that would own tile n_full
+	if ((n % EXP_ROUND) != 0 && (n_full % stride) == first)
+		expand_ragged_tile<WITH_FLAGS, NT>(c, parents, n_full * EXP_ROUND, (int)(n % EXP_ROUND), children, solved, stats);
 }
 
 // ================================================================================================================
@@ -808,6 +1024,16 @@ void k_store_geometry(u32x4 *__restrict__ dst, size_t total_kib)
 	}
 }
 
+// Diagnostic: read `n16` 16-byte words and discard them (pulls a buffer into the Infinity Cache with a pure read stream).
+__global__ __launch_bounds__(256)
+void k_touch(const u32x4 *__restrict__ src, size_t n16)
+{
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+		const u32x4 v = src[i];
+		asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+	}
+}
+
 // tuning aid (benchmarks/tune_expand.py): the same kernel in its other shapes; grid_blocks > 0 makes the grid persistent.
 void launch_expand12_variant(int variant, const int8_t *parents, int8_t *children, uint8_t *solved, long long *stats, size_t n,
                              int grid_blocks, hipStream_t st)
@@ -871,6 +1097,42 @@ void launch_expand12_variant(int variant, const int8_t *parents, int8_t *childre
 			else hipLaunchKernelGGL((k_expand12_geometry_chunk<false>), dim3((unsigned)n_groups), dim3(1024), 0, st, (const uint32_t *)parents, (u32x4 *)children, (uint32_t *)solved, n_groups);
 			break;
 		}
+		case 100: case 101: case 102: case 104: case 108: case 121: case 122: case 124: case 128: case 141: case 142: case 144: {   // ring form
+			const size_t n_tiles = (n + EXP_ROUND - 1) / EXP_ROUND;
+			const unsigned grid = grid_blocks > 0 ? (unsigned)grid_blocks : grid_for(n_tiles, EXP_WAVES, variant == 100 ? (1u << 20) : (unsigned)EXP_GRID_PERSISTENT);
+			#define RK_RING(DP, NTS, NTL) hipLaunchKernelGGL((k_expand12r<true, DP, NTS, NTL>), dim3(grid), dim3(EXP_WAVES * WAVE), 0, st, \
+				(const uint32_t *)parents, (u32x4 *)children, (uint32_t *)solved, stats, n)
+			if (variant == 100) RK_RING(0, true, false);
+			if (variant == 101) RK_RING(1, true, false);
+			if (variant == 102) RK_RING(2, true, false);
+			if (variant == 104) RK_RING(4, true, false);
+			if (variant == 108) RK_RING(8, true, false);
+			if (variant == 121) RK_RING(1, true, true);            // non-temporal parent loads
+			if (variant == 122) RK_RING(2, true, true);
+			if (variant == 124) RK_RING(4, true, true);
+			if (variant == 128) RK_RING(8, true, true);
+			if (variant == 141) RK_RING(1, false, false);          // plain stores
+			if (variant == 142) RK_RING(2, false, false);
+			if (variant == 144) RK_RING(4, false, false);
+			#undef RK_RING
+			break;
+		}
+		case 200: case 202: {                                  // read phase then write phase: touch <= 8 M parents (160 MB), then expand them
+			const size_t chunk = (size_t)8 << 20;
+			for (size_t p0 = 0; p0 < n; p0 += chunk) {
+				const size_t m = n - p0 < chunk ? n - p0 : chunk;
+				const size_t n16 = m * STATE_BYTES / 16;
+				hipLaunchKernelGGL(k_touch, dim3(grid_for(n16, 256, 2048)), dim3(256), 0, st, (const u32x4 *)(parents + p0 * STATE_BYTES), n16);
+				const size_t n_tiles = (m + EXP_ROUND - 1) / EXP_ROUND;
+				if (variant == 200)
+					hipLaunchKernelGGL((k_expand12r<true, 0, true, false>), dim3(grid_for(n_tiles, EXP_WAVES, 1u << 20)), dim3(EXP_WAVES * WAVE), 0, st,
+					                   (const uint32_t *)(parents + p0 * STATE_BYTES), (u32x4 *)(children + p0 * 240), (uint32_t *)(solved + p0 * 12), stats, m);
+				else
+					hipLaunchKernelGGL((k_expand12r<true, 2, true, false>), dim3(grid_blocks > 0 ? grid_blocks : EXP_GRID_PERSISTENT), dim3(EXP_WAVES * WAVE), 0, st,
+					                   (const uint32_t *)(parents + p0 * STATE_BYTES), (u32x4 *)(children + p0 * 240), (uint32_t *)(solved + p0 * 12), stats, m);
+			}
+			break;
+		}
 		default: RK_LAUNCH(1, true, 4, false, 1); break;       // 16: the shipping shape
 	}
 	#undef RK_LAUNCH
@@ -878,21 +1140,31 @@ void launch_expand12_variant(int variant, const int8_t *parents, int8_t *childre
 
 #endif  // RK_TUNING
 
-// Shipping shape (benchmarks/tune_expand.py; profiles/r01_tune_expand.json, profiles/r02_tune_expand.json): 64-parent wave
-// tiles + non-temporal stores.  Measured cache-neutral in round 2 (inputs AND outputs rotating over > 1 GB, so the parents
-// come from HBM): one tile per wave 50.0 us per 1 M parents -- a wave waits a full HBM latency for its only tile with
-// nothing else to do -- against 43.5-45.3 us for a persistent grid of 2 048-3 072 workgroups (3 072 ship) whose waves issue the NEXT tile's
-// parent loads before expanding the current one (PRELOAD).  Small batches (their input is cache-resident and there
-// are not enough tiles to pipeline) keep one tile per wave.
+// Shipping shapes (benchmarks/tune_expand.py, profiles/r03_tune_sizes.json: every size measured with the parents coming
+// from HBM -- inputs rotating over >= 640 MB --, 250 k ... 32 M parents, fraction of the 8 TB/s peak, round-2 kernel first):
+//   parents      r02 kernel   one tile per wave (depth 0)   ring 2, grid = tiles/8   ring 2, 3 072 workgroups
+//   250 k        0.54         0.62                          0.63                     0.53
+//   500 k        0.62         0.65                          0.70                     0.63
+//   1 M          0.71         0.70                          0.68                     0.73
+//   2 M          0.74         0.76                          0.75                     0.75
+//   4 M / 8 M    0.74 / 0.71  0.78 / 0.78                   0.72 / 0.70              0.73 / 0.70
+//   16 M / 32 M  0.76 / 0.74  0.75 / 0.77                   0.79 / 0.74              0.78 / 0.74
+// A grid with ONE tile per wave wins wherever there are many more tiles than resident waves (2 048): fresh workgroups
+// dispatched in address order keep the write front dense.  Around 1 M parents (a handful of tiles per resident wave) a
+// persistent grid whose waves keep the next two tiles' parents in flight hides the HBM read latency that a one-tile wave
+// would wait out: 3 072 workgroups (six full residencies) at 0.75-1.5 M parents, tiles/8 workgroups below that.
 void launch_expand12(const int8_t *parents, int8_t *children, uint8_t *solved, long long *stats, size_t n, hipStream_t st)
 {
 	const size_t n_tiles = (n + EXP_ROUND - 1) / EXP_ROUND;
-	const bool persistent = n_tiles >= (size_t)8192;                   // from about half a million parents on
-	const unsigned grid = grid_for(n_tiles, EXP_WAVES, persistent ? (unsigned)EXP_GRID_PERSISTENT : 1u << 20);
-	#define RK_GO(FLAGS, PRE) hipLaunchKernelGGL((k_expand12<FLAGS, 1, true, EXP_WAVES, PRE>), dim3(grid), dim3(EXP_WAVES * WAVE), 0, st, \
-		(const uint32_t *)parents, (u32x4 *)children, (uint32_t *)(FLAGS ? solved : nullptr), FLAGS ? stats : (long long *)nullptr, n, n_tiles)
-	if (solved != nullptr) { if (persistent) RK_GO(true, true); else RK_GO(true, false); }
-	else                   { if (persistent) RK_GO(false, true); else RK_GO(false, false); }
+	const bool ring = n_tiles >= 3000 && n_tiles < 24000;
+	unsigned grid;
+	if (!ring) grid = grid_for(n_tiles, EXP_WAVES, 1u << 22);
+	else if (n_tiles >= 12000) grid = (unsigned)EXP_GRID_PERSISTENT;
+	else grid = (unsigned)(n_tiles / 8);
+	#define RK_GO(FLAGS, DEPTH) hipLaunchKernelGGL((k_expand12r<FLAGS, DEPTH, true, false>), dim3(grid), dim3(EXP_WAVES * WAVE), 0, st, \
+		(const uint32_t *)parents, (u32x4 *)children, (uint32_t *)(FLAGS ? solved : nullptr), FLAGS ? stats : (long long *)nullptr, n)
+	if (solved != nullptr) { if (ring) RK_GO(true, 2); else RK_GO(true, 0); }
+	else                   { if (ring) RK_GO(false, 2); else RK_GO(false, 0); }
 	#undef RK_GO
 }
 

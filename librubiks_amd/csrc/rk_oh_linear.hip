@@ -39,11 +39,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ uint32_t f32_to_bf16_rne(float x)
+// f32 -> bf16, nearest even, by the hardware convert (v_cvt_pk_bf16_f32): a NaN stays a NaN.  Integer rounding on the f32
+// bits -- (u + 0x7FFF + ((u >> 16) & 1)) >> 16, what this file did until round 3 -- turns some NaNs into zeros or
+// infinities (MI355X_MICROARCH.md, correctness boundaries), which would hide a diverged net from whoever reads the layer's output.
+__device__ __forceinline__ uint32_t f32_pair_to_bf16(float lo, float hi)
 {
-	uint32_t u = __builtin_bit_cast(uint32_t, x);
-	u += 0x7FFFu + ((u >> 16) & 1u);
-	return u >> 16;
+	const f32x2 pair = {lo, hi};
+	return __builtin_bit_cast(uint32_t, __builtin_convertvector(pair, bf16x2));
+}
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float x)
+{
+	return (uint16_t)(f32_pair_to_bf16(x, 0.0f) & 0xFFFFu);
 }
 
 // weight preparation: W (H, 480) in f32 or bf16 -> W^T (480, H) f32 and W (H, 480) bf16
@@ -56,7 +62,7 @@ __global__ void k_ohl_prepare(const void *w, int w_is_bf16, int H, float *wt_f32
 	if (w_is_bf16) v = __builtin_bit_cast(float, (uint32_t)reinterpret_cast<const uint16_t *>(w)[i] << 16);
 	else v = reinterpret_cast<const float *>(w)[i];
 	wt_f32[k * (size_t)H + h] = v;
-	w_bf16[i] = (uint16_t)f32_to_bf16_rne(v);
+	w_bf16[i] = f32_to_bf16_rne(v);
 }
 
 __global__ void k_ohl_bias(const void *b, int b_is_bf16, int H, float *out)
@@ -143,8 +149,8 @@ void k_ohl_gather(const uint32_t *__restrict__ states, const float *__restrict__
 		}
 		if (OUT_BF16) {
 			u32x2 v;
-			v.x = f32_to_bf16_rne(acc.x) | (f32_to_bf16_rne(acc.y) << 16);
-			v.y = f32_to_bf16_rne(acc.z) | (f32_to_bf16_rne(acc.w) << 16);
+			v.x = f32_pair_to_bf16(acc.x, acc.y);
+			v.y = f32_pair_to_bf16(acc.z, acc.w);
 			*reinterpret_cast<u32x2 *>(reinterpret_cast<uint16_t *>(out) + r * (size_t)H + c0 + 4 * q) = v;
 		} else {
 			*reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(out) + r * (size_t)H + c0 + 4 * q) = acc;

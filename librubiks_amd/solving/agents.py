@@ -60,10 +60,55 @@ class Agent:
 		return self._explored_states
 
 
+def _net_signature(net):
+	"""Changes whenever the net is swapped or its parameters / buffers are modified in place (optimizer steps,
+	load_state_dict, BatchNorm statistics): module identity + training flag + the tensors' storage and version counters."""
+	sig = [id(net), bool(getattr(net, "training", False))]
+	for get in ("parameters", "buffers"):
+		it = getattr(net, get, None)
+		if callable(it):
+			for t in it():
+				sig.append((t.data_ptr(), t._version))
+	return tuple(sig)
+
+
 class DeepAgent(Agent):
-	def __init__(self, net):
+	"""
+	An agent with a value/policy net.  `fused_first_layer` (False, True, "epilogue", "folded"; librubiks_amd.oh_linear)
+	makes the net's first Linear(480, H) read the engine's 20-byte states; that form COPIES weights (and, folded, BatchNorm
+	statistics and the merged heads), while the reference trains its net in place and reassigns `agent.net` during
+	training (train.py:134, :214).  So the copy is never trusted blindly: `_from_states` -- read at the start of every
+	search -- rebuilds it whenever the net's signature (module identity, training flag, every parameter's and buffer's
+	storage and in-place version counter) differs from the one the copy was taken at.
+	"""
+	def __init__(self, net, fused_first_layer=False):
 		super().__init__()
+		if fused_first_layer not in (False, None, True, "epilogue", "folded"):
+			raise ValueError('fused_first_layer is False, True, "epilogue" or "folded"')
+		self._fused_mode = fused_first_layer or False
+		self._fused, self._fused_sig = None, None
+		self._fs = None                    # `_from_states` as checked at the start of the running search (hot loops use this)
 		self.net = net
+
+	@property
+	def net(self):
+		return self._net
+
+	@net.setter
+	def net(self, net):
+		self._net = net                    # the signature holds the module's identity: a swapped net is re-copied at the next search
+
+	@property
+	def _from_states(self):
+		"""callable(states (n, 20) int8, policy, value) equal to net(as_oh(states), policy, value), or None when not fused."""
+		if not self._fused_mode:
+			return None
+		self._net.eval()
+		sig = _net_signature(self._net)
+		if self._fused is None or sig != self._fused_sig:
+			from librubiks_amd.oh_linear import fused_net
+			self._fused, self._fused_sig = fused_net(self._net, self._fused_mode), sig
+		return self._fused
 
 	@classmethod
 	def from_saved(cls, loc: str, use_best: bool, loader=None):
@@ -299,14 +344,10 @@ class AStar(DeepAgent):
 
 	def __init__(self, net, lambda_: float, expansions: int, capacity: int = None, poll: int = 4, use_hipgraph: bool = False,
 	             fused_first_layer=False, exact_batch: bool = None):
-		super().__init__(net)
-		self.exact_batch = exact_batch
 		# fused_first_layer: the engine hands the net the new nodes' 20-byte states and the net's first Linear(480, H)
-		# reads them directly (librubiks_amd.oh_linear) -- no one-hot batch exists at all
-		self._from_states = None
-		if fused_first_layer:
-			from librubiks_amd.oh_linear import fused_net
-			self._from_states = fused_net(net, fused_first_layer)
+		# reads them directly (librubiks_amd.oh_linear) -- no one-hot batch exists at all (DeepAgent keeps the copy fresh)
+		super().__init__(net, fused_first_layer)
+		self.exact_batch = exact_batch
 		self.lambda_ = lambda_
 		self.expansions = int(expansions)
 		self.capacity = capacity
@@ -357,7 +398,7 @@ class AStar(DeepAgent):
 	def _iteration(self, h, oh, code):
 		lib = _ffi.lib()
 		_ffi.check(lib.rk_astar_step_expand(h, oh.data_ptr(), code, _ffi.stream_ptr()))
-		values = _values_for_engine(h, (self._from_states or self.net)(oh, policy=False, value=True))
+		values = _values_for_engine(h, (self._fs or self.net)(oh, policy=False, value=True))
 		self._keep = values                # the commit kernels read it after this call returns
 		_ffi.check(lib.rk_astar_step_commit(h, values.data_ptr(), _ffi.stream_ptr()))
 
@@ -372,7 +413,8 @@ class AStar(DeepAgent):
 		K = 12 * self.expansions
 		cap = max(int(min(max_states, self.capacity or self.default_capacity)), K + 2)
 		lib = _ffi.lib()
-		if self._from_states is not None:
+		self._fs = self._from_states           # re-copied here if the net changed since the last search
+		if self._fs is not None:
 			oh, code = torch.from_numpy(cube.repeat_state(cube.get_solved(), K)).to(gpu), _ffi.OH_STATES      # (K, 20) int8: valid codes everywhere
 		else:
 			oh_dtype = _oh_dtype(self.net)
@@ -414,7 +456,7 @@ class AStar(DeepAgent):
 				values = None
 				if n_new:
 					_ffi.check(lib.rk_astar_new_states_oh(h, oh.data_ptr(), code, _ffi.stream_ptr()))
-					values = _values_for_engine(h, (self._from_states or self.net)(oh[:n_new], policy=False, value=True))
+					values = _values_for_engine(h, (self._fs or self.net)(oh[:n_new], policy=False, value=True))
 				_ffi.check(lib.rk_astar_commit(h, values.data_ptr() if values is not None else None, _ffi.stream_ptr()))
 				if time.perf_counter() - t0 >= time_limit:
 					break
@@ -549,13 +591,15 @@ class MCTSBatch(DeepAgent):
 	"""
 
 	def __init__(self, net, c: float, n_trees: int, capacity: int = 50_000, max_path: int = None, nu: float = 100.0,
-	             fused_first_layer=False):
-		super().__init__(net)
+	             fused_first_layer=False, torch_softmax: bool = False):
 		# fused_first_layer: the net's first Linear(480, H) reads the children's 20-byte states (librubiks_amd.oh_linear)
-		self._from_states = None
-		if fused_first_layer:
-			from librubiks_amd.oh_linear import fused_net
-			self._from_states = fused_net(net, fused_first_layer)
+		super().__init__(net, fused_first_layer)
+		# The priors are softmax(logits) (agents.py:551-552).  By default the backup kernel computes it itself from the net's
+		# raw float32 / bfloat16 logits (exp(x - max) / sum in float32: two kernels and a copy fewer per simulation); that
+		# agrees with torch.softmax to the last float32 bits but is not bit-identical to it on arbitrary logits
+		# (tests/test_mcts_gpu.py states the bound), and a one-ulp difference in P can flip an arg-max tie of U + Q.
+		# torch_softmax=True makes the priors torch's own softmax on this device, as the reference computes them.
+		self.torch_softmax = bool(torch_softmax)
 		self.c, self.nu, self.n_trees = float(c), float(nu), int(n_trees)
 		self.capacity = int(capacity)
 		self.max_path = int(max_path or max(4096, 2 * self.capacity))
@@ -595,14 +639,14 @@ class MCTSBatch(DeepAgent):
 	def _step(self, oh, h):
 		lib = _ffi.lib()
 		_ffi.check(lib.rk_mcts_expand(h, _ffi.stream_ptr()))
-		if self._from_states is not None:
+		if self._fs is not None:
 			# the first layer reads the children where the engine keeps them; no one-hot, no copy
-			x = self._from_states.first.from_pointer(lib.rk_mcts_children(h), 12 * self.n_trees)
-			p, v = self._from_states.tail(x)
+			x = self._fs.first.from_pointer(lib.rk_mcts_children(h), 12 * self.n_trees)
+			p, v = self._fs.tail(x)
 		else:
 			_ffi.check(lib.rk_mcts_children_oh(h, oh.data_ptr(), _OH_CODES[oh.dtype], _ffi.stream_ptr()))
 			p, v = self.net(oh)
-		if isinstance(p, torch.Tensor) and p.is_cuda and p.dtype == v.dtype and p.dtype in (torch.float32, torch.bfloat16) \
+		if not self.torch_softmax and isinstance(p, torch.Tensor) and p.is_cuda and p.dtype == v.dtype and p.dtype in (torch.float32, torch.bfloat16) \
 		   and p.dim() == 2 and p.stride(1) == 1 and p.stride(0) >= 12 and v.numel() == len(p) and v.reshape(len(p), -1).stride(0) >= 1:
 			# raw logits and values in the net's dtype (rows may be views into one tensor of merged heads): the softmax
 			# (agents.py:551) runs inside the backup kernel
@@ -629,10 +673,11 @@ class MCTSBatch(DeepAgent):
 		ms = np.minimum(np.broadcast_to(np.asarray(max_states, dtype=np.int64), (self.n_trees,)), self.capacity).copy()
 		h, lib = self._engine(), _ffi.lib()
 		_ffi.check(lib.rk_mcts_reset(h, states.ctypes.data, ms.ctypes.data, self.c, self.nu, _ffi.stream_ptr()))
-		if self._from_states is not None:
+		self._fs = self._from_states           # re-copied here if the net changed since the last search
+		if self._fs is not None:
 			root_oh = torch.empty((self.n_trees, 20), dtype=torch.int8, device=gpu)
 			_ffi.check(lib.rk_mcts_roots_oh(h, root_oh.data_ptr(), _ffi.OH_STATES, _ffi.stream_ptr()))
-			p, v = _policy_value_f32(self._from_states(root_oh))
+			p, v = _policy_value_f32(self._fs(root_oh))
 			oh = torch.from_numpy(cube.repeat_state(cube.get_solved(), 12 * self.n_trees)).to(gpu)
 		else:
 			oh_dtype = _oh_dtype(self.net)
@@ -711,8 +756,9 @@ class MCTS(DeepAgent):
 	default_capacity = 200_000
 	max_capacity = 25_000_000           # 461 B per node: 11.5 GB
 
-	def __init__(self, net, c: float, search_graph: bool, capacity: int = None, use_hipgraph: bool = False):
+	def __init__(self, net, c: float, search_graph: bool, capacity: int = None, use_hipgraph: bool = False, torch_softmax: bool = False):
 		super().__init__(net)
+		self.torch_softmax = torch_softmax        # priors by torch.softmax instead of the backup kernel's own (see MCTSBatch)
 		self.c = c
 		self.search_graph = search_graph
 		self.nu = 100
@@ -735,7 +781,7 @@ class MCTS(DeepAgent):
 		cap = int(min(max_states, self.capacity or self.default_capacity))
 		while True:
 			if self._batch is None or self._batch.capacity != cap or self._batch.c != float(self.c):
-				self._batch = MCTSBatch(self.net, self.c, 1, capacity=cap, nu=self.nu)
+				self._batch = MCTSBatch(self.net, self.c, 1, capacity=cap, nu=self.nu, torch_softmax=self.torch_softmax)
 			self._batch.net = self.net
 			left = time_limit - (time.perf_counter() - t0)
 			solved = bool(self._batch.search(np.asarray(state)[None], time_limit=max(left, 1e-3), max_states=cap, poll=8,
@@ -849,13 +895,9 @@ class AStarBatch(DeepAgent):
 	"""
 
 	def __init__(self, net, lambda_: float, expansions: int, n_searches: int, capacity: int = 200_000, fused_first_layer=False):
-		super().__init__(net)
+		super().__init__(net, fused_first_layer)           # fused: the net's first Linear reads the new nodes' 20-byte states
 		self.lambda_, self.expansions, self.n_searches = float(lambda_), int(expansions), int(n_searches)
 		self.capacity = max(int(capacity), 12 * self.expansions + 2)
-		self._from_states = None
-		if fused_first_layer:                              # the net's first Linear reads the new nodes' 20-byte states
-			from librubiks_amd.oh_linear import fused_net
-			self._from_states = fused_net(net, fused_first_layer)
 		self._h = None
 		self.status = None
 		self.iterations = 0
@@ -886,7 +928,7 @@ class AStarBatch(DeepAgent):
 	def _step(self, oh, code):
 		lib, h = _ffi.lib(), self._h
 		_ffi.check(lib.rk_astarb_step_expand(h, oh.data_ptr(), code, _ffi.stream_ptr()))
-		v = (self._from_states or self.net)(oh, policy=False, value=True)
+		v = (self._fs or self.net)(oh, policy=False, value=True)
 		v = v[-1] if isinstance(v, (list, tuple)) else v
 		if isinstance(v, torch.Tensor) and v.is_cuda and v.dtype == torch.bfloat16 and v.is_contiguous():
 			values, vcode = v.detach().reshape(-1), _ffi.OH_BF16        # a bf16 net's values go in as they are
@@ -914,7 +956,8 @@ class AStarBatch(DeepAgent):
 		_ffi.check(lib.rk_astarb_reset(h, states.ctypes.data, budget.ctypes.data, self.lambda_, _ffi.stream_ptr()))
 		self._vcode = _ffi.OH_F32
 		_ffi.check(lib.rk_astarb_set_values_dtype(h, self._vcode, _ffi.stream_ptr()))
-		if self._from_states is not None:
+		self._fs = self._from_states           # re-copied here if the net changed since the last search
+		if self._fs is not None:
 			oh, code = torch.from_numpy(cube.repeat_state(cube.get_solved(), S * K)).to(gpu), _ffi.OH_STATES
 		else:
 			oh_dtype = _oh_dtype(self.net)

@@ -20,9 +20,14 @@ iterations; steps after the decision are no-ops on the device):
   4. `rk_astar_shard_insert`: first the shortcut offers that arrived (relaxation case 2 of the PREVIOUS iteration, on
      the parents' owner), then membership, first-occurrence de-duplication in arrival order, append, goal test,
      relaxation case 1, one-hot of the new states;
-  5. value net on the fixed (world * 12 N, 480) batch, `rk_astar_shard_push`: cost, push into the local queue, this
-     iteration's shortcut offers into the send blocks (they ride on the next all-to-all, so relaxation case 2 costs no
-     collective of its own), next candidates, next all-gather contribution.
+  5. value net on the NEW states only, `rk_astar_shard_push`: cost, push into the local queue, this iteration's shortcut
+     offers into the send blocks (they ride on the next all-to-all, so relaxation case 2 costs no collective of its
+     own), next candidates, next all-gather contribution.  All ranks together pop at most N nodes, so a rank can receive
+     at most 12 N children and appends at most 12 N new states, whatever the world size: the net batch is bounded by
+     12 N rows, not world * 12 N.  A rank expects 12 N / world of them, so the net runs in two pieces: the first
+     ceil(12 N / world) rows at once, without waiting for anything; while the GPU works on them the host reads the
+     iteration's new-state count (4 bytes, asynchronous copy into pinned memory + event) and enqueues the remaining
+     rows, rounded up to 64, only if there are any.  With world = 1 the first piece is the whole batch and nothing waits.
 
 The action queue is rebuilt by walking (rank, index) parent references with one small broadcast per hop.
 
@@ -120,12 +125,8 @@ class ShardedAStar(DeepAgent):
 
 	def __init__(self, net, lambda_: float, expansions: int, capacity: int = 2_000_000, group=None, force_collectives: bool = False,
 	             poll: int = 1, profile: bool = False, fused_first_layer=False):
-		super().__init__(net)
 		# fused_first_layer (True / "epilogue" / "folded"): the net's first Linear reads the new nodes' 20-byte states
-		self._from_states = None
-		if fused_first_layer:
-			from librubiks_amd.oh_linear import fused_net
-			self._from_states = fused_net(net, fused_first_layer)
+		super().__init__(net, fused_first_layer)
 		self.lambda_, self.expansions, self.capacity = lambda_, int(expansions), int(capacity)
 		self.tp = Transport(group, force_collectives)
 		self.poll = max(1, int(poll))
@@ -136,6 +137,8 @@ class ShardedAStar(DeepAgent):
 		self.total_states = 0
 		self.stop_reason = "running"
 		self._n = 0
+		self.net_rows_max = 0                  # rows pushed through the net: largest iteration / sum over the last search
+		self.net_rows_total = 0
 
 	def _engine(self):
 		if self._h is None:
@@ -172,13 +175,20 @@ class ShardedAStar(DeepAgent):
 		_ffi.check(lib.rk_astar_shard_bind(h, mine.data_ptr()))
 		_ffi.check(lib.rk_astar_shard_reset(h, state.ctypes.data, float(self.lambda_), send.data_ptr(), st()))
 		root_owner = lib.rk_shard_owner(state.ctypes.data, tp.world)
-		if self._from_states is not None:
-			oh = torch.from_numpy(cube.repeat_state(cube.get_solved(), 12 * N * tp.world)).to(gpu)     # rows = states
-			code, forward = _ffi.OH_STATES, self._from_states
+		K = 12 * N                                                       # upper bound of a rank's new states per iteration
+		first = K if tp.world == 1 else min(K, -(-(-(-K // tp.world)) // 64) * 64)   # rows evaluated without waiting for the count
+		self._fs = self._from_states                                     # re-copied here if the net changed since the last search
+		if self._fs is not None:
+			oh = torch.from_numpy(cube.repeat_state(cube.get_solved(), K)).to(gpu)                     # rows = states
+			code, forward = _ffi.OH_STATES, self._fs
 		else:
 			oh_dtype = _oh_dtype(self.net)
-			oh = torch.zeros((12 * N * tp.world, 480), dtype=oh_dtype, device=gpu)
+			oh = torch.zeros((K, 480), dtype=oh_dtype, device=gpu)
 			code, forward = _OH_CODES[oh_dtype], self.net
+		n_new_host = torch.zeros(1, dtype=torch.int32).pin_memory() if first < K else None
+		counted = torch.cuda.Event() if first < K else None
+		vals = None                                                      # (K,) values of both pieces, in the net's value dtype
+		self.net_rows_max = self.net_rows_total = 0
 		decision = (C.c_longlong * 8)()
 		marks = []                                                       # per iteration: events between the phases
 
@@ -207,7 +217,25 @@ class ShardedAStar(DeepAgent):
 			mark(row)
 			_ffi.check(lib.rk_astar_shard_insert(h, got.data_ptr(), send.data_ptr(), oh.data_ptr(), code, st()))
 			mark(row)
-			values = _values_for_engine(h, forward(oh, policy=False, value=True))
+			if first == K:
+				values = _values_for_engine(h, forward(oh, policy=False, value=True))
+				rows = K
+			else:
+				_ffi.check(lib.rk_astar_shard_new_count(h, n_new_host.data_ptr(), st()))
+				counted.record()
+				v0 = _values_for_engine(h, forward(oh[:first], policy=False, value=True))
+				if vals is None or vals.dtype != v0.dtype:
+					vals = torch.zeros(K, dtype=v0.dtype, device=gpu)
+				vals[:first].copy_(v0)
+				counted.synchronize()                                    # the GPU is busy with the first piece meanwhile
+				rows = first
+				n_new = int(n_new_host[0])
+				if n_new > first:
+					rows = min(K, -(-n_new // 64) * 64)
+					vals[first:rows].copy_(_values_for_engine(h, forward(oh[first:rows], policy=False, value=True)))
+				values = vals
+			self.net_rows_max = max(self.net_rows_max, rows)
+			self.net_rows_total += rows
 			self._keep = (values, gathered)
 			mark(row)
 			_ffi.check(lib.rk_astar_shard_push(h, values.data_ptr(), got.data_ptr(), send.data_ptr(), st()))
@@ -286,7 +314,8 @@ class PartitionedMCTS:
 		self.n_trees = int(n_trees)
 		self.mine = np.arange(self.tr.rank, self.n_trees, self.tr.world)
 		self.max_path = int(max_path or 4096)
-		self.local = MCTSBatch(net, c, max(len(self.mine), 1), capacity=capacity, max_path=max_path, **kw)
+		# the engine's path limit IS the row width of the final all-gather: a tree cannot report more moves than fit a row
+		self.local = MCTSBatch(net, c, max(len(self.mine), 1), capacity=capacity, max_path=self.max_path, **kw)
 		self.solved = self.states = self.sims = None
 		self._queues = None
 
@@ -301,11 +330,16 @@ class PartitionedMCTS:
 			for k in range(len(self.mine)):
 				q = list(self.local.action_queue_of(k)) if solved[k] else []
 				if len(q) > self.max_path:
-					raise RuntimeError(f"a solution of {len(q)} moves exceeds max_path = {self.max_path}")
+					# never raise before the collective (the other ranks would wait in it for ever): the row carries the error
+					out[k, :4] = (-2, int(st[k, 2]), int(st[k, 3]), len(q))
+					continue
 				out[k, :4] = (int(solved[k]), int(st[k, 2]), int(st[k, 3]), len(q))
 				out[k, 4:4 + len(q)] = q
 		every = self.tr.all_gather(torch.from_numpy(out).reshape(-1).to(gpu if self.tr.on_device else "cpu"))
 		every = every.cpu().numpy().reshape(self.tr.world, per, row)
+		too_long = [(r, k, int(every[r, k, 3])) for r in range(self.tr.world) for k in range(per) if every[r, k, 0] == -2]
+		if too_long:                                                     # the same rows on every rank: all of them raise
+			raise RuntimeError(f"solutions longer than max_path = {self.max_path} (rank, local tree, moves): {too_long}")
 		self.solved, self.states, self.sims = (np.zeros(self.n_trees, t) for t in (bool, np.int64, np.int64))
 		self._queues = [deque() for _ in range(self.n_trees)]
 		for r in range(self.tr.world):

@@ -236,3 +236,85 @@ def test_bf16_net_outputs_go_to_the_engines_as_they_are():
 		assert np.allclose(t["P"][1:m + 1], p.float().softmax(dim=1).cpu().numpy(), atol=1e-2)
 		assert np.allclose(t["V"][1:m + 1], v.float().reshape(-1).cpu().numpy(), atol=2e-2)
 		assert np.allclose(t["P"][1:m + 1].sum(axis=1), 1.0, atol=1e-6)
+
+
+@pytest.mark.parametrize("mode", [True, "folded"])
+def test_fused_copy_follows_the_net(mode):
+	"""the fused first layer COPIES weights (and, folded, BatchNorm statistics and heads) while the reference trains
+	its net in place and reassigns agent.net (train.py:134, :214).  The agent re-copies at the start of a search whenever the
+	net changed -- in place (optimizer step) or by assignment -- and only then."""
+	from benchmarks.nets import FcSmall
+	from librubiks_amd.solving.agents import AStar, MCTSBatch
+	net = FcSmall(seed=4).cuda().eval()
+	np.random.seed(31)
+	start, _, _ = orc.scramble(9, True)
+
+	def same_search(x, y):
+		n = len(x)
+		return n == len(y) and (x.states[1:n + 1] == y.states[1:n + 1]).all() and (x.G[1:n + 1] == y.G[1:n + 1]).all() \
+		       and (x.parents[1:n + 1] == y.parents[1:n + 1]).all()
+
+	a = AStar(net, 0.2, 50, fused_first_layer=mode)
+	a.search(start, None, 8_000)
+	first = a._fs
+	a.search(start, None, 8_000)
+	assert a._fs is first                                          # nothing changed: no new copy
+	before = (a.states.copy(), a.G.copy())
+	with torch.no_grad():                                          # an optimizer step: parameters AND BatchNorm statistics move in place
+		for prm in net.parameters():
+			prm.mul_(0.5).add_(0.01)
+		for m in net.modules():
+			if isinstance(m, torch.nn.BatchNorm1d):
+				m.running_mean.add_(0.05)
+	a.search(start, None, 8_000)
+	assert a._fs is not first
+	fresh = AStar(net, 0.2, 50, fused_first_layer=mode)
+	fresh.search(start, None, 8_000)
+	assert same_search(a, fresh)
+	assert len(a) != len(before[0]) - 1 or not (a.states == before[0]).all() or not (a.G == before[1]).all()      # the new weights do search differently
+	net2 = FcSmall(seed=9).cuda().eval()                           # the net is swapped (train.py:214: agent.net = net)
+	a.net = net2
+	a.search(start, None, 8_000)
+	other = AStar(net2, 0.2, 50, fused_first_layer=mode)
+	other.search(start, None, 8_000)
+	assert same_search(a, other)
+	# MCTS drives its batch engine with `self._batch.net = self.net`: the batch agent follows too
+	mb = MCTSBatch(net, 1.0, 2, capacity=600, fused_first_layer=mode)
+	starts = np.array([start, start])
+	mb.search(starts, max_states=600, max_sims=30)
+	copy1 = mb._fs
+	mb.net = net
+	mb.search(starts, max_states=600, max_sims=30)
+	assert mb._fs is copy1                                         # re-assigning the SAME unchanged module costs nothing
+	mb.net = net2
+	mb.search(starts, max_states=600, max_sims=30)
+	assert mb._fs is not copy1
+
+
+def test_nan_stays_nan_through_the_bf16_outputs():
+	"""f32 -> bf16 by integer arithmetic on the bits turns some NaNs into +0 or +inf (0xFFFFFFFF -> +0,
+	0x7F800001 -> +inf; MI355X_MICROARCH.md, correctness boundaries).  Both places that round to bf16 -- the weight copy of
+	the MFMA route and the GATHER route's bf16 output -- use the hardware convert now: a NaN in, a NaN out."""
+	lin = torch.nn.Linear(480, 128).cuda()
+	nan_bits = torch.tensor([-1, 0x7F800001, 0x7FC00000, -4194304], dtype=torch.int32, device="cuda").view(torch.float32)   # 0xFFFFFFFF, sNaN, qNaN, 0xFFC00000
+	assert torch.isnan(nan_bits).all()
+	with torch.no_grad():
+		lin.bias[:4] = nan_bits                                # columns 0..3 of every output row: NaN + finite = NaN
+		lin.weight[8, 0] = nan_bits[0]                         # one-hot column 0 = "cubie 0 has code 0"
+		lin.weight[9, 24] = nan_bits[1]                        # one-hot column 24 = "cubie 1 has code 0"
+	states = torch.from_numpy(random_walk(512, 15, seed=5)).cuda()
+	picked8, picked9 = states[:, 0] == 0, states[:, 1] == 0
+	assert picked8.any() and not picked8.all() and picked9.any() and not picked9.all()
+	first = OhLinear(lin)
+	outs = {}
+	for route in ("gather", "mfma"):
+		outs[route] = torch.empty((512, 128), dtype=torch.bfloat16, device="cuda")
+		first(states, out=outs[route], route=route)
+		nan = torch.isnan(outs[route])
+		assert nan[:, :4].all() and not nan[:, 16:].any() and not torch.isinf(outs[route]).any(), route
+	# a NaN WEIGHT: the gather-sum meets it only in the rows that select it; the matrix product multiplies it with the
+	# one-hot's zeros in every row (0 * NaN = NaN), exactly as torch's dense Linear on the one-hot rows does
+	g, m = torch.isnan(outs["gather"]), torch.isnan(outs["mfma"])
+	assert torch.equal(g[:, 8], picked8) and torch.equal(g[:, 9], picked9)
+	dense = torch.isnan(torch.nn.functional.linear(cube.device.as_oh(states), lin.weight, lin.bias))
+	assert dense[:, 8].all() and dense[:, 9].all() and m[:, 8].all() and m[:, 9].all()
