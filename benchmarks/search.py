@@ -98,6 +98,8 @@ def bench_astar_batch(args):
 			agent.search(starts[0], None, 5 * 12 * args.expansions)
 		else:
 			agent = AStarBatch(net, args.lam, args.expansions, S, capacity=args.max_states, fused_first_layer=FUSED[args.fused])
+			if args.slice >= 0:
+				agent.net_slice_rows = args.slice or 10 ** 9                 # 0: the whole padded batch in one forward (round 2's behaviour)
 			agent.search(starts, max_states=5 * 12 * args.expansions, use_graph=mode.endswith("graph"), poll=2)
 		torch.cuda.synchronize()
 		t0 = time.perf_counter()
@@ -118,7 +120,8 @@ def bench_astar_batch(args):
 			states, iters, solved = int(agent.status[:, 2].sum()), int(agent.status[:, 3].sum()), int(res.sum())
 		out[mode] = {"seconds": dt, "states": int(states), "states_per_s": states / dt, "search_iterations": int(iters), "solved": int(solved)}
 	row = {"bench": "astar_batch", "config": f"{S} depth-{args.depth} scrambles, lambda={args.lam}, N={args.expansions}, max_states={args.max_states} each, "
-	       f"fc_small random init {'bf16' if args.bf16 else 'fp32'}" + FUSED_NOTE[args.fused], **out,
+	       f"fc_small random init {'bf16' if args.bf16 else 'fp32'}" + FUSED_NOTE[args.fused]
+	       + (f", net forwards of at most {args.slice} rows" if args.slice > 0 else ", ONE net forward on the whole padded batch" if args.slice == 0 else ", net forwards of at most 16384 rows (default)"), **out,
 	       "speedup_batch_graph_vs_sequential": out["sequential"]["seconds"] / out["batch+graph"]["seconds"]}
 	print(json.dumps(row), flush=True)
 	return row
@@ -164,6 +167,7 @@ if __name__ == "__main__":
 	ap.add_argument("--max-states", type=int, default=150_000)
 	ap.add_argument("--lam", type=float, default=0.16)
 	ap.add_argument("--bf16", type=int, default=0)
+	ap.add_argument("--slice", type=int, default=-1, help="astar_batch: rows per net forward (0 = whole padded batch, -1 = the agent's default)")
 	ap.add_argument("--fused", type=int, default=0, help="1: first Linear reads the 20-byte states (rk_ohl_*), no one-hot batch; "
 	                "2: and its ELU + BatchNorm run in the kernel's epilogue; 3: and the other BatchNorm layers are folded into the next Linear")
 	ap.add_argument("--trees", type=int, default=256)

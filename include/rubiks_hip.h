@@ -302,6 +302,13 @@ int rk_mcts_reset(rk_mcts_t *h, const int8_t *h_start_states, const long long *h
 int rk_mcts_roots_oh(rk_mcts_t *h, void *d_out, int out_dtype, void *stream);
 int rk_mcts_set_root_pv(rk_mcts_t *h, const float *d_probs, const float *d_values, void *stream);
 int rk_mcts_expand(rk_mcts_t *h, void *stream);
+/* Expand ahead: with sim_limit != 0 the backup + select launch ends by expanding the leaf it has just found (the first half
+ * of the NEXT simulation's expand_leaf, agents.py:505-543), and the rk_mcts_expand call that follows it is then a no-op
+ * without a launch: one launch and its dependent start-up less per simulation, same order of steps (select, expand, net,
+ * backup).  sim_limit > 0: only while the simulation just backed up has a number below sim_limit (so that a search of
+ * sim_limit simulations ends exactly where the reference's would); < 0: always; 0 (default): off.  A driver that stops for
+ * another reason (time) sets the limit to 0 and runs one more step, which completes the pending expansions. */
+int rk_mcts_set_expand_ahead(rk_mcts_t *h, long long sim_limit);
 int rk_mcts_children_oh(rk_mcts_t *h, void *d_out, int out_dtype, void *stream);
 int rk_mcts_backup_select(rk_mcts_t *h, const float *d_probs, const float *d_values, void *stream);
 /* The same step from the net's RAW outputs: d_logits, T*12 rows of 12 logits `logits_stride` elements apart, and d_values,

@@ -98,6 +98,7 @@ SIGNATURES = {
 	"rk_mcts_roots_oh": (_i, [_vp, _vp, _i, _vp]),
 	"rk_mcts_set_root_pv": (_i, [_vp, _vp, _vp, _vp]),
 	"rk_mcts_expand": (_i, [_vp, _vp]),
+	"rk_mcts_set_expand_ahead": (_i, [_vp, C.c_longlong]),
 	"rk_mcts_children_oh": (_i, [_vp, _vp, _i, _vp]),
 	"rk_mcts_backup_select": (_i, [_vp, _vp, _vp, _vp]),
 	"rk_mcts_backup_select_logits": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp]),

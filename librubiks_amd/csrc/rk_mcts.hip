@@ -197,29 +197,19 @@ __global__ void k_mcts_gather_roots(MctsDev d, uint32_t *out)
 	out[i] = d.states[((size_t)t * d.cap1 + 1) * 5 + j];
 }
 
-// expand_leaf, first half (agents.py:505-543)
-__global__ __launch_bounds__(64)
-void k_mcts_expand(MctsDev d)
+// expand_leaf, first half (agents.py:505-543): the 12 children of `leaf`, membership, new indices, neighbour links, goal
+// test.  One wave, lane a < 12 = action a.  `n` = states of the tree, `flags` = its TR_FLAGS word (not done).
+__device__ __forceinline__ void expand_leaf_body(const MctsDev &d, const u32x4 *s_act, int t, int lane, int n, int max_states, int flags, int leaf)
 {
-	__shared__ u32x4 s_act[36];
-	const int t = blockIdx.x, lane = threadIdx.x;
-	stage_action_tables(s_act, lane);
-	__syncthreads();
 	const bool active = lane < 12;
 	const size_t cbase = (size_t)t * 12 + lane;
-	if (active) d.child_new[cbase] = 0;
-	const TreeRec tr = load_tree(d.tree, t);
 	int32_t *trw = d.tree + (size_t)t * TR_INTS;
-	if (tr.v[TR_FLAGS] & 0xFF) return;                 // done
-	const int n = tr.v[TR_NSTATES];
-	if (n + 12 > tr.v[TR_MAXSTATES]) {                // loop guard of agents.py:476
-		if (lane == 0) trw[TR_FLAGS] = tr.v[TR_FLAGS] | 1;
+	if (n + 12 > max_states) {                        // loop guard of agents.py:476
+		if (active) d.child_new[cbase] = 0;
+		if (lane == 0) trw[TR_FLAGS] = flags | 1;
 		return;
 	}
 	const size_t node0 = (size_t)t * d.cap1;
-	const int plen = tr.v[TR_PLEN];
-	const int leaf = d.path_nodes[(size_t)t * d.max_path + plen - 1];
-
 	uint32_t s[5];
 	#pragma unroll
 	for (int j = 0; j < 5; j++) s[j] = d.states[(node0 + leaf) * 5 + j];
@@ -257,7 +247,7 @@ void k_mcts_expand(MctsDev d)
 	}
 	const unsigned long long solvedmask = __ballot(active && is_solved5(s));   // agents.py:540-543: first solved child
 	if (solvedmask != 0ull && lane == __ffsll((long long)solvedmask) - 1) {
-		trw[TR_FLAGS] = (tr.v[TR_FLAGS] & 0xFF) | (1 << 8);              // solved = 1
+		trw[TR_FLAGS] = (flags & 0xFF) | (1 << 8);                         // solved = 1
 		trw[TR_SOLVE_ACTION] = lane;
 		trw[TR_SOLVE_LEAF] = idx;
 	}
@@ -265,6 +255,24 @@ void k_mcts_expand(MctsDev d)
 		node_of(d, node0, leaf).expanded() = 1u;                           // leaves[leaf] = False, agents.py:536
 		trw[TR_NSTATES] = n + __popcll(newmask);
 	}
+}
+
+// the first expansion of a search (the root's); later ones ride at the end of the previous simulation's backup + select
+// kernel when the engine expands ahead (rk_mcts_set_expand_ahead)
+__global__ __launch_bounds__(64)
+void k_mcts_expand(MctsDev d)
+{
+	__shared__ u32x4 s_act[36];
+	const int t = blockIdx.x, lane = threadIdx.x;
+	stage_action_tables(s_act, lane);
+	__syncthreads();
+	const TreeRec tr = load_tree(d.tree, t);
+	if (tr.v[TR_FLAGS] & 0xFF) {                       // done: the backup must see no new children
+		if (lane < 12) d.child_new[(size_t)t * 12 + lane] = 0;
+		return;
+	}
+	const int leaf = d.path_nodes[(size_t)t * d.max_path + tr.v[TR_PLEN] - 1];
+	expand_leaf_body(d, s_act, t, lane, tr.v[TR_NSTATES], tr.v[TR_MAXSTATES], tr.v[TR_FLAGS], leaf);
 }
 
 // The net's outputs as the kernel takes them.  IN = 0: float32 probabilities (the caller ran softmax, agents.py:551) and
@@ -295,11 +303,18 @@ __device__ __forceinline__ void child_policy(const void *probs, size_t row, int 
 }
 
 // expand_leaf, second half (agents.py:546-571) + find_leaf (agents.py:575-595)
+// ahead_limit: 0 = the kernel ends with the selection (the next expansion is a launch of its own: k_mcts_expand);
+// otherwise the wave that has just found its tree's next leaf expands it on the spot (expand_leaf's first half of the NEXT
+// simulation: one launch and its dependent start-up less per simulation) -- as long as another simulation will follow,
+// i.e. this simulation's number is below ahead_limit (< 0: no limit).  The order of the reference's steps is unchanged:
+// select, expand, net, backup.
 template <int IN>
 __global__ __launch_bounds__(64)
-void k_mcts_backup_select(MctsDev d, const void *probs, const void *values, int p_stride, int v_stride)
+void k_mcts_backup_select(MctsDev d, const void *probs, const void *values, int p_stride, int v_stride, int ahead_limit)
 {
+	__shared__ u32x4 s_act[36];
 	const int t = blockIdx.x, lane = threadIdx.x;
+	if (ahead_limit != 0) stage_action_tables(s_act, lane);            // (one wave: visible to it without a barrier after the fence below)
 	const bool active = lane < 12;
 	const size_t node0 = (size_t)t * d.cap1;
 	const size_t cbase = (size_t)t * 12 + lane;
@@ -314,7 +329,10 @@ void k_mcts_backup_select(MctsDev d, const void *probs, const void *values, int 
 	const int idx = active ? d.child_idx[cbase] : 0;
 	const bool is_new = active && d.child_new[cbase] != 0;
 	const float vf = active ? net_scalar<IN>(values, cbase * (size_t)v_stride) : 0.0f;
-	if (is_done) return;
+	if (is_done) {
+		if (ahead_limit != 0 && active) d.child_new[cbase] = 0;            // (k_mcts_expand does this when it runs)
+		return;
+	}
 	const int leaf = pnodes[plen - 1];
 	const double v = (double)vf;
 	if (is_new) {
@@ -360,6 +378,7 @@ void k_mcts_backup_select(MctsDev d, const void *probs, const void *values, int 
 			pacts[plen - 1] = (uint8_t)tr.v[TR_SOLVE_ACTION];
 			trw[TR_FLAGS] = tr.v[TR_FLAGS] | 1;
 		}
+		if (ahead_limit != 0 && active) d.child_new[cbase] = 0;
 		return;
 	}
 	fence_wave_to_wave();
@@ -412,6 +431,14 @@ void k_mcts_backup_select(MctsDev d, const void *probs, const void *values, int 
 		}
 	}
 	if (lane == 0) trw[TR_PLEN] = len;
+	// ---- expand_leaf of the next simulation, first half (agents.py:505-543) ----
+	const bool broke_on_error = len >= (int)d.max_path || cur <= 0;
+	if (ahead_limit != 0 && !broke_on_error && (ahead_limit < 0 || sim < ahead_limit)) {
+		fence_wave_to_wave();                                              // the table staged at the top, the path written above
+		expand_leaf_body(d, s_act, t, lane, tr.v[TR_NSTATES], tr.v[TR_MAXSTATES], tr.v[TR_FLAGS], cur);
+	} else if (ahead_limit != 0 && active) {
+		d.child_new[cbase] = 0;                                            // nothing pending for this tree
+	}
 }
 
 }  // namespace rk
@@ -425,6 +452,8 @@ struct rk_mcts {
 	uint32_t *starts_dev = nullptr;
 	int32_t *max_states_dev = nullptr;
 	bool ready = false;
+	int ahead_limit = 0;          // rk_mcts_set_expand_ahead: 0 off, < 0 always, > 0 while the simulation number is below it
+	bool ahead = false;           // the last backup + select launch already expanded the leaves it found
 };
 
 namespace {
@@ -510,6 +539,14 @@ int rk_mcts_reset(rk_mcts_t *h, const int8_t *h_start_states, const long long *h
 	RK_HIP(hipGetLastError());
 	RK_HIP(hipStreamSynchronize(st));           // host buffers may go away after return
 	h->ready = true;
+	h->ahead = false;
+	return RK_OK;
+}
+
+int rk_mcts_set_expand_ahead(rk_mcts_t *h, long long sim_limit)
+{
+	if (!h) return fail(RK_EINVAL, "rk_mcts_set_expand_ahead: null handle");
+	h->ahead_limit = sim_limit < 0 ? -1 : (sim_limit > INT_MAX ? INT_MAX : (int)sim_limit);
 	return RK_OK;
 }
 
@@ -540,6 +577,7 @@ int rk_mcts_set_root_pv(rk_mcts_t *h, const float *d_probs, const float *d_value
 int rk_mcts_expand(rk_mcts_t *h, void *stream)
 {
 	if (!h || !h->ready) return fail(RK_ESTATE, "rk_mcts_expand: reset the engine first");
+	if (h->ahead) { h->ahead = false; return RK_OK; }    // the previous backup + select launch has done it already
 	hipLaunchKernelGGL(k_mcts_expand, dim3(h->d.T), dim3(64), 0, (hipStream_t)stream, h->d);
 	RK_HIP(hipGetLastError());
 	return RK_OK;
@@ -560,8 +598,9 @@ int rk_mcts_backup_select(rk_mcts_t *h, const float *d_probs, const float *d_val
 {
 	if (!h || !h->ready) return fail(RK_ESTATE, "rk_mcts_backup_select: reset the engine first");
 	if (!d_probs || !d_values) return fail(RK_EINVAL, "rk_mcts_backup_select: null pointer");
-	hipLaunchKernelGGL(k_mcts_backup_select<0>, dim3(h->d.T), dim3(64), 0, (hipStream_t)stream, h->d, (const void *)d_probs, (const void *)d_values, 12, 1);
+	hipLaunchKernelGGL(k_mcts_backup_select<0>, dim3(h->d.T), dim3(64), 0, (hipStream_t)stream, h->d, (const void *)d_probs, (const void *)d_values, 12, 1, h->ahead_limit);
 	RK_HIP(hipGetLastError());
+	h->ahead = h->ahead_limit != 0;
 	return RK_OK;
 }
 
@@ -571,12 +610,13 @@ int rk_mcts_backup_select_logits(rk_mcts_t *h, const void *d_logits, int logits_
 	if (!d_logits || !d_values) return fail(RK_EINVAL, "rk_mcts_backup_select_logits: null pointer");
 	if (logits_stride < 12 || values_stride < 1) return fail(RK_EINVAL, "rk_mcts_backup_select_logits: strides are in elements, at least 12 and 1");
 	if (dtype == RK_OH_F32)
-		hipLaunchKernelGGL(k_mcts_backup_select<1>, dim3(h->d.T), dim3(64), 0, (hipStream_t)stream, h->d, d_logits, d_values, logits_stride, values_stride);
+		hipLaunchKernelGGL(k_mcts_backup_select<1>, dim3(h->d.T), dim3(64), 0, (hipStream_t)stream, h->d, d_logits, d_values, logits_stride, values_stride, h->ahead_limit);
 	else if (dtype == RK_OH_BF16)
-		hipLaunchKernelGGL(k_mcts_backup_select<2>, dim3(h->d.T), dim3(64), 0, (hipStream_t)stream, h->d, d_logits, d_values, logits_stride, values_stride);
+		hipLaunchKernelGGL(k_mcts_backup_select<2>, dim3(h->d.T), dim3(64), 0, (hipStream_t)stream, h->d, d_logits, d_values, logits_stride, values_stride, h->ahead_limit);
 	else
 		return fail(RK_EINVAL, "rk_mcts_backup_select_logits: logits and values must be float32 or bfloat16");
 	RK_HIP(hipGetLastError());
+	h->ahead = h->ahead_limit != 0;
 	return RK_OK;
 }
 

@@ -315,6 +315,27 @@ def _values_for_engine(h, out) -> torch.Tensor:
 	return v
 
 
+#: Rows per net forward.  A forward on B rows streams B x 4096 activations per layer through every elementwise kernel
+#: of the torch module (Linear, ELU, BatchNorm ...); while a slice's activations fit the 256 MiB Infinity Cache those
+#: kernels run out of it, beyond that every one of them goes to HBM: 64 searches x 12 000 rows in ONE forward ran four
+#: times slower PER ROW than 12 000-row forwards (profiles/r02_astar_batch.json: batch 0.22x of sequential at N = 1000).
+#: 16 384 rows x 4 096 x 2 B = 134 MB (bf16).  The reference slices its own large forwards the same way (train.py:301-311).
+NET_SLICE_ROWS = 16_384
+
+
+def _value_of(out):
+	return out[-1] if isinstance(out, (list, tuple)) else out
+
+
+def _sliced_value_forward(forward, rows: torch.Tensor, max_rows: int = None):
+	"""The value head of `forward` on `rows`, evaluated in slices of at most `max_rows` rows (see NET_SLICE_ROWS)."""
+	max_rows = max_rows or NET_SLICE_ROWS
+	n = len(rows)
+	if n <= max_rows:
+		return _value_of(forward(rows, policy=False, value=True))
+	return torch.cat([_value_of(forward(rows[i:i + max_rows], policy=False, value=True)).reshape(-1) for i in range(0, n, max_rows)])
+
+
 class CapacityExhausted(RuntimeWarning):
 	"""A search that was limited only by time stopped because its node pool was full (the reference grows its arrays)."""
 
@@ -398,7 +419,7 @@ class AStar(DeepAgent):
 	def _iteration(self, h, oh, code):
 		lib = _ffi.lib()
 		_ffi.check(lib.rk_astar_step_expand(h, oh.data_ptr(), code, _ffi.stream_ptr()))
-		values = _values_for_engine(h, (self._fs or self.net)(oh, policy=False, value=True))
+		values = _values_for_engine(h, _sliced_value_forward(self._fs or self.net, oh))
 		self._keep = values                # the commit kernels read it after this call returns
 		_ffi.check(lib.rk_astar_step_commit(h, values.data_ptr(), _ffi.stream_ptr()))
 
@@ -456,7 +477,7 @@ class AStar(DeepAgent):
 				values = None
 				if n_new:
 					_ffi.check(lib.rk_astar_new_states_oh(h, oh.data_ptr(), code, _ffi.stream_ptr()))
-					values = _values_for_engine(h, (self._fs or self.net)(oh[:n_new], policy=False, value=True))
+					values = _values_for_engine(h, _sliced_value_forward(self._fs or self.net, oh[:n_new]))
 				_ffi.check(lib.rk_astar_commit(h, values.data_ptr() if values is not None else None, _ffi.stream_ptr()))
 				if time.perf_counter() - t0 >= time_limit:
 					break
@@ -686,6 +707,8 @@ class MCTSBatch(DeepAgent):
 			p, v = _policy_value_f32(self.net(root_oh))                  # agents.py:470-473
 			oh = torch.empty((12 * self.n_trees, 480), dtype=oh_dtype, device=gpu)
 		_ffi.check(lib.rk_mcts_set_root_pv(h, p.data_ptr(), v.data_ptr(), _ffi.stream_ptr()))
+		# every backup + select launch also expands the leaf it found, while another simulation is to follow
+		_ffi.check(lib.rk_mcts_set_expand_ahead(h, int(max_sims) if max_sims is not None else -1))
 		self.simulations = 0
 		graph = None
 		if use_graph:
@@ -709,6 +732,12 @@ class MCTSBatch(DeepAgent):
 			self.simulations += burst
 			if self._poll()[:, 0].all():
 				break
+		_ffi.check(lib.rk_mcts_set_expand_ahead(h, 0))
+		if (max_sims is None or self.simulations < max_sims) and not self._poll()[:, 0].all():
+			# out of time with leaves expanded ahead: one more step (net + backup, no further expansion) completes them, so
+			# that every tree is the reference's tree after a whole number of simulations
+			self._step(oh, h)
+			self.simulations += 1
 		st = self._poll()
 		return st[:, 1] != 0
 
@@ -896,6 +925,7 @@ class AStarBatch(DeepAgent):
 
 	def __init__(self, net, lambda_: float, expansions: int, n_searches: int, capacity: int = 200_000, fused_first_layer=False):
 		super().__init__(net, fused_first_layer)           # fused: the net's first Linear reads the new nodes' 20-byte states
+		self.net_slice_rows = None                         # rows per net forward (None: NET_SLICE_ROWS)
 		self.lambda_, self.expansions, self.n_searches = float(lambda_), int(expansions), int(n_searches)
 		self.capacity = max(int(capacity), 12 * self.expansions + 2)
 		self._h = None
@@ -928,8 +958,7 @@ class AStarBatch(DeepAgent):
 	def _step(self, oh, code):
 		lib, h = _ffi.lib(), self._h
 		_ffi.check(lib.rk_astarb_step_expand(h, oh.data_ptr(), code, _ffi.stream_ptr()))
-		v = (self._fs or self.net)(oh, policy=False, value=True)
-		v = v[-1] if isinstance(v, (list, tuple)) else v
+		v = _sliced_value_forward(self._fs or self.net, oh, self.net_slice_rows)
 		if isinstance(v, torch.Tensor) and v.is_cuda and v.dtype == torch.bfloat16 and v.is_contiguous():
 			values, vcode = v.detach().reshape(-1), _ffi.OH_BF16        # a bf16 net's values go in as they are
 		else:

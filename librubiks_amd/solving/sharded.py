@@ -47,7 +47,7 @@ import torch
 import torch.distributed as dist
 
 from librubiks_amd import gpu, no_grad, _ffi, cube
-from librubiks_amd.solving.agents import DeepAgent, _values_for_engine, _oh_dtype, _OH_CODES
+from librubiks_amd.solving.agents import DeepAgent, _values_for_engine, _sliced_value_forward, _oh_dtype, _OH_CODES
 
 STOP_REASONS = {0: "running", 1: "won", 2: "budget", 3: "capacity", 4: "time", 5: "nothing open", 6: "engine error"}
 
@@ -218,12 +218,12 @@ class ShardedAStar(DeepAgent):
 			_ffi.check(lib.rk_astar_shard_insert(h, got.data_ptr(), send.data_ptr(), oh.data_ptr(), code, st()))
 			mark(row)
 			if first == K:
-				values = _values_for_engine(h, forward(oh, policy=False, value=True))
+				values = _values_for_engine(h, _sliced_value_forward(forward, oh))
 				rows = K
 			else:
 				_ffi.check(lib.rk_astar_shard_new_count(h, n_new_host.data_ptr(), st()))
 				counted.record()
-				v0 = _values_for_engine(h, forward(oh[:first], policy=False, value=True))
+				v0 = _values_for_engine(h, _sliced_value_forward(forward, oh[:first]))
 				if vals is None or vals.dtype != v0.dtype:
 					vals = torch.zeros(K, dtype=v0.dtype, device=gpu)
 				vals[:first].copy_(v0)
@@ -232,7 +232,7 @@ class ShardedAStar(DeepAgent):
 				n_new = int(n_new_host[0])
 				if n_new > first:
 					rows = min(K, -(-n_new // 64) * 64)
-					vals[first:rows].copy_(_values_for_engine(h, forward(oh[first:rows], policy=False, value=True)))
+					vals[first:rows].copy_(_values_for_engine(h, _sliced_value_forward(forward, oh[first:rows])))
 				values = vals
 			self.net_rows_max = max(self.net_rows_max, rows)
 			self.net_rows_total += rows
