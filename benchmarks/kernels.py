@@ -35,6 +35,33 @@ def timed(fn, reps, warm=10):
 	return e0.elapsed_time(e1) / reps * 1e-3
 
 
+def timed_graph(fn, reps, warm=3):
+	"""The same launches captured ONCE into a hipGraph (through torch.cuda.CUDAGraph) and replayed: the host issues one
+	graph launch for `reps` kernels, so a small kernel is timed at the GPU's pace and not at the pace of Python + ctypes
+	(a launch through the Python shim costs the host about 8 us -- the LAUNCH FLOOR row -- which is what round 2's figures
+	for the 1 M-row kernels, 8-10 us each, actually measured)."""
+	side = torch.cuda.Stream()
+	side.wait_stream(torch.cuda.current_stream())
+	with torch.cuda.stream(side):
+		for _ in range(warm):
+			fn()
+	torch.cuda.current_stream().wait_stream(side)
+	graph = torch.cuda.CUDAGraph()
+	with torch.cuda.graph(graph):
+		for _ in range(reps):
+			fn()
+	for _ in range(3):
+		graph.replay()
+	e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+	torch.cuda.synchronize()
+	e0.record()
+	for _ in range(5):
+		graph.replay()
+	e1.record()
+	torch.cuda.synchronize()
+	return e0.elapsed_time(e1) / (5 * reps) * 1e-3
+
+
 def main():
 	ap = argparse.ArgumentParser()
 	ap.add_argument("--n", type=int, default=1_000_000)
@@ -65,6 +92,16 @@ def main():
 		             "algorithmic_bytes": bytes_per_launch, f"{unit_name}/s": units / t})
 		print(json.dumps(rows[-1]), flush=True)
 
+	# what a small launch costs whatever it does: back-to-back launches of the goal test on ONE 256-state tile, and torch's own
+	# copy / fill of buffers as small as the 1 M-row kernels' (20 MB): the per-launch floor those kernels sit on
+	tiny, tiny_fl = states[:256].contiguous(), torch.empty(256, dtype=torch.uint8, device="cuda")
+	t_floor = timed(lambda: cube.device.multi_is_solved(tiny, tiny_fl), 400)
+	rows.append({"kernel": "LAUNCH FLOOR: multi_is_solved on 256 states, back-to-back", "ms": t_floor * 1e3})
+	print(json.dumps(rows[-1]), flush=True)
+	small_a, small_b = torch.empty(20 * n, dtype=torch.uint8, device="cuda"), torch.empty(20 * n, dtype=torch.uint8, device="cuda")
+	report(f"device copy {20 * n // 1_000_000} MB (torch; same bytes as multi_rotate at this size)", 40 * n, timed(lambda: small_b.copy_(small_a), args.reps), 20 * n, "bytes")
+	report(f"device fill {20 * n // 1_000_000} MB (torch fill_)", 20 * n, timed(lambda: small_b.fill_(1), args.reps), 20 * n, "bytes")
+	del small_a, small_b
 	report("device copy 256 MiB (torch, reference point)", 2 * a.numel(), timed(lambda: b.copy_(a), 50), a.numel(), "bytes")
 	report("device fill 240 MB (torch fill_, pure store stream)", children.numel(), timed(lambda: children.fill_(1), 50), children.numel(), "bytes")
 	report("expand12 + goal test", 272 * n, timed(lambda: cube.device.expand12(states, children, solved), args.reps), n, "expansions")
@@ -75,8 +112,29 @@ def main():
 	report("expand12 + goal test, structure-of-arrays planes", 272 * n, timed(lambda: cube.device.expand12_soa(planes, ch_soa, fl_soa), args.reps), n, "expansions")
 	del ch_soa, fl_soa
 	report("multi_rotate (per-state action)", 41 * n, timed(lambda: cube.device.multi_rotate(states, acts, out), args.reps), n, "transitions")
+	# the same with the states coming from HBM (32 distinct sets = 640 MB rotating, as bench.py does for the fan-out)
+	rot = [states] + [cube.device.apply_sequences(torch.randint(0, 12, (20, n), device="cuda", dtype=torch.uint8, generator=g), False, True) for _ in range(31)]
+	k = [0]
+	def rot_rotate():
+		k[0] += 1
+		cube.device.multi_rotate(rot[k[0] % 32], acts, out)
+	def rot_solved():
+		k[0] += 1
+		cube.device.multi_is_solved(rot[k[0] % 32], flags)
+	report("multi_rotate (per-state action), states rotating over 640 MB", 41 * n, timed(rot_rotate, 3 * args.reps), n, "transitions")
+	report("multi_is_solved, states rotating over 640 MB", 21 * n, timed(rot_solved, 3 * args.reps), n, "states")
+	del rot
 	report("multi_rotate on 12 M rows", 41 * 12 * n, timed(lambda: cube.device.multi_rotate(children, acts.repeat(12), children), 20), 12 * n, "transitions")
 	report("multi_is_solved", 21 * n, timed(lambda: cube.device.multi_is_solved(states, flags), args.reps), n, "states")
+	# the small launches again, replayed from a hipGraph (GPU pace, see timed_graph)
+	report("LAUNCH FLOOR replayed from a hipGraph: multi_is_solved on 256 states", 21 * 256, timed_graph(lambda: cube.device.multi_is_solved(tiny, tiny_fl), 200), 256, "states")
+	report("multi_is_solved, replayed from a hipGraph", 21 * n, timed_graph(lambda: cube.device.multi_is_solved(states, flags), 100), n, "states")
+	report("multi_rotate (per-state action), replayed from a hipGraph", 41 * n, timed_graph(lambda: cube.device.multi_rotate(states, acts, out), 100), n, "transitions")
+	n100 = min(n, 100_000)
+	report("expand12 + goal test on 100 k parents, replayed from a hipGraph", 272 * n100,
+	       timed_graph(lambda: cube.device.expand12(states[:n100], children[:12 * n100], solved[:12 * n100]), 100), n100, "expansions")
+	report("expand12 + goal test on 100 k parents (eager launches)", 272 * n100,
+	       timed(lambda: cube.device.expand12(states[:n100], children[:12 * n100], solved[:12 * n100]), args.reps), n100, "expansions")
 	report("multi_is_solved on 12 M rows", 21 * 12 * n, timed(lambda: cube.device.multi_is_solved(children, solved), 50), 12 * n, "states")
 	report("as_oh f32", (20 + 1920) * n_oh, timed(lambda: cube.device.as_oh(states[:n_oh], oh), 50), n_oh, "states")
 	report("as_oh bf16", (20 + 960) * n_oh, timed(lambda: cube.device.as_oh(states[:n_oh], oh16, torch.bfloat16), 50), n_oh, "states")

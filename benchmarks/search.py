@@ -121,7 +121,7 @@ def bench_astar_batch(args):
 		out[mode] = {"seconds": dt, "states": int(states), "states_per_s": states / dt, "search_iterations": int(iters), "solved": int(solved)}
 	row = {"bench": "astar_batch", "config": f"{S} depth-{args.depth} scrambles, lambda={args.lam}, N={args.expansions}, max_states={args.max_states} each, "
 	       f"fc_small random init {'bf16' if args.bf16 else 'fp32'}" + FUSED_NOTE[args.fused]
-	       + (f", net forwards of at most {args.slice} rows" if args.slice > 0 else ", ONE net forward on the whole padded batch" if args.slice == 0 else ", net forwards of at most 16384 rows (default)"), **out,
+	       + (f", net forwards of at most {args.slice} rows" if args.slice > 0 else ", ONE net forward on the whole padded batch" if args.slice == 0 else ", net forwards of whole searches (the agent's default: one search per forward from K = 4096 rows on, else up to 16384 rows)"), **out,
 	       "speedup_batch_graph_vs_sequential": out["sequential"]["seconds"] / out["batch+graph"]["seconds"]}
 	print(json.dumps(row), flush=True)
 	return row
@@ -159,7 +159,7 @@ def bench_mcts(args):
 if __name__ == "__main__":
 	ap = argparse.ArgumentParser()
 	ap.add_argument("what", choices=["astar", "mcts", "astar_batch"])
-	ap.add_argument("--searches", type=int, default=64)
+	ap.add_argument("--searches", type=int, default=64, help="upper bound of iterations between two polls of the engines")
 	ap.add_argument("--sequential-games", type=int, default=16)
 	ap.add_argument("--games", type=int, default=5)
 	ap.add_argument("--depth", type=int, default=14)
@@ -174,7 +174,7 @@ if __name__ == "__main__":
 	ap.add_argument("--sims", type=int, default=4096)
 	ap.add_argument("--c", type=float, default=0.6)
 	ap.add_argument("--graph", type=int, default=1)
-	ap.add_argument("--poll", type=int, default=64)
+	ap.add_argument("--poll", type=int, default=64, help="upper bound of iterations between two polls of the engines")
 	ap.add_argument("--max-path", type=int, default=16384)
 	a = ap.parse_args()
 	_ffi.check(_ffi.lib().rk_init(0))

@@ -113,7 +113,8 @@ def main():
 		       "stop": agent.stop_reason, "iterations": agent.iterations, "total_states": agent.total_states, "seconds": dt,
 		       "ms_per_iteration": dt / max(agent.iterations, 1) * 1e3, "states_per_s": agent.total_states / dt,
 		       "solution_length": len(agent.action_queue) if solved else None, "collectives": agent.tp.collectives,
-		       "phase_ms": agent.phase_ms}
+		       "net_rows_per_iteration": agent.net_rows_total / max(agent.iterations, 1), "net_rows_max": agent.net_rows_max,
+		       "net_rows_bound_12N": 12 * args.expansions, "phase_ms": agent.phase_ms}
 		rows.append(row)
 		if rank == 0:
 			print(json.dumps(row), flush=True)

@@ -274,6 +274,29 @@ int rk_astar_shard_clear_send(rk_astar_t *h, void *d_send, int records, int offe
 /* h_out = {parent rank, parent index, action} of node `index` on this rank (for the cross-rank path walk). */
 int rk_astar_shard_parent(rk_astar_t *h, long long index, long long *h_out, void *stream);
 
+/* ---- transport of the hash-sharded search over RCCL / xGMI, for callers without torch.distributed ----------------
+ * No counterpart in the reference (single process); SURVEY.md 8(b) `rk_comm_*`.  One communicator per process (= per GPU,
+ * the device current at rk_comm_create).  Rank 0 calls rk_comm_unique_id and hands the RK_COMM_ID_BYTES bytes to the other
+ * ranks by any means (file, socket, MPI); every rank then calls rk_comm_create with the same bytes (a collective call).
+ * The three transfers are exactly what rk_astar_shard_* needs, on the engine's own fixed-size DEVICE buffers, enqueued on
+ * the caller's stream and ordered with the engine's kernels (nothing synchronises):
+ *   rk_comm_all_gather   bytes_per_rank from every rank, rank-major, into d_recv (world * bytes_per_rank)
+ *   rk_comm_all_to_all   block p of d_send goes to rank p, block q of d_recv comes from rank q (equal blocks: the record
+ *                        and offer counts travel inside them, rk_astar_shard_block_bytes); d_send != d_recv
+ *   rk_comm_broadcast    in place, from `root` (the three integers of one hop of the path walk)
+ * librccl is opened at first use (RK_RCCL_LIB overrides the name); RK_EHIP with RCCL's message if a call fails.
+ * librubiks_amd/solving/sharded.py::RcclTransport drives ShardedAStar through these; torch.distributed stays the default. */
+#define RK_COMM_ID_BYTES 128
+typedef struct rk_comm rk_comm_t;
+int rk_comm_unique_id(void *out_128_bytes);
+int rk_comm_create(rk_comm_t **out, const void *id_128_bytes, int rank, int world);
+int rk_comm_destroy(rk_comm_t *c);
+int rk_comm_rank(const rk_comm_t *c);
+int rk_comm_world(const rk_comm_t *c);
+int rk_comm_all_gather(rk_comm_t *c, const void *d_send, void *d_recv, size_t bytes_per_rank, void *stream);
+int rk_comm_all_to_all(rk_comm_t *c, const void *d_send, void *d_recv, size_t bytes_per_peer, void *stream);
+int rk_comm_broadcast(rk_comm_t *c, void *d_buf, size_t bytes, int root, void *stream);
+
 /* ---- Monte Carlo tree search (agents.py:415-645): T independent trees, all state in HBM ----------------------
  * Replaces MCTS.expand_leaf / find_leaf for a whole batch of searches (the reference runs one tree at a time).
  * Per tree the engine owns the reference's arrays: states, neighbors (cap,12), leaves, P, V, N, W, L

@@ -92,6 +92,14 @@ SIGNATURES = {
 	"rk_astar_shard_flush": (_i, [_vp, _vp, _vp]),
 	"rk_astar_shard_clear_send": (_i, [_vp, _vp, _i, _i, _vp]),
 	"rk_astar_shard_parent": (_i, [_vp, C.c_longlong, _vp, _vp]),
+	"rk_comm_unique_id": (_i, [_vp]),
+	"rk_comm_create": (_i, [C.POINTER(_vp), _vp, _i, _i]),
+	"rk_comm_destroy": (_i, [_vp]),
+	"rk_comm_rank": (_i, [_vp]),
+	"rk_comm_world": (_i, [_vp]),
+	"rk_comm_all_gather": (_i, [_vp, _vp, _vp, _sz, _vp]),
+	"rk_comm_all_to_all": (_i, [_vp, _vp, _vp, _sz, _vp]),
+	"rk_comm_broadcast": (_i, [_vp, _vp, _sz, _i, _vp]),
 	"rk_mcts_create": (_i, [C.POINTER(_vp), _i, _sz, _sz]),
 	"rk_mcts_destroy": (_i, [_vp]),
 	"rk_mcts_reset": (_i, [_vp, _vp, _vp, C.c_double, C.c_double, _vp]),

@@ -51,6 +51,7 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -1171,7 +1172,11 @@ int launch_commit(rk_astar *h, const float *d_values, const uint8_t *recv, hipSt
 			from ^= 1;
 		}
 	}
-	const unsigned grid = std::min<unsigned>(1024u, std::max<unsigned>(blocks((size_t)d.Kpad * 4), 8u));
+	// The merge's size is decided on the device (it is the new records most of the time and a whole queue level now and
+	// then); workgroups beyond it leave after the plan.  With 32 workgroups at N = 100 the occasional level merge (up to
+	// the whole open set) ran 32 records per thread, each a chain of dependent binary searches: 310 us spikes in round 2.
+	static const unsigned min_grid = [] { const char *e = std::getenv("RK_INSERT_MIN_GRID"); return e ? (unsigned)std::atoi(e) : 512u; }();
+	const unsigned grid = std::min<unsigned>(1024u, std::max<unsigned>(blocks((size_t)d.Kpad * 4), min_grid));
 	hipLaunchKernelGGL((k_queue_insert<SHARDED>), dim3(grid), dim3(256), 0, st, d, from);
 	if (!SHARDED) {
 		hipLaunchKernelGGL((k_end<false>), dim3(1), dim3(1024), 0, st, d, from, 1);

@@ -373,7 +373,12 @@ class AStar(DeepAgent):
 		self.expansions = int(expansions)
 		self.capacity = capacity
 		self.poll = max(1, int(poll))
-		self.use_hipgraph = use_hipgraph
+		# use_hipgraph: True / False, or "auto" = replay the iteration as a hipGraph only where that wins.  Measured eager vs
+		# graph, us per iteration (profiles/r03_astar_small.json): with a real net the graph wins while the HOST is the
+		# bottleneck (fc_small bf16: N = 10 207 -> 124, N = 27 196 -> 140), ties at N = 100 and LOSES above (N = 700: 471 -> 589;
+		# float32 1580 -> 1878), although the kernels and their order are the same and under rocprofv3 (which serialises both)
+		# both modes take the same time kernel by kernel (profiles/r03_astar_graph_gaps.json).
+		self.use_hipgraph = (self.expansions <= 50) if use_hipgraph == "auto" else bool(use_hipgraph)
 		self._h = None
 		self._h_cap = 0
 		self._n = 0
@@ -958,7 +963,13 @@ class AStarBatch(DeepAgent):
 	def _step(self, oh, code):
 		lib, h = _ffi.lib(), self._h
 		_ffi.check(lib.rk_astarb_step_expand(h, oh.data_ptr(), code, _ffi.stream_ptr()))
-		v = _sliced_value_forward(self._fs or self.net, oh, self.net_slice_rows)
+		# rows per forward: whole searches, as many as fit NET_SLICE_ROWS -- and exactly ONE search per forward once a search's
+		# own batch is that large: then every forward has the shape a sequential AStar would give the net, so the batch can
+		# not lose to it through the library's kernel choice (measured at N = 1000, 64 searches, bf16 fc_small: hipBLASLt and
+		# torch's BatchNorm pick kernels for 16 384-row forwards that cost three times as much per row as for 12 000 rows)
+		K = 12 * self.expansions
+		rows = self.net_slice_rows or (K if K >= NET_SLICE_ROWS // 4 else (NET_SLICE_ROWS // K) * K)
+		v = _sliced_value_forward(self._fs or self.net, oh, rows)
 		if isinstance(v, torch.Tensor) and v.is_cuda and v.dtype == torch.bfloat16 and v.is_contiguous():
 			values, vcode = v.detach().reshape(-1), _ffi.OH_BF16        # a bf16 net's values go in as they are
 		else:
@@ -1004,14 +1015,24 @@ class AStarBatch(DeepAgent):
 			graph = torch.cuda.CUDAGraph()
 			with torch.cuda.graph(graph):
 				self._step(oh, code)
+		# Steps after a search is done are no-ops on the device but still run the net on the padded batch, so the host must not
+		# poll too rarely: a search grows by at most K states per iteration, so no live search can run out of budget in fewer
+		# than (budget - states) // K iterations -- poll after that many (at most `poll`).  Round 2's harness polled every 64
+		# iterations of a search that needs 12: that, not a kernel, was the 0.22x of profiles/r02_astar_batch.json at N = 1000.
+		n_states = np.ones(S, np.int64)
+		live = np.ones(S, bool)
 		while time.perf_counter() - t0 < time_limit:
-			for _ in range(poll):
+			safe = int(((budget[live] - n_states[live]) // K).min()) if live.any() else 1
+			burst = max(1, min(poll, safe))
+			for _ in range(burst):
 				if graph is not None:
 					graph.replay()
 				else:
 					self._step(oh, code)
-			self.iterations += poll
-			if self._poll()[:, 0].all():
+			self.iterations += burst
+			st = self._poll()
+			live, n_states = st[:, 0] == 0, st[:, 2]
+			if not live.any():
 				break
 		return self._poll()[:, 1] != 0
 

@@ -103,6 +103,57 @@ class Transport:
 		return t.cpu().numpy()
 
 
+class RcclTransport:
+	"""
+	The same three transfers through the C ABI's own RCCL layer (`rk_comm_*`, include/rubiks_hip.h) instead of
+	torch.distributed: what a caller of the shared library without torch.distributed uses (route B).
+	Rank 0 obtains the 128-byte id with `RcclTransport.unique_id()` and hands it to the other ranks by any means (a file, a
+	socket, MPI); every rank then constructs `RcclTransport(id, rank, world)` -- a collective call.  Device buffers only,
+	on the current stream, nothing synchronises.  `ShardedAStar(..., transport=...)` takes it.
+	"""
+	on_device, backend, active = True, "rccl (rk_comm)", True
+
+	@staticmethod
+	def unique_id() -> bytes:
+		buf = C.create_string_buffer(128)
+		_ffi.check(_ffi.lib().rk_comm_unique_id(buf))
+		return buf.raw
+
+	def __init__(self, unique_id: bytes, rank: int, world: int):
+		if len(unique_id) != 128:
+			raise ValueError("the RCCL unique id is 128 bytes")
+		_ffi.require_gpu()
+		h = C.c_void_p()
+		_ffi.check(_ffi.lib().rk_comm_create(C.byref(h), unique_id, int(rank), int(world)))
+		self._h, self.rank, self.world = h, int(rank), int(world)
+		self.shortcut = False                      # the collectives always run, also with one rank: that is how a one-GPU box tests them
+		self.collectives = 0
+
+	def __del__(self):
+		try:
+			if getattr(self, "_h", None) is not None:
+				_ffi.lib().rk_comm_destroy(self._h)
+				self._h = None
+		except Exception:
+			pass
+
+	def all_gather(self, mine: torch.Tensor) -> torch.Tensor:
+		self.collectives += 1
+		out = torch.empty((self.world, mine.numel()), dtype=mine.dtype, device=mine.device)
+		_ffi.check(_ffi.lib().rk_comm_all_gather(self._h, mine.data_ptr(), out.data_ptr(), mine.numel() * mine.element_size(), _ffi.stream_ptr()))
+		return out
+
+	def all_to_all(self, send: torch.Tensor, recv: torch.Tensor) -> torch.Tensor:
+		self.collectives += 1
+		_ffi.check(_ffi.lib().rk_comm_all_to_all(self._h, send.data_ptr(), recv.data_ptr(), send.shape[1] * send.element_size(), _ffi.stream_ptr()))
+		return recv
+
+	def broadcast_vec(self, vec: np.ndarray, src: int) -> np.ndarray:
+		t = torch.from_numpy(np.ascontiguousarray(vec, dtype=np.int64)).to(gpu)
+		_ffi.check(_ffi.lib().rk_comm_broadcast(self._h, t.data_ptr(), t.numel() * 8, int(src), _ffi.stream_ptr()))
+		return t.cpu().numpy()
+
+
 def select_pops(heads: np.ndarray, n: int) -> np.ndarray:
 	"""
 	Host statement of the selection rule the device kernel `k_shard_decide` implements (used by the tests as its spec):
@@ -124,11 +175,11 @@ class ShardedAStar(DeepAgent):
 	"""Collective agent: every rank constructs it and calls `search` with the same arguments."""
 
 	def __init__(self, net, lambda_: float, expansions: int, capacity: int = 2_000_000, group=None, force_collectives: bool = False,
-	             poll: int = 1, profile: bool = False, fused_first_layer=False):
+	             poll: int = 1, profile: bool = False, fused_first_layer=False, transport=None):
 		# fused_first_layer (True / "epilogue" / "folded"): the net's first Linear reads the new nodes' 20-byte states
 		super().__init__(net, fused_first_layer)
 		self.lambda_, self.expansions, self.capacity = lambda_, int(expansions), int(capacity)
-		self.tp = Transport(group, force_collectives)
+		self.tp = transport if transport is not None else Transport(group, force_collectives)      # torch.distributed unless told otherwise
 		self.poll = max(1, int(poll))
 		self.profile = profile                 # record device-time per phase (HIP events); read `self.phase_ms` afterwards
 		self.phase_ms = {}

@@ -405,3 +405,44 @@ def test_sharded_world1_with_fused_first_layer():
 	assert (states[1:n + 1] == one.states[1:n + 1]).all() and (G[1:n + 1] == one.G[1:n + 1]).all()
 	if a:
 		assert list(one.action_queue) == list(many.action_queue)
+
+
+def _rk_comm_world1(rank, out_path, case):
+	"""One rank over the C ABI's own RCCL layer (rk_comm_*): no torch.distributed anywhere in this process."""
+	from librubiks_amd.solving.sharded import RcclTransport
+	torch.cuda.set_device(0)
+	seed, depth, lam, n, budget = case
+	np.random.seed(seed)
+	start, _, _ = orc.scramble(depth, True)
+	tp = RcclTransport(RcclTransport.unique_id(), 0, 1)
+	agent = ShardedAStar(StubNet(), lam, n, capacity=budget + 16, transport=tp)
+	assert not agent.tp.shortcut and agent.tp.on_device
+	solved = agent.search(start, None, budget)
+	states, G, parents, pact = agent.local_arrays()
+	# the raw transfers, checked on known bytes: all-gather and all-to-all of one rank are copies, broadcast leaves the buffer alone
+	a = torch.arange(40, dtype=torch.float64, device="cuda")
+	assert torch.equal(tp.all_gather(a)[0], a)
+	s, r = torch.randint(0, 255, (1, 4096), dtype=torch.uint8, device="cuda"), torch.zeros((1, 4096), dtype=torch.uint8, device="cuda")
+	assert torch.equal(tp.all_to_all(s, r), s)
+	assert tp.broadcast_vec(np.array([3, 5, 7]), 0).tolist() == [3, 5, 7]
+	np.savez(out_path, solved=solved, states=states[1:], G=G[1:], parents=parents[2:], pact=pact[2:], queue=np.array(agent.action_queue, dtype=np.int64),
+	         collectives=tp.collectives, iters=agent.iterations)
+
+
+def test_rk_comm_transport_world1(tmp_path):
+	"""the hash-sharded search driven through rk_comm_* (RCCL behind the C ABI) instead of torch.distributed --
+	the route a ctypes-only caller takes to configs[4].  One rank on the one-GPU box: the collectives really run (all-gather,
+	grouped send/recv, broadcast on device buffers) and the search equals the oracle's, array by array."""
+	case = (19, 7, 0.1, 300, 60_000)
+	out = str(tmp_path / "rkcomm.npz")
+	mp.spawn(_rk_comm_world1, args=(out, case), nprocs=1, join=True)
+	z = np.load(out)
+	seed, depth, lam, n, budget = case
+	np.random.seed(seed)
+	start, _, _ = orc.scramble(depth, True)
+	ref = AStarOracle(StubNet(), lam, n)
+	assert ref.search(start, budget) == bool(z["solved"])
+	rs, rG, rp, ra = ref.arrays()
+	assert (z["states"] == rs).all() and (z["G"] == rG).all() and (z["parents"] == rp).all() and (z["pact"] == ra).all()
+	assert z["queue"].tolist() == list(ref.action_queue)
+	assert int(z["collectives"]) >= 2 * int(z["iters"])                        # two collectives per iteration went through RCCL
