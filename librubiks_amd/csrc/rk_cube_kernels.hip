@@ -527,20 +527,34 @@ void k_multi_rotate(const uint32_t *__restrict__ states, const uint8_t *__restri
 	__shared__ u32x4 s_buf[ROW_WAVES][320];       // 5 120 B per wave
 
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const size_t first_tile = (size_t)blockIdx.x * ROW_WAVES + wv;
+	// the first tile's states are requested before the move tables are staged (a wave of the usual one-tile grid would
+	// otherwise wait for the table's round trip and only then start its own)
+	u32x4 pre[5];
+	const bool have_pre = first_tile < n_tiles && n - first_tile * ROW_TILE >= (size_t)ROW_TILE
+	                      && ((reinterpret_cast<uintptr_t>(states + first_tile * ROW_TILE * STATE_DWORDS) & 15) == 0);
+	if (have_pre) {
+		const u32x4 *src4 = reinterpret_cast<const u32x4 *>(states + first_tile * ROW_TILE * STATE_DWORDS);
+		#pragma unroll
+		for (int k = 0; k < 5; k++) pre[k] = src4[k * 64 + lane];
+	}
 	stage_action_tables(s_act, tid);
 	__syncthreads();
 
 	u32x4 *buf = s_buf[wv];
 	uint32_t *buf_dw = reinterpret_cast<uint32_t *>(buf);
 
-	for (size_t tile = (size_t)blockIdx.x * ROW_WAVES + wv; tile < n_tiles; tile += (size_t)gridDim.x * ROW_WAVES) {
+	for (size_t tile = first_tile; tile < n_tiles; tile += (size_t)gridDim.x * ROW_WAVES) {
 		const size_t p0 = tile * ROW_TILE;
 		const int np = (int)((n - p0 < (size_t)ROW_TILE) ? (n - p0) : (size_t)ROW_TILE);
 		const uint32_t *src = states + p0 * STATE_DWORDS;
 		uint32_t *dst = out + p0 * STATE_DWORDS;
 		const bool full = np == ROW_TILE && (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0);
 
-		if (full) {
+		if (tile == first_tile && have_pre) {
+			#pragma unroll
+			for (int k = 0; k < 5; k++) buf[k * 64 + lane] = pre[k];
+		} else if (full) {
 			const u32x4 *src4 = reinterpret_cast<const u32x4 *>(src);
 			#pragma unroll
 			for (int k = 0; k < 5; k++) buf[k * 64 + lane] = src4[k * 64 + lane];
@@ -552,14 +566,23 @@ void k_multi_rotate(const uint32_t *__restrict__ states, const uint8_t *__restri
 				buf_dw[idx] = idx < ndw ? src[idx] : 0u;
 			}
 		}
-		// the four actions of this lane's states
+		// the four actions of this lane's states: one dword per lane when the tile is whole and the codes are aligned
 		uint32_t act[4];
-		#pragma unroll
-		for (int q = 0; q < 4; q++) {
-			const size_t i = p0 + 4 * lane + q;
-			uint32_t a = 0;
-			if (4 * lane + q < np) a = SPLIT_FD ? (2u * act_or_faces[i] + (1u - dirs[i])) : act_or_faces[i];
-			act[q] = a < 12u ? a : 0u;            // out-of-range actions are rejected on the host; never index past the table
+		if (!SPLIT_FD && np == ROW_TILE && ((reinterpret_cast<uintptr_t>(act_or_faces + p0) & 3) == 0)) {
+			const uint32_t w = reinterpret_cast<const uint32_t *>(act_or_faces + p0)[lane];
+			#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				const uint32_t a = (w >> (8 * q)) & 0xFFu;
+				act[q] = a < 12u ? a : 0u;
+			}
+		} else {
+			#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				const size_t i = p0 + 4 * lane + q;
+				uint32_t a = 0;
+				if (4 * lane + q < np) a = SPLIT_FD ? (2u * act_or_faces[i] + (1u - dirs[i])) : act_or_faces[i];
+				act[q] = a < 12u ? a : 0u;            // out-of-range actions are rejected on the host; never index past the table
+			}
 		}
 		wave_lds_fence();
 

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -387,8 +388,10 @@ void k_mcts_backup_select(MctsDev d, const void *probs, const void *values, int 
 	// One round of loads per tree level: the leaf flag and the node's five rows are requested together, and the virtual
 	// loss the previous step owes this node's reverse edge (agents.py:591) is applied on arrival by the lane that owns
 	// that column, so there is no second dependent round trip for the read-modify-write.
-	// (Tried in round 2 and dropped: touching all 12 children's records as soon as `neighbors` arrives, to overlap the
-	// next level's miss with this level's f64 arithmetic -- 31.7 us against 30.6 us without it; and a copy of the previous
+	// (Tried and dropped: touching all 12 children's records as soon as `neighbors` arrives, to overlap the next level's miss
+	// with this level's f64 arithmetic -- round 2, first 256 simulations: 31.7 us against 30.6 us without it; round 3, one wave
+	// instruction fetching all four lines of all twelve children, whole 4096-simulation runs: 0.1618 against 0.1594 ms per
+	// step (profiles/r03_mcts_variants.json).  And a copy of the previous
 	// path's records in LDS (56 KB, two records per wave instruction) from which the descent reads while it follows
 	// that path: 54.7 us against 49.4 us per simulation over 4096 simulations -- the copy costs more than the hits save.)
 	int cur = 1, len = 1, owed_lane = -1;

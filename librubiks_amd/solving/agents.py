@@ -688,11 +688,24 @@ class MCTSBatch(DeepAgent):
 	def search(self, states: np.ndarray, time_limit: float = None, max_states=None, max_sims: int = None,
 	           use_graph: bool = False, poll: int = 16) -> np.ndarray:
 		"""Runs all trees until each is solved or out of budget; returns the bool vector `solved` (T,)."""
-		_ffi.require_gpu()
 		t0 = time.perf_counter()
 		assert time_limit or max_states is not None or max_sims
-		self.net.eval()
 		time_limit = time_limit or 1e10
+		self._begin(states, max_states, max_sims, use_graph)
+		while time.perf_counter() - t0 < time_limit and (max_sims is None or self.simulations < max_sims):
+			self._advance(poll if max_sims is None else min(poll, max_sims - self.simulations))
+			if self._poll()[:, 0].all():
+				break
+		return self._finish()
+
+	# The three stages of a search.  Everything is enqueued on the CURRENT stream, so several engines can be advanced in turn on
+	# streams of their own (tried in round 3 with 2 and 4 engines sharing the 256 trees, so that one engine's descent would
+	# overlap the others' net forwards: 0.166 and 0.242 ms per 256-tree step against 0.159 with one engine,
+	# profiles/r03_mcts_variants.json -- the small GEMMs of the halves do not overlap each other; dropped).
+	@no_grad
+	def _begin(self, states: np.ndarray, max_states, max_sims, use_graph: bool):
+		_ffi.require_gpu()
+		self.net.eval()
 		states = np.ascontiguousarray(states, dtype=np.int8).reshape(self.n_trees, 20)
 		if max_states is None:
 			max_states = self.capacity
@@ -715,8 +728,8 @@ class MCTSBatch(DeepAgent):
 		# every backup + select launch also expands the leaf it found, while another simulation is to follow
 		_ffi.check(lib.rk_mcts_set_expand_ahead(h, int(max_sims) if max_sims is not None else -1))
 		self.simulations = 0
-		graph = None
-		if use_graph:
+		self._max_sims, self._oh, self._graph = max_sims, oh, None
+		if use_graph and (max_sims is None or max_sims > 2):
 			side = torch.cuda.Stream()
 			side.wait_stream(torch.cuda.current_stream())
 			with torch.cuda.stream(side):
@@ -724,24 +737,26 @@ class MCTSBatch(DeepAgent):
 					self._step(oh, h)
 					self.simulations += 1
 			torch.cuda.current_stream().wait_stream(side)
-			graph = torch.cuda.CUDAGraph()
-			with torch.cuda.graph(graph):
+			self._graph = torch.cuda.CUDAGraph()
+			with torch.cuda.graph(self._graph):
 				self._step(oh, h)
-		while time.perf_counter() - t0 < time_limit and (max_sims is None or self.simulations < max_sims):
-			burst = poll if max_sims is None else min(poll, max_sims - self.simulations)
-			for _ in range(burst):
-				if graph is not None:
-					graph.replay()
-				else:
-					self._step(oh, h)
-			self.simulations += burst
-			if self._poll()[:, 0].all():
-				break
-		_ffi.check(lib.rk_mcts_set_expand_ahead(h, 0))
-		if (max_sims is None or self.simulations < max_sims) and not self._poll()[:, 0].all():
-			# out of time with leaves expanded ahead: one more step (net + backup, no further expansion) completes them, so
-			# that every tree is the reference's tree after a whole number of simulations
-			self._step(oh, h)
+
+	@no_grad
+	def _advance(self, n: int):
+		for _ in range(n):
+			if self._graph is not None:
+				self._graph.replay()
+			else:
+				self._step(self._oh, self._h)
+		self.simulations += n
+
+	@no_grad
+	def _finish(self) -> np.ndarray:
+		_ffi.check(_ffi.lib().rk_mcts_set_expand_ahead(self._h, 0))
+		if (self._max_sims is None or self.simulations < self._max_sims) and not self._poll()[:, 0].all():
+			# stopped early (time) with leaves expanded ahead: one more step (net + backup, no further expansion) completes
+			# them, so that every tree is the reference's tree after a whole number of simulations
+			self._step(self._oh, self._h)
 			self.simulations += 1
 		st = self._poll()
 		return st[:, 1] != 0
