@@ -148,11 +148,24 @@ def check(rc: int):
 		raise RubiksHipError(f"librubiks_hip error {rc}: {lib().rk_last_error().decode()}")
 
 
+_gpu_seen = False
+
+
 def require_gpu():
-	if not torch.cuda.is_available():
-		raise RubiksHipError("no HIP device visible: librubiks_amd computes only on a gfx950 GPU (no CPU fallback)")
+	global _gpu_seen
+	if not _gpu_seen:                      # asked once: a device does not disappear, and the question costs a microsecond per launch
+		if not torch.cuda.is_available():
+			raise RubiksHipError("no HIP device visible: librubiks_amd computes only on a gfx950 GPU (no CPU fallback)")
+		_gpu_seen = True
+
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
 def stream_ptr() -> int:
-	"""hipStream_t of torch's current stream, so that kernels order with the caller's torch work."""
+	"""hipStream_t of torch's current stream, so that kernels order with the caller's torch work.  (The raw accessor skips
+	building a torch.cuda.Stream object: a launch through this shim costs the host about 8 us -- profiles/r03_kernels.json,
+	"LAUNCH FLOOR" -- and a third of that was this call.)"""
+	if _raw_stream is not None:
+		return _raw_stream(torch.cuda.current_device())
 	return torch.cuda.current_stream().cuda_stream

@@ -1166,12 +1166,12 @@ void launch_expand12_variant(int variant, const int8_t *parents, int8_t *childre
 // Shipping shapes (benchmarks/tune_expand.py, profiles/r03_tune_sizes.json: every size measured with the parents coming
 // from HBM -- inputs rotating over >= 640 MB --, 250 k ... 32 M parents, fraction of the 8 TB/s peak, round-2 kernel first):
 //   parents      r02 kernel   one tile per wave (depth 0)   ring 2, grid = tiles/8   ring 2, 3 072 workgroups
-//   250 k        0.54         0.62                          0.63                     0.53
-//   500 k        0.62         0.65                          0.70                     0.63
-//   1 M          0.71         0.70                          0.68                     0.73
-//   2 M          0.74         0.76                          0.75                     0.75
-//   4 M / 8 M    0.74 / 0.71  0.78 / 0.78                   0.72 / 0.70              0.73 / 0.70
-//   16 M / 32 M  0.76 / 0.74  0.75 / 0.77                   0.79 / 0.74              0.78 / 0.74
+//   250 k        0.54         0.61                          0.62                     0.53
+//   500 k        0.62         0.64                          0.68                     0.63
+//   1 M          0.70         0.70                          0.67                     0.72
+//   2 M / 4 M    0.68 / 0.67  0.74 / 0.76                   0.67 / 0.67              0.67 / 0.66
+//   8 M          0.77         0.78                          0.79                     0.78
+//   16 M / 32 M  0.75 / 0.74  0.79 / 0.78                   0.74 / 0.76              0.75 / 0.75
 // A grid with ONE tile per wave wins wherever there are many more tiles than resident waves (2 048): fresh workgroups
 // dispatched in address order keep the write front dense.  Around 1 M parents (a handful of tiles per resident wave) a
 // persistent grid whose waves keep the next two tiles' parents in flight hides the HBM read latency that a one-tile wave
