@@ -122,6 +122,9 @@ def bench_astar_batch(args):
 	row = {"bench": "astar_batch", "config": f"{S} depth-{args.depth} scrambles, lambda={args.lam}, N={args.expansions}, max_states={args.max_states} each, "
 	       f"fc_small random init {'bf16' if args.bf16 else 'fp32'}" + FUSED_NOTE[args.fused]
 	       + (f", net forwards of at most {args.slice} rows" if args.slice > 0 else ", ONE net forward on the whole padded batch" if args.slice == 0 else ", net forwards of whole searches (the agent's default: one search per forward from K = 4096 rows on, else up to 16384 rows)"), **out,
+	       "modes": "sequential = AStar, one search after the other; batch = AStarBatch, eager, net on the searches' NEW rows compacted on the device "
+	                "(exact_batch, the default for a real net); batch+graph = AStarBatch on the padded batch, iteration replayed as a hipGraph",
+	       "speedup_batch_vs_sequential": out["sequential"]["seconds"] / out["batch"]["seconds"],
 	       "speedup_batch_graph_vs_sequential": out["sequential"]["seconds"] / out["batch+graph"]["seconds"]}
 	print(json.dumps(row), flush=True)
 	return row

@@ -226,6 +226,13 @@ int rk_astarb_destroy(rk_astarb_t *h);
 int rk_astarb_reset(rk_astarb_t *h, const int8_t *h_start_states, const long long *h_max_states, double lambda, void *stream);
 int rk_astarb_set_values_dtype(rk_astarb_t *h, int dtype, void *stream);
 int rk_astarb_step_expand(rk_astarb_t *h, void *d_onehot, int out_dtype, void *stream);
+/* The same step with the net's rows COMPACTED across the searches: only the NEW states of every search, one search after
+ * the other (each search's first row rounded up to a multiple of 4 rows), and their total copied asynchronously into
+ * (pinned) host memory at h_total.  The caller waits for the count (an event recorded behind this call), runs the net on
+ * that many rows and commits values laid out the same way: the net never sees a padded row -- what the sequential
+ * `AStar` does for a float32 net (agents.py:315, :369-383 evaluate exactly the new states).  One host wait per iteration;
+ * not capturable in a hipGraph (the batch size varies). */
+int rk_astarb_step_expand_compact(rk_astarb_t *h, void *d_rows, int out_dtype, int *h_total, void *stream);
 int rk_astarb_step_commit(rk_astarb_t *h, const float *d_values, void *stream);
 int rk_astarb_status(rk_astarb_t *h, long long *h_status, void *stream);
 int rk_astarb_export(rk_astarb_t *h, int search, size_t first, size_t count, int8_t *h_states, double *h_G,

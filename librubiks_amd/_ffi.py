@@ -73,6 +73,7 @@ SIGNATURES = {
 	"rk_astarb_reset": (_i, [_vp, _vp, _vp, C.c_double, _vp]),
 	"rk_astarb_set_values_dtype": (_i, [_vp, _i, _vp]),
 	"rk_astarb_step_expand": (_i, [_vp, _vp, _i, _vp]),
+	"rk_astarb_step_expand_compact": (_i, [_vp, _vp, _i, _vp, _vp]),
 	"rk_astarb_step_commit": (_i, [_vp, _vp, _vp]),
 	"rk_astarb_status": (_i, [_vp, _vp, _vp]),
 	"rk_astarb_export": (_i, [_vp, _i, _sz, _sz, _vp, _vp, _vp, _vp, _vp]),

@@ -384,13 +384,45 @@ void k_new_rows(AstarDev d, u32x4 *out, uint32_t one_bits, const uint8_t *recv)
 {
 	new_rows_body<ELEM_BYTES, SHARDED>(d, out, one_bits, recv);
 }
+// row_off (batched engines, compact mode): row_off[s] = first row of search s in the shared net batch when only the NEW rows
+// of every search are laid out, one search after the other (exclusive prefix of the searches' new-state counts; row_off[S] =
+// their total).  Null: search s owns rows s K ... s K + K - 1 (padded).  A row offset must keep 16-byte alignment: offsets
+// are rounded up to multiples of 4 rows, which it does for every row type (20-byte states: 80 bytes).
+__global__ __launch_bounds__(1024)
+void kb_row_offsets(const AstarDev *__restrict__ devs, int S, int32_t *__restrict__ row_off)
+{
+	__shared__ int s_part[1024];
+	__shared__ int s_carry;
+	const int tid = threadIdx.x;
+	if (tid == 0) s_carry = 0;
+	__syncthreads();
+	for (int base = 0; base < S; base += 1024) {
+		const int s = base + tid;
+		const int mine = s < S ? ((devs[s].ctr[C_NNEW] + 3) & ~3) : 0;
+		s_part[tid] = mine;
+		__syncthreads();
+		for (int off = 1; off < 1024; off <<= 1) {                          // inclusive scan (Hillis-Steele): S is small
+			const int v = tid >= off ? s_part[tid - off] : 0;
+			__syncthreads();
+			s_part[tid] += v;
+			__syncthreads();
+		}
+		if (s < S) row_off[s] = s_carry + s_part[tid] - mine;
+		__syncthreads();
+		if (tid == 1023) s_carry += s_part[1023];
+		__syncthreads();
+	}
+	if (tid == 0) row_off[S] = s_carry;
+}
+
 template <int ELEM_BYTES, bool SHARDED>
 __global__ __launch_bounds__(256)
-void kb_new_rows(const AstarDev *__restrict__ devs, u32x4 *out, uint32_t one_bits, const uint8_t *recv)
+void kb_new_rows(const AstarDev *__restrict__ devs, u32x4 *out, uint32_t one_bits, const uint8_t *recv, const int32_t *__restrict__ row_off)
 {
 	const AstarDev d = devs[blockIdx.y];              // search blockIdx.y of the batch (rk_astarb_*)
-	// this search's K rows of the shared net batch: 480 elements (30 * ELEM_BYTES 16-byte chunks) or 20 bytes (K = 12 N: 15 N chunks) each
-	if (out != nullptr) out += (size_t)blockIdx.y * (ELEM_BYTES == 0 ? (size_t)d.K * 5 / 4 : (size_t)d.K * 30 * ELEM_BYTES);
+	// this search's rows of the shared net batch: 480 elements (30 * ELEM_BYTES 16-byte chunks) or 20 bytes (5/4 chunks) each
+	const size_t first_row = row_off != nullptr ? (size_t)row_off[blockIdx.y] : (size_t)blockIdx.y * d.K;
+	if (out != nullptr) out += ELEM_BYTES == 0 ? first_row * 5 / 4 : first_row * 30 * ELEM_BYTES;
 	new_rows_body<ELEM_BYTES, SHARDED>(d, out, one_bits, recv);
 }
 
@@ -567,10 +599,11 @@ void k_records_sort(AstarDev d, const float *values)
 }
 template <int CHUNK>
 __global__ __launch_bounds__(CHUNK / 2)
-void kb_records_sort(const AstarDev *__restrict__ devs, const float *values)
+void kb_records_sort(const AstarDev *__restrict__ devs, const float *values, const int32_t *__restrict__ row_off)
 {
 	const AstarDev d = devs[blockIdx.y];              // search blockIdx.y of the batch (rk_astarb_*)
-	values = reinterpret_cast<const float *>(reinterpret_cast<const char *>(values) + (size_t)blockIdx.y * d.K * (d.values_bf16 ? 2 : 4));
+	const size_t first_row = row_off != nullptr ? (size_t)row_off[blockIdx.y] : (size_t)blockIdx.y * d.K;
+	values = reinterpret_cast<const float *>(reinterpret_cast<const char *>(values) + first_row * (d.values_bf16 ? 2 : 4));
 	records_sort_body<CHUNK>(d, values);
 }
 
@@ -1679,7 +1712,8 @@ struct rk_astarb {
 	std::vector<rk_astar *> eng;
 	std::vector<uint8_t> start_solved;
 	AstarDev *devs = nullptr;                     // device copy of every engine's descriptor
-	bool ready = false, pending = false;
+	int32_t *row_off = nullptr;                   // compact mode: S + 1 row offsets of the pending step
+	bool ready = false, pending = false, compact = false;
 };
 
 static int astarb_upload(rk_astarb *b, hipStream_t st)
@@ -1707,7 +1741,8 @@ int rk_astarb_create(rk_astarb_t **out, int n_searches, size_t capacity_per_sear
 		if (rc) { rk_astarb_destroy(b); return rc; }
 		b->eng.push_back(e);
 	}
-	if (hipMalloc((void **)&b->devs, (size_t)n_searches * sizeof(AstarDev)) != hipSuccess) {
+	if (hipMalloc((void **)&b->devs, (size_t)n_searches * sizeof(AstarDev)) != hipSuccess ||
+	    hipMalloc((void **)&b->row_off, ((size_t)n_searches + 1) * sizeof(int32_t)) != hipSuccess) {
 		rk_astarb_destroy(b);
 		return fail(RK_EHIP, "rk_astarb_create: hipMalloc failed");
 	}
@@ -1720,6 +1755,7 @@ int rk_astarb_destroy(rk_astarb_t *b)
 	if (!b) return RK_OK;
 	for (rk_astar *e : b->eng) rk_astar_destroy(e);
 	(void)hipFree(b->devs);
+	(void)hipFree(b->row_off);
 	delete b;
 	return RK_OK;
 }
@@ -1762,7 +1798,24 @@ int rk_astarb_set_values_dtype(rk_astarb_t *b, int dtype, void *stream)
 	return astarb_upload(b, (hipStream_t)stream);
 }
 
+static int astarb_step_expand_impl(rk_astarb_t *b, void *d_onehot, int out_dtype, int *h_total, void *stream);
+
 int rk_astarb_step_expand(rk_astarb_t *b, void *d_onehot, int out_dtype, void *stream)
+{
+	return astarb_step_expand_impl(b, d_onehot, out_dtype, nullptr, stream);
+}
+
+/* The same step with the net's rows COMPACTED across the searches: only the new states of every search, one search after
+ * the other (each search's first row rounded up to a multiple of 4), and the total row count copied asynchronously into
+ * (pinned) host memory.  The caller waits for that count (an event behind this call), runs the net on that many rows and
+ * commits with values laid out the same way.  Not capturable in a hipGraph (the batch size varies). */
+int rk_astarb_step_expand_compact(rk_astarb_t *b, void *d_rows, int out_dtype, int *h_total, void *stream)
+{
+	if (!h_total) return fail(RK_EINVAL, "rk_astarb_step_expand_compact: null host pointer for the row count");
+	return astarb_step_expand_impl(b, d_rows, out_dtype, h_total, stream);
+}
+
+static int astarb_step_expand_impl(rk_astarb_t *b, void *d_onehot, int out_dtype, int *h_total, void *stream)
 {
 	if (!b || !b->ready) return fail(RK_ESTATE, "rk_astarb_step_expand: reset the engine first");
 	if (b->pending) return fail(RK_ESTATE, "rk_astarb_step_expand: previous step not committed");
@@ -1773,16 +1826,23 @@ int rk_astarb_step_expand(rk_astarb_t *b, void *d_onehot, int out_dtype, void *s
 	const unsigned S = (unsigned)b->S;
 	hipLaunchKernelGGL(kb_expand_lookup, dim3(blocks((size_t)d.K), S), dim3(256), 0, st, b->devs);
 	hipLaunchKernelGGL((kb_append<false>), dim3(blocks((size_t)d.K, ASCAN), S), dim3(ASCAN), 0, st, b->devs, (const uint8_t *)nullptr);
+	const int32_t *row_off = nullptr;
+	if (h_total != nullptr) {
+		hipLaunchKernelGGL(kb_row_offsets, dim3(1), dim3(1024), 0, st, b->devs, b->S, b->row_off);
+		RK_HIP(hipMemcpyAsync(h_total, b->row_off + b->S, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+		row_off = b->row_off;
+	}
 	const size_t chunks = (size_t)d.K * (out_dtype == RK_OH_F32 ? 120 : out_dtype == RK_OH_STATES ? 2 : 60);
 	const unsigned grid = std::min<unsigned>(blocks(chunks), 8192u);
 	if (out_dtype == RK_OH_F32)
-		hipLaunchKernelGGL((kb_new_rows<4, false>), dim3(grid, S), dim3(256), 0, st, b->devs, (u32x4 *)d_onehot, 0x3F800000u, (const uint8_t *)nullptr);
+		hipLaunchKernelGGL((kb_new_rows<4, false>), dim3(grid, S), dim3(256), 0, st, b->devs, (u32x4 *)d_onehot, 0x3F800000u, (const uint8_t *)nullptr, row_off);
 	else if (out_dtype == RK_OH_STATES)
-		hipLaunchKernelGGL((kb_new_rows<0, false>), dim3(grid, S), dim3(256), 0, st, b->devs, (u32x4 *)d_onehot, 0u, (const uint8_t *)nullptr);
+		hipLaunchKernelGGL((kb_new_rows<0, false>), dim3(grid, S), dim3(256), 0, st, b->devs, (u32x4 *)d_onehot, 0u, (const uint8_t *)nullptr, row_off);
 	else
-		hipLaunchKernelGGL((kb_new_rows<2, false>), dim3(grid, S), dim3(256), 0, st, b->devs, (u32x4 *)d_onehot, out_dtype == RK_OH_F16 ? 0x3C00u : 0x3F80u, (const uint8_t *)nullptr);
+		hipLaunchKernelGGL((kb_new_rows<2, false>), dim3(grid, S), dim3(256), 0, st, b->devs, (u32x4 *)d_onehot, out_dtype == RK_OH_F16 ? 0x3C00u : 0x3F80u, (const uint8_t *)nullptr, row_off);
 	RK_HIP(hipGetLastError());
 	b->pending = true;
+	b->compact = h_total != nullptr;
 	return RK_OK;
 }
 
@@ -1794,10 +1854,11 @@ int rk_astarb_step_commit(rk_astarb_t *b, const float *d_values, void *stream)
 	const AstarDev &d = b->eng[0]->d;
 	const unsigned S = (unsigned)b->S;
 	int from = 0;
+	const int32_t *row_off = b->compact ? b->row_off : nullptr;
 	if (d.chunk == SMALL_CHUNK) {
-		hipLaunchKernelGGL((kb_records_sort<SMALL_CHUNK>), dim3(d.Kpad / SMALL_CHUNK, S), dim3(SMALL_CHUNK / 2), 0, st, b->devs, d_values);
+		hipLaunchKernelGGL((kb_records_sort<SMALL_CHUNK>), dim3(d.Kpad / SMALL_CHUNK, S), dim3(SMALL_CHUNK / 2), 0, st, b->devs, d_values, row_off);
 	} else {
-		hipLaunchKernelGGL((kb_records_sort<SORT_CHUNK>), dim3(d.Kpad / SORT_CHUNK, S), dim3(SORT_CHUNK / 2), 0, st, b->devs, d_values);
+		hipLaunchKernelGGL((kb_records_sort<SORT_CHUNK>), dim3(d.Kpad / SORT_CHUNK, S), dim3(SORT_CHUNK / 2), 0, st, b->devs, d_values, row_off);
 		for (int L = SORT_CHUNK; L < d.Kpad && new_chunk_of(d.chunk, d.Kpad) == 0; L <<= 1) {
 			hipLaunchKernelGGL(kb_merge_pass, dim3(blocks(d.Kpad), S), dim3(256), 0, st, b->devs, L, from);
 			from ^= 1;

@@ -975,9 +975,32 @@ class AStarBatch(DeepAgent):
 		self.status = st
 		return st
 
+	def _step_exact(self, oh, code):
+		"""One iteration with the net's batch compacted to the searches' NEW rows (one host wait for their count)."""
+		lib, h = _ffi.lib(), self._h
+		_ffi.check(lib.rk_astarb_step_expand_compact(h, oh.data_ptr(), code, self._n_rows.data_ptr(), _ffi.stream_ptr()))
+		self._counted.record()
+		self._counted.synchronize()
+		rows = int(self._n_rows[0])
+		self.net_rows_total += rows
+		if rows == 0:
+			values = self._no_values
+		else:
+			v = _sliced_value_forward(self._fs or self.net, oh[:min(len(oh), -(-rows // 64) * 64)], self.net_slice_rows or 12_288)
+			if isinstance(v, torch.Tensor) and v.is_cuda and v.dtype == torch.bfloat16 and v.is_contiguous():
+				values, vcode = v.detach().reshape(-1), _ffi.OH_BF16
+			else:
+				values, vcode = _value_f32(v), _ffi.OH_F32
+			if vcode != self._vcode:
+				_ffi.check(lib.rk_astarb_set_values_dtype(h, vcode, _ffi.stream_ptr()))
+				self._vcode = vcode
+		self._keep = values
+		_ffi.check(lib.rk_astarb_step_commit(h, values.data_ptr(), _ffi.stream_ptr()))
+
 	def _step(self, oh, code):
 		lib, h = _ffi.lib(), self._h
 		_ffi.check(lib.rk_astarb_step_expand(h, oh.data_ptr(), code, _ffi.stream_ptr()))
+		self.net_rows_total += len(oh)
 		# rows per forward: whole searches, as many as fit NET_SLICE_ROWS -- and exactly ONE search per forward once a search's
 		# own batch is that large: then every forward has the shape a sequential AStar would give the net, so the batch can
 		# not lose to it through the library's kernel choice (measured at N = 1000, 64 searches, bf16 fc_small: hipBLASLt and
@@ -996,8 +1019,12 @@ class AStarBatch(DeepAgent):
 		_ffi.check(lib.rk_astarb_step_commit(h, values.data_ptr(), _ffi.stream_ptr()))
 
 	@no_grad
-	def search(self, states: np.ndarray, time_limit: float = None, max_states=None, use_graph: bool = False, poll: int = 8) -> np.ndarray:
-		"""Runs all searches until each is solved or out of budget / time; returns the bool vector `solved` (S,)."""
+	def search(self, states: np.ndarray, time_limit: float = None, max_states=None, use_graph: bool = False, poll: int = 8,
+	           exact_batch: bool = None) -> np.ndarray:
+		"""Runs all searches until each is solved or out of budget / time; returns the bool vector `solved` (S,).
+		exact_batch: evaluate the net on exactly the new states of all searches (compacted on the device, one host wait per
+		iteration) instead of on the padded (S * 12 N)-row batch.  Default: whenever the net is a torch module with parameters
+		(a forward then costs far more than the wait) and the iteration is not replayed as a hipGraph."""
 		_ffi.require_gpu()
 		t0 = time.perf_counter()
 		assert time_limit or max_states is not None
@@ -1019,6 +1046,15 @@ class AStarBatch(DeepAgent):
 			oh = torch.zeros((S * K, 480), dtype=oh_dtype, device=gpu)
 			code = _OH_CODES[oh_dtype]
 		self.iterations = 0
+		self.net_rows_total = 0
+		if exact_batch is None:
+			exact_batch = not use_graph and callable(getattr(self.net, "parameters", None)) and any(True for _ in self.net.parameters())
+		exact_batch = bool(exact_batch) and not use_graph
+		if exact_batch:
+			self._n_rows = torch.zeros(1, dtype=torch.int32).pin_memory()
+			self._counted = torch.cuda.Event()
+			self._no_values = torch.zeros(4, dtype=torch.float32, device=gpu)
+		step = self._step_exact if exact_batch else self._step
 		graph = None
 		if use_graph:
 			side = torch.cuda.Stream()
@@ -1043,7 +1079,7 @@ class AStarBatch(DeepAgent):
 				if graph is not None:
 					graph.replay()
 				else:
-					self._step(oh, code)
+					step(oh, code)
 			self.iterations += burst
 			st = self._poll()
 			live, n_states = st[:, 0] == 0, st[:, 2]

@@ -154,6 +154,14 @@ class RcclTransport:
 		return t.cpu().numpy()
 
 
+def first_piece_rows(K: int, world: int) -> int:
+	"""Rows of a rank's net batch that are evaluated without waiting for the iteration's new-state count: all K = 12 N with one
+	rank (nothing ever waits), else a rank's expected share ceil(K / world) rounded up to 64, never more than K."""
+	if world <= 1:
+		return K
+	return min(K, -(-(-(-K // world)) // 64) * 64)
+
+
 def select_pops(heads: np.ndarray, n: int) -> np.ndarray:
 	"""
 	Host statement of the selection rule the device kernel `k_shard_decide` implements (used by the tests as its spec):
@@ -227,7 +235,7 @@ class ShardedAStar(DeepAgent):
 		_ffi.check(lib.rk_astar_shard_reset(h, state.ctypes.data, float(self.lambda_), send.data_ptr(), st()))
 		root_owner = lib.rk_shard_owner(state.ctypes.data, tp.world)
 		K = 12 * N                                                       # upper bound of a rank's new states per iteration
-		first = K if tp.world == 1 else min(K, -(-(-(-K // tp.world)) // 64) * 64)   # rows evaluated without waiting for the count
+		first = first_piece_rows(K, tp.world)                            # rows evaluated without waiting for the count
 		self._fs = self._from_states                                     # re-copied here if the net changed since the last search
 		if self._fs is not None:
 			oh = torch.from_numpy(cube.repeat_state(cube.get_solved(), K)).to(gpu)                     # rows = states

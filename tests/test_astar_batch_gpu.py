@@ -30,8 +30,10 @@ def test_batch_of_one_reproduces_reference_traces(golden, tag):
 	assert list(agent.action_queue_of(0)) == t[f"{tag}_action_queue"].tolist()
 
 
-@pytest.mark.parametrize("use_graph,n", [(False, 10), (True, 10), (False, 200), (True, 200)])
-def test_batch_equals_oracle_per_search(use_graph, n):
+@pytest.mark.parametrize("use_graph,n,exact", [(False, 10, False), (True, 10, False), (False, 200, False), (True, 200, False),
+                                               (False, 10, True), (False, 200, True), (False, 1000, True)])
+def test_batch_equals_oracle_per_search(use_graph, n, exact):
+	"""exact: the net's batch compacted to the searches' new rows (rk_astarb_step_expand_compact) instead of the padded batch."""
 	S, lam = 10, 0.3
 	starts, budgets = [], []
 	for i in range(S):
@@ -41,7 +43,9 @@ def test_batch_equals_oracle_per_search(use_graph, n):
 	starts = np.array(starts)
 	starts[4] = orc.SOLVED
 	agent = AStarBatch(StubNet(), lam, n, S, capacity=max(budgets))
-	solved = agent.search(starts, max_states=np.array(budgets), use_graph=use_graph, poll=4)
+	solved = agent.search(starts, max_states=np.array(budgets), use_graph=use_graph, poll=4, exact_batch=exact)
+	if exact:                                                            # fewer rows than the padded batch went through the net
+		assert 0 < agent.net_rows_total < agent.iterations * S * 12 * n
 	n_solved = 0
 	for i in range(S):
 		ref = AStarOracle(StubNet(), lam, n)
@@ -73,8 +77,14 @@ def test_batch_with_a_bf16_net(fused):
 	starts = np.array(starts)
 	budgets = np.array([4000 + 1000 * i for i in range(S)])
 	agent = AStarBatch(net, 0.3, n, S, capacity=int(budgets.max()), fused_first_layer=fused)
-	solved = agent.search(starts, max_states=budgets, use_graph=True, poll=4)
-	assert solved[:2].all()                                              # two and three moves from solved
+	for use_graph in (True, False):                                      # replayed on the padded batch; eager on the compacted new rows (the default for a real net)
+		solved = agent.search(starts, max_states=budgets, use_graph=use_graph, poll=4)
+		assert solved[:2].all()                                          # two and three moves from solved
+		_check_invariants(agent, starts, budgets, solved)
+
+
+def _check_invariants(agent, starts, budgets, solved):
+	S = len(starts)
 	for i in range(S):
 		states, G, parents, pact = agent.arrays_of(i)
 		m = len(states) - 1
