@@ -48,6 +48,8 @@ NAMES = {0: "nt, tile256", 1: "plain, tile256", 3: "plain, tile64",
          124: "RING form, 4 tiles in flight, non-temporal parent loads", 128: "RING form, 8 tiles in flight, non-temporal parent loads",
          200: "READ PHASE THEN WRITE PHASE: touch <= 8 M parents (pure read stream into the Infinity Cache), then one-shot ring-0 expand of them",
          202: "READ PHASE THEN WRITE PHASE: touch <= 8 M parents, then persistent ring-2 expand of them",
+         152: "RING form, depth 0, stores sc1", 153: "RING form, depth 0, stores sc0 sc1 (write-through)", 154: "RING form, depth 0, stores sc1 nt",
+         162: "RING form, 2 tiles in flight, stores sc1", 163: "RING form, 2 tiles in flight, stores sc0 sc1 (write-through)", 164: "RING form, 2 tiles in flight, stores sc1 nt",
          141: "RING form, 1 tile in flight, plain stores", 142: "RING form, 2 tiles in flight, plain stores", 144: "RING form, 4 tiles in flight, plain stores"}
 # (dropped from the code after losing clearly, results kept in profiles/r01_tune_expand*.json: atomic tile counter on a
 #  persistent grid, per-lane strided input loads)

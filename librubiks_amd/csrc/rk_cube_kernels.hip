@@ -236,6 +236,23 @@ void k_expand12(const uint32_t *__restrict__ parents, u32x4 *__restrict__ childr
 // of the next DEPTH tiles of the wave are in flight in registers (a ring, the loop unrolled DEPTH times so that the
 // ring index is static), and the ragged last tile takes a separate predicated path after the loop.
 // ================================================================================================================
+// 16-byte store with a cache policy.  SP 0 plain, 1 non-temporal (`nt`; what ships); the others exist for the tuning build's
+// A/B (benchmarks/tune_expand.py): 2 `sc1`, 3 `sc0 sc1` (write-through: the line leaves the XCD's L2 at once), 4 `sc1 nt`.
+// They go through a raw buffer store so that the compiler still counts them in vmcnt (an asm store would not be counted).
+template <int SP>
+__device__ __forceinline__ void store16(u32x4 *base /* the same in every lane */, int idx /* 16-byte words, per lane */, const u32x4 v)
+{
+	if (SP == 0) base[idx] = v;
+	else if (SP == 1) __builtin_nontemporal_store(v, base + idx);
+	else {
+		const uint64_t b = reinterpret_cast<uint64_t>(base);               // into SGPRs: a buffer descriptor is scalar
+		const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+		const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)hi << 32) | lo), 0, 1 << 20, 0x00020000);
+		constexpr int aux = SP == 2 ? 16 : SP == 3 ? 17 : 18;              // cache-policy bits: sc0 = 1, nt = 2, sc1 = 16
+		__builtin_amdgcn_raw_buffer_store_b128(v, rsrc, idx * 16, 0, aux);
+	}
+}
+
 struct ExpandCtx {
 	const u32x4 *rows;            // LDS: 48 rows of the per-cubie table
 	u32x4       *stage;           // LDS: this wave's 15 360-byte staging area (head doubles as input staging)
@@ -284,7 +301,7 @@ __device__ __forceinline__ void report_solved(const uint32_t fl[3], bool lane_va
 }
 
 // One FULL tile: raw[k] = dword k*64+lane of the tile's 1 280 bytes (already in registers).  No predicate anywhere.
-template <bool WITH_FLAGS, bool NT>
+template <bool WITH_FLAGS, int NT>
 __device__ __forceinline__ void expand_full_tile(const ExpandCtx &c, const uint32_t raw[5], size_t p0, u32x4 *__restrict__ children,
                                                  uint32_t *__restrict__ solved, long long *__restrict__ stats)
 {
@@ -311,16 +328,14 @@ __device__ __forceinline__ void expand_full_tile(const ExpandCtx &c, const uint3
 	#pragma unroll
 	for (int v = 0; v < 15; v++) {
 		const u32x4 val = c.stage[v * 64 + c.lane];
-		if (NT) __builtin_nontemporal_store(val, dst + v * 64 + c.lane);
-		else dst[v * 64 + c.lane] = val;
+		store16<NT>(dst, v * 64 + c.lane, val);
 	}
 	if (WITH_FLAGS) {
 		uint32_t *fdst = solved + p0 * 3;                  // p0 is a multiple of 64 -> 768-byte blocks, 16-byte aligned if the base is
 		if ((reinterpret_cast<uintptr_t>(fdst) & 15) == 0) {
 			if (c.lane < 48) {
 				const u32x4 val = reinterpret_cast<const u32x4 *>(c.flags)[c.lane];
-				if (NT) __builtin_nontemporal_store(val, reinterpret_cast<u32x4 *>(fdst) + c.lane);
-				else reinterpret_cast<u32x4 *>(fdst)[c.lane] = val;
+				store16<NT>(reinterpret_cast<u32x4 *>(fdst), c.lane, val);
 			}
 		} else {
 			#pragma unroll
@@ -332,7 +347,7 @@ __device__ __forceinline__ void expand_full_tile(const ExpandCtx &c, const uint3
 }
 
 // The ragged last tile (np < 64 parents): predicated, not pipelined.
-template <bool WITH_FLAGS, bool NT>
+template <bool WITH_FLAGS, int NT>
 __device__ __forceinline__ void expand_ragged_tile(const ExpandCtx &c, const uint32_t *__restrict__ parents, size_t p0, int np,
                                                    u32x4 *__restrict__ children, uint32_t *__restrict__ solved, long long *__restrict__ stats)
 {
@@ -367,8 +382,7 @@ __device__ __forceinline__ void expand_ragged_tile(const ExpandCtx &c, const uin
 		const int idx = v * 64 + c.lane;
 		if (idx < nvec) {
 			const u32x4 val = c.stage[idx];
-			if (NT) __builtin_nontemporal_store(val, dst + idx);
-			else dst[idx] = val;
+			store16<NT>(dst, idx, val);
 		}
 	}
 	if (WITH_FLAGS) {
@@ -385,7 +399,7 @@ __device__ __forceinline__ void expand_ragged_tile(const ExpandCtx &c, const uin
 
 // DEPTH = tiles of parents a wave keeps in flight (0: load, wait, expand -- for batches with one tile per wave).
 // NTL = non-temporal parent loads.
-template <bool WITH_FLAGS, int DEPTH, bool NT = true, bool NTL = false>
+template <bool WITH_FLAGS, int DEPTH, int NT = 1, bool NTL = false>
 __global__ __launch_bounds__(EXP_WAVES * WAVE)
 void k_expand12r(const uint32_t *__restrict__ parents, u32x4 *__restrict__ children, uint32_t *__restrict__ solved,
                  long long *__restrict__ stats, size_t n)
@@ -1138,6 +1152,21 @@ void launch_expand12_variant(int variant, const int8_t *parents, int8_t *childre
 			if (variant == 142) RK_RING(2, false, false);
 			if (variant == 144) RK_RING(4, false, false);
 			#undef RK_RING
+			break;
+		}
+		case 152: case 153: case 154: case 162: case 163: case 164: {       // store cache policies: sc1, sc0 sc1, sc1 nt (ring 0 one-shot / ring 2)
+			const size_t n_tiles = (n + EXP_ROUND - 1) / EXP_ROUND;
+			const bool ring = variant >= 160;
+			const unsigned grid = grid_blocks > 0 ? (unsigned)grid_blocks : grid_for(n_tiles, EXP_WAVES, ring ? (unsigned)EXP_GRID_PERSISTENT : (1u << 20));
+			#define RK_SP(DP, SP) hipLaunchKernelGGL((k_expand12r<true, DP, SP, false>), dim3(grid), dim3(EXP_WAVES * WAVE), 0, st, \
+				(const uint32_t *)parents, (u32x4 *)children, (uint32_t *)solved, stats, n)
+			if (variant == 152) RK_SP(0, 2);
+			if (variant == 153) RK_SP(0, 3);
+			if (variant == 154) RK_SP(0, 4);
+			if (variant == 162) RK_SP(2, 2);
+			if (variant == 163) RK_SP(2, 3);
+			if (variant == 164) RK_SP(2, 4);
+			#undef RK_SP
 			break;
 		}
 		case 200: case 202: {                                  // read phase then write phase: touch <= 8 M parents (160 MB), then expand them
