@@ -50,6 +50,8 @@ NAMES = {0: "nt, tile256", 1: "plain, tile256", 3: "plain, tile64",
          202: "READ PHASE THEN WRITE PHASE: touch <= 8 M parents, then persistent ring-2 expand of them",
          152: "RING form, depth 0, stores sc1", 153: "RING form, depth 0, stores sc0 sc1 (write-through)", 154: "RING form, depth 0, stores sc1 nt",
          162: "RING form, 2 tiles in flight, stores sc1", 163: "RING form, 2 tiles in flight, stores sc0 sc1 (write-through)", 164: "RING form, 2 tiles in flight, stores sc1 nt",
+         170: "RING form, depth 0 + 64 PULL workgroups in front (read the input once into the Infinity Cache)", 172: "RING form, 2 tiles in flight + 64 PULL workgroups",
+         174: "RING form, 2 tiles in flight + 32 PULL workgroups", 176: "RING form, 2 tiles in flight + 128 PULL workgroups",
          141: "RING form, 1 tile in flight, plain stores", 142: "RING form, 2 tiles in flight, plain stores", 144: "RING form, 4 tiles in flight, plain stores"}
 # (dropped from the code after losing clearly, results kept in profiles/r01_tune_expand*.json: atomic tile counter on a
 #  persistent grid, per-lane strided input loads)

@@ -399,7 +399,39 @@ __device__ __forceinline__ void expand_ragged_tile(const ExpandCtx &c, const uin
 
 // DEPTH = tiles of parents a wave keeps in flight (0: load, wait, expand -- for batches with one tile per wave).
 // NTL = non-temporal parent loads.
-template <bool WITH_FLAGS, int DEPTH, int NT = 1, bool NTL = false>
+// PULL > 0: the first PULL workgroups of the grid do not expand anything: they read the parent array once, front to back, as a
+// dense read-only stream (16 x 1 KiB in flight per wave) and throw the words away.  They are dispatched first, so the stream
+// runs in the first microseconds of the launch -- while the expanding workgroups are still waiting for their first tile and
+// no child has been written, i.e. while the HBM bus would be idle -- and it leaves the parents in the Infinity Cache: the
+// tile loads of every later workgroup are cache hits instead of HBM reads mixed into the write stream (the regime the
+// counters of DESIGN 3 show to cost 4-9 % at 1 M parents).  At most PULL_MAX_BYTES are pulled (what the cache holds with room
+// to spare); the expanding workgroups are blockIdx.x - PULL of gridDim.x - PULL.
+constexpr size_t PULL_MAX_BYTES = (size_t)96 << 20;
+
+__device__ __forceinline__ void pull_parents(const uint32_t *__restrict__ parents, size_t n, size_t wave, size_t n_waves, int lane)
+{
+	size_t bytes = n * STATE_BYTES;
+	bytes = bytes < PULL_MAX_BYTES ? bytes : PULL_MAX_BYTES;
+	if ((reinterpret_cast<uintptr_t>(parents) & 15) != 0 || bytes < 1024) return;
+	const u32x4 *src16 = reinterpret_cast<const u32x4 *>(parents);
+	const size_t last16 = bytes / 16 - 1, n_kib = (bytes + 1023) / 1024;
+	size_t c = wave;
+	u32x4 a[8], b[8];
+	#define RK_ISSUE(r) _Pragma("unroll") for (int j = 0; j < 8; j++) { const size_t i = c * 64 + lane; r[j] = src16[i < last16 ? i : last16]; c += n_waves; }
+	#define RK_EAT(r) _Pragma("unroll") for (int j = 0; j < 8; j++) asm volatile("" :: "v"(r[j].x), "v"(r[j].y), "v"(r[j].z), "v"(r[j].w) : "memory");
+	RK_ISSUE(a)
+	while (c < n_kib) {
+		RK_ISSUE(b)
+		RK_EAT(a)
+		RK_ISSUE(a)
+		RK_EAT(b)
+	}
+	RK_EAT(a)
+	#undef RK_ISSUE
+	#undef RK_EAT
+}
+
+template <bool WITH_FLAGS, int DEPTH, int NT = 1, bool NTL = false, int PULL = 0>
 __global__ __launch_bounds__(EXP_WAVES * WAVE)
 void k_expand12r(const uint32_t *__restrict__ parents, u32x4 *__restrict__ children, uint32_t *__restrict__ solved,
                  long long *__restrict__ stats, size_t n)
@@ -407,9 +439,13 @@ void k_expand12r(const uint32_t *__restrict__ parents, u32x4 *__restrict__ child
 	__shared__ u32x4 s_rows[48];
 	__shared__ ExpandWaveLdsT<1> s_wave[EXP_WAVES];
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	if (PULL > 0 && blockIdx.x < PULL) {                                 // the whole workgroup: no barrier has been reached yet
+		pull_parents(parents, n, (size_t)blockIdx.x * EXP_WAVES + wv, (size_t)PULL * EXP_WAVES, lane);
+		return;
+	}
 	const size_t n_full = n / EXP_ROUND;                               // tiles without a predicate
-	const size_t stride = (size_t)gridDim.x * EXP_WAVES;
-	const size_t first = (size_t)blockIdx.x * EXP_WAVES + wv;
+	const size_t stride = (size_t)(gridDim.x - PULL) * EXP_WAVES;
+	const size_t first = (size_t)(blockIdx.x - PULL) * EXP_WAVES + wv;
 	constexpr int D = DEPTH > 0 ? DEPTH : 1;
 	uint32_t ring[D][5];
 
@@ -1167,6 +1203,18 @@ void launch_expand12_variant(int variant, const int8_t *parents, int8_t *childre
 			if (variant == 163) RK_SP(2, 3);
 			if (variant == 164) RK_SP(2, 4);
 			#undef RK_SP
+			break;
+		}
+		case 170: case 172: case 174: case 176: {                         // ring form + PULL workgroups in front of the grid
+			const size_t n_tiles = (n + EXP_ROUND - 1) / EXP_ROUND;
+			const unsigned base = grid_blocks > 0 ? (unsigned)grid_blocks : grid_for(n_tiles, EXP_WAVES, variant == 170 ? (1u << 20) : (unsigned)EXP_GRID_PERSISTENT);
+			#define RK_PULL(DP, PL) hipLaunchKernelGGL((k_expand12r<true, DP, 1, false, PL>), dim3(base + (PL)), dim3(EXP_WAVES * WAVE), 0, st, \
+				(const uint32_t *)parents, (u32x4 *)children, (uint32_t *)solved, stats, n)
+			if (variant == 170) RK_PULL(0, 64);
+			if (variant == 172) RK_PULL(2, 64);
+			if (variant == 174) RK_PULL(2, 32);
+			if (variant == 176) RK_PULL(2, 128);
+			#undef RK_PULL
 			break;
 		}
 		case 200: case 202: {                                  // read phase then write phase: touch <= 8 M parents (160 MB), then expand them
