@@ -123,7 +123,6 @@ def main():
 		cube.device.multi_is_solved(rot[k[0] % 32], flags)
 	report("multi_rotate (per-state action), states rotating over 640 MB", 41 * n, timed(rot_rotate, 3 * args.reps), n, "transitions")
 	report("multi_is_solved, states rotating over 640 MB", 21 * n, timed(rot_solved, 3 * args.reps), n, "states")
-	del rot
 	report("multi_rotate on 12 M rows", 41 * 12 * n, timed(lambda: cube.device.multi_rotate(children, acts.repeat(12), children), 20), 12 * n, "transitions")
 	report("multi_is_solved", 21 * n, timed(lambda: cube.device.multi_is_solved(states, flags), args.reps), n, "states")
 	# the small launches again, replayed from a hipGraph (GPU pace, see timed_graph)
@@ -139,6 +138,31 @@ def main():
 	report("as_oh f32", (20 + 1920) * n_oh, timed(lambda: cube.device.as_oh(states[:n_oh], oh), 50), n_oh, "states")
 	report("as_oh bf16", (20 + 960) * n_oh, timed(lambda: cube.device.as_oh(states[:n_oh], oh16, torch.bfloat16), 50), n_oh, "states")
 	report("apply_sequences depth 20 (last state only)", (20 + 20) * n, timed(lambda: cube.device.apply_sequences(acts20, False, True), 50), 20 * n, "transitions")
+	# the large kernels again CACHE-NEUTRAL (the rows above reuse one 240 MB / 10 MB input every launch, which the 256 MiB Infinity
+	# Cache serves at least in part): three 240 MB row buffers in turn, one-hot inputs from the 32 rotating state sets, two outputs each
+	ch3 = [children, torch.empty_like(children), torch.empty_like(children)]
+	for c in ch3[1:]:
+		cube.device.expand12(rot[1], c, solved)
+	acts12 = acts.repeat(12)
+	def rot12_rotate():
+		k[0] += 1
+		cube.device.multi_rotate(ch3[k[0] % 3], acts12, ch3[k[0] % 3])
+	def rot12_solved():
+		k[0] += 1
+		cube.device.multi_is_solved(ch3[k[0] % 3], solved)
+	report("multi_rotate on 12 M rows, cache-neutral (3 buffers = 720 MB in turn)", 41 * 12 * n, timed(rot12_rotate, 30), 12 * n, "transitions")
+	report("multi_is_solved on 12 M rows, cache-neutral (3 buffers in turn)", 21 * 12 * n, timed(rot12_solved, 60), 12 * n, "states")
+	del ch3[1:]
+	oh_b, oh16_b = torch.empty_like(oh), torch.empty_like(oh16)
+	def rot_oh():
+		k[0] += 1
+		cube.device.as_oh(rot[k[0] % 32][:n_oh], (oh, oh_b)[k[0] % 2])
+	def rot_oh16():
+		k[0] += 1
+		cube.device.as_oh(rot[k[0] % 32][:n_oh], (oh16, oh16_b)[k[0] % 2], torch.bfloat16)
+	report("as_oh f32, cache-neutral (inputs over 32 sets, 2 outputs)", (20 + 1920) * n_oh, timed(rot_oh, 64), n_oh, "states")
+	report("as_oh bf16, cache-neutral (inputs over 32 sets, 2 outputs)", (20 + 960) * n_oh, timed(rot_oh16, 64), n_oh, "states")
+	del rot, oh_b, oh16_b
 
 	# PCIe-inclusive: the NumPy drop-in surface (host array in, host array out)
 	host = states.cpu().numpy()

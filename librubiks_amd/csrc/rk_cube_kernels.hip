@@ -858,12 +858,33 @@ void k_rotate686(const uint16_t *__restrict__ states, const uint8_t *__restrict_
 	if (FLAGS && threadIdx.x >= 128 && threadIdx.x < 128 + N_ACTIONS * S686_SLOTS / 16)
 		reinterpret_cast<u32x4 *>(s_near)[threadIdx.x - 128] = reinterpret_cast<const u32x4 *>(&D_TAB.near686[0][0])[threadIdx.x - 128];
 	const size_t n_groups = (n_in + GROUP - 1) / GROUP;
+	// Software pipeline of the input (round 3, as in the 20-byte fan-out): a workgroup walks several groups and requests the
+	// NEXT group's states (GROUP x 18 16-byte words, PW per thread, clamped so that every load is in range)
+	// before it gathers and stores the current one -- with the states coming from HBM a workgroup that only ever sees one
+	// group waits a full memory latency for it first (cache-neutral: 0.61 of peak for the fan-out, 0.76 with the input
+	// cache-resident; profiles/r03_kernels686.json).
+	constexpr int PW = (GROUP * 18 + 255) / 256;
+	u32x4 pre[PW];
+	const u32x4 *all4 = reinterpret_cast<const u32x4 *>(states);
+	const size_t last_word = n_in * 18 - 1;
+	auto request = [&](size_t group) {
+		#pragma unroll
+		for (int k = 0; k < PW; k++) {
+			const size_t w = group * (GROUP * 18) + (size_t)(k * 256 + threadIdx.x);
+			if (k * 256 + (int)threadIdx.x < GROUP * 18) pre[k] = all4[w < last_word ? w : last_word];
+		}
+	};
+	if (blockIdx.x < n_groups) request(blockIdx.x);
 	for (size_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
 		const size_t first = g * GROUP;
 		const int ng = (int)((n_in - first < (size_t)GROUP) ? (n_in - first) : (size_t)GROUP);
 		__syncthreads();                                  // previous step's gathers are done (and the tables are ready)
-		const u32x4 *src4 = reinterpret_cast<const u32x4 *>(states + first * 144);
-		for (int i = threadIdx.x; i < ng * 18; i += 256) reinterpret_cast<u32x4 *>(s_in)[i] = src4[i];
+		#pragma unroll
+		for (int k = 0; k < PW; k++) {
+			const int i = k * 256 + threadIdx.x;
+			if (i < GROUP * 18) reinterpret_cast<u32x4 *>(s_in)[i] = pre[k];
+		}
+		if (g + gridDim.x < n_groups) request(g + gridDim.x);
 		__syncthreads();
 		if (FLAGS && (int)threadIdx.x < ng * S686_SLOTS) {   // slot colours of the staged parents (threads 0..191)
 			const uint16_t *h = s_in + threadIdx.x * 3;       // (parent, slot) -> 3 ushorts = 6 one-hot bytes
@@ -1344,14 +1365,14 @@ void launch_rotate686(const int8_t *states, const uint8_t *actions, int8_t *out,
 {
 	if (fanout) {
 		const size_t n_in = n_out / 12;
-		const unsigned grid = grid_for(n_in, 4, 1u << 22);
+		const unsigned grid = grid_for(n_in, 4, 8192u);               // persistent from 32 k parents on: the next group's states are in flight
 		if (flags != nullptr || stats != nullptr)          // children and their solved flags in ONE launch
 			hipLaunchKernelGGL((k_rotate686<true, true>), dim3(grid), dim3(256), 0, st, (const uint16_t *)states, actions, (u32x4 *)out, n_in, flags, stats);
 		else
 			hipLaunchKernelGGL((k_rotate686<true, false>), dim3(grid), dim3(256), 0, st, (const uint16_t *)states, actions, (u32x4 *)out, n_in,
 			                   (uint8_t *)nullptr, (long long *)nullptr);
 	} else {
-		const unsigned grid = grid_for(n_out, 64, 1u << 20);
+		const unsigned grid = grid_for(n_out, 64, 2048u);
 		hipLaunchKernelGGL((k_rotate686<false, false>), dim3(grid), dim3(256), 0, st, (const uint16_t *)states, actions, (u32x4 *)out, n_out,
 		                   (uint8_t *)nullptr, (long long *)nullptr);
 	}
