@@ -6,6 +6,8 @@
 //   registers --v_perm_b32 table look-ups / byte transposes--> LDS --16 B/lane coalesced--> global
 // The move tables (576..768 B) and the solved state live in the constant segment and are staged in LDS once per
 // workgroup.  LDS staging areas are private to a wave, so the streaming loops contain no s_barrier.
+#include <cstdlib>
+
 #include "rk_device.h"
 #include "rk_kernels.h"
 
@@ -579,31 +581,37 @@ void k_multi_rotate(const uint32_t *__restrict__ states, const uint8_t *__restri
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const size_t first_tile = (size_t)blockIdx.x * ROW_WAVES + wv;
 	// the first tile's states are requested before the move tables are staged (a wave of the usual one-tile grid would
-	// otherwise wait for the table's round trip and only then start its own)
+	// otherwise wait for the table's round trip and only then start its own) ...
+	// ... and on a persistent grid every further tile's states are requested while the previous tile is moved and stored.
 	u32x4 pre[5];
-	const bool have_pre = first_tile < n_tiles && n - first_tile * ROW_TILE >= (size_t)ROW_TILE
-	                      && ((reinterpret_cast<uintptr_t>(states + first_tile * ROW_TILE * STATE_DWORDS) & 15) == 0);
-	if (have_pre) {
-		const u32x4 *src4 = reinterpret_cast<const u32x4 *>(states + first_tile * ROW_TILE * STATE_DWORDS);
-		#pragma unroll
-		for (int k = 0; k < 5; k++) pre[k] = src4[k * 64 + lane];
-	}
+	const size_t tile_stride = (size_t)gridDim.x * ROW_WAVES;
+	auto request = [&](size_t t) {                                       // whole, 16-byte aligned tiles only; wave-uniform answer
+		const bool ok = t < n_tiles && n - t * ROW_TILE >= (size_t)ROW_TILE && ((reinterpret_cast<uintptr_t>(states + t * ROW_TILE * STATE_DWORDS) & 15) == 0);
+		if (ok) {
+			const u32x4 *src4 = reinterpret_cast<const u32x4 *>(states + t * ROW_TILE * STATE_DWORDS);
+			#pragma unroll
+			for (int k = 0; k < 5; k++) pre[k] = src4[k * 64 + lane];
+		}
+		return ok;
+	};
+	bool have_pre = request(first_tile);
 	stage_action_tables(s_act, tid);
 	__syncthreads();
 
 	u32x4 *buf = s_buf[wv];
 	uint32_t *buf_dw = reinterpret_cast<uint32_t *>(buf);
 
-	for (size_t tile = first_tile; tile < n_tiles; tile += (size_t)gridDim.x * ROW_WAVES) {
+	for (size_t tile = first_tile; tile < n_tiles; tile += tile_stride) {
 		const size_t p0 = tile * ROW_TILE;
 		const int np = (int)((n - p0 < (size_t)ROW_TILE) ? (n - p0) : (size_t)ROW_TILE);
 		const uint32_t *src = states + p0 * STATE_DWORDS;
 		uint32_t *dst = out + p0 * STATE_DWORDS;
 		const bool full = np == ROW_TILE && (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0);
 
-		if (tile == first_tile && have_pre) {
+		if (have_pre) {
 			#pragma unroll
 			for (int k = 0; k < 5; k++) buf[k * 64 + lane] = pre[k];
+			have_pre = request(tile + tile_stride);
 		} else if (full) {
 			const u32x4 *src4 = reinterpret_cast<const u32x4 *>(src);
 			#pragma unroll
@@ -681,12 +689,29 @@ void k_multi_is_solved(const uint32_t *__restrict__ states, uint8_t *__restrict_
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	u32x4 *buf = s_buf[wv];
 	uint32_t *buf_dw = reinterpret_cast<uint32_t *>(buf);
+	// on a persistent grid the next tile's states are requested while the current tile is tested (whole, aligned tiles)
+	u32x4 pre[5];
+	const size_t first_tile = (size_t)blockIdx.x * ROW_WAVES + wv, tile_stride = (size_t)gridDim.x * ROW_WAVES;
+	auto request = [&](size_t t) {
+		const bool ok = t < n_tiles && n - t * ROW_TILE >= (size_t)ROW_TILE && ((reinterpret_cast<uintptr_t>(states + t * ROW_TILE * STATE_DWORDS) & 15) == 0);
+		if (ok) {
+			const u32x4 *src4 = reinterpret_cast<const u32x4 *>(states + t * ROW_TILE * STATE_DWORDS);
+			#pragma unroll
+			for (int k = 0; k < 5; k++) pre[k] = src4[k * 64 + lane];
+		}
+		return ok;
+	};
+	bool have_pre = request(first_tile);
 
-	for (size_t tile = (size_t)blockIdx.x * ROW_WAVES + wv; tile < n_tiles; tile += (size_t)gridDim.x * ROW_WAVES) {
+	for (size_t tile = first_tile; tile < n_tiles; tile += tile_stride) {
 		const size_t p0 = tile * ROW_TILE;
 		const int np = (int)((n - p0 < (size_t)ROW_TILE) ? (n - p0) : (size_t)ROW_TILE);
 		const uint32_t *src = states + p0 * STATE_DWORDS;
-		if (np == ROW_TILE && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+		if (have_pre) {
+			#pragma unroll
+			for (int k = 0; k < 5; k++) buf[k * 64 + lane] = pre[k];
+			have_pre = request(tile + tile_stride);
+		} else if (np == ROW_TILE && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
 			const u32x4 *src4 = reinterpret_cast<const u32x4 *>(src);
 			#pragma unroll
 			for (int k = 0; k < 5; k++) buf[k * 64 + lane] = src4[k * 64 + lane];
@@ -1304,10 +1329,18 @@ void launch_states_soa(const int8_t *states, uint32_t *planes, size_t n, bool to
 	hipLaunchKernelGGL(k_states_to_soa, dim3(grid), dim3(256), 0, st, (const uint32_t *)states, planes, n, to_soa ? 1 : 0);
 }
 
+// Workgroups of the per-row kernels (multi_rotate, multi_is_solved): one 256-state tile per wave up to this many workgroups,
+// a persistent grid whose waves request their next tile ahead beyond it.  RK_ROW_GRID overrides (tuning).
+static unsigned row_grid_cap()
+{
+	static const unsigned cap = [] { const char *e = std::getenv("RK_ROW_GRID"); return e ? (unsigned)std::atoi(e) : (1u << 22); }();
+	return cap > 0 ? cap : (1u << 22);
+}
+
 void launch_multi_rotate(const int8_t *states, const uint8_t *actions, const uint8_t *dirs, int8_t *out, size_t n, hipStream_t st)
 {
 	const size_t n_tiles = (n + ROW_TILE - 1) / ROW_TILE;
-	const unsigned grid = grid_for(n_tiles, ROW_WAVES, 1u << 22);
+	const unsigned grid = grid_for(n_tiles, ROW_WAVES, row_grid_cap());
 	if (dirs != nullptr)
 		hipLaunchKernelGGL(k_multi_rotate<true>, dim3(grid), dim3(ROW_WAVES * WAVE), 0, st, (const uint32_t *)states, actions, dirs,
 		                   (uint32_t *)out, n, n_tiles);
@@ -1319,7 +1352,7 @@ void launch_multi_rotate(const int8_t *states, const uint8_t *actions, const uin
 void launch_multi_is_solved(const int8_t *states, uint8_t *flags, long long *stats, size_t n, hipStream_t st)
 {
 	const size_t n_tiles = (n + ROW_TILE - 1) / ROW_TILE;
-	const unsigned grid = grid_for(n_tiles, ROW_WAVES, 1u << 22);
+	const unsigned grid = grid_for(n_tiles, ROW_WAVES, row_grid_cap());
 	hipLaunchKernelGGL(k_multi_is_solved, dim3(grid), dim3(ROW_WAVES * WAVE), 0, st, (const uint32_t *)states, flags, stats, n, n_tiles);
 }
 
