@@ -43,7 +43,7 @@ BYTES_PER_PARENT = 20 + 240 + 12          # read parent, write 12 children, writ
 READ_BYTES_PER_PARENT = 20
 N_IN_SETS = 32                            # rotating parent sets: 32 x 20 MB = 640 MB of distinct input (> 2 x 256 MiB)
 N_OUT_SETS = 4                            # rotating children/flag sets: 3 x 252 MB pass between two writes of a line
-KERNEL = "rk::k_expand12r<true, 2, 1, false, 0>"            # the instantiation launch_expand12 picks at 1 M parents (rocprofv3's spelling)
+KERNEL = "rk::k_expand12p<true>"                            # the instantiation launch_expand12 picks at 1 M parents (rocprofv3's spelling)
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8.0 TB/s spec (about 6.3 TB/s achievable)
 
 

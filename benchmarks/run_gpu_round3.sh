@@ -17,7 +17,7 @@ step 300 python bench.py > $O/bench.log 2>&1; tail -1 $O/bench.log | cut -c1-400
 step 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline > $O/bench_prof.log 2>&1
 step 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -- python3 bench.py --steps 64 --warmup 8 --no-cpu-baseline > $O/pmc_f.log 2>&1
 step 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -- python3 bench.py --steps 64 --warmup 8 --no-cpu-baseline > $O/pmc_w.log 2>&1
-python benchmarks/pmc_summary.py --stats $O/prof_stats --fetch $O/pmc_f --write $O/pmc_w --kernel k_expand12r --commit "${RK_COMMIT:-unknown}" \
+python benchmarks/pmc_summary.py --stats $O/prof_stats --fetch $O/pmc_f --write $O/pmc_w --kernel k_expand12p --commit "${RK_COMMIT:-unknown}" \
 	--command "python3 bench.py --steps 64 --warmup 8 --no-cpu-baseline" --out-pmc $O/expand12_pmc.json --out-stats $O/expand12_kernel_stats.csv > $O/pmc_summary.log 2>&1; cut -c1-400 $O/pmc_summary.log
 # the N > 1 contract of bench.py, rehearsed with two ranks sharing the GPU (host-staged gloo collectives)
 RK_BENCH_BACKEND=gloo step 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --steps 50 --warmup 5 > $O/bench_2ranks_gloo.log 2>&1; tail -1 $O/bench_2ranks_gloo.log | cut -c1-200

@@ -15,7 +15,7 @@ for grp in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum" "TCC_EA0_WRREQ_sum TCC_EA
 	p=$((p+1))
 	step 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pmc_$p -- python3 benchmarks/pmc_regimes.py --manifest $O/manifest_pmc_$p.json > $O/pmc_$p.log 2>&1
 done
-python benchmarks/pmc_regimes_summary.py --manifest $O/manifest.json --passes $O/pmc_* --kernel k_expand12r --out $O/regimes_pmc.json > $O/regimes_summary.log 2>&1
+python benchmarks/pmc_regimes_summary.py --manifest $O/manifest.json --passes $O/pmc_* --kernel k_expand12p --out $O/regimes_pmc.json > $O/regimes_summary.log 2>&1
 step 400 python benchmarks/tune_expand.py 24:3072 100 101:3072 102:3072 104:3072 108:3072 102:2048 104:1024 108:512 121:3072 142:3072 44 45 40 > $O/tune_1m.json 2>/dev/null
 RK_TUNE_N=16000000 step 400 python benchmarks/tune_expand.py 24:3072 100 102:3072 108:512 124:2048 142:2048 200 202:3072 44 45 40 > $O/tune_16m.json 2>/dev/null
 for n in 250000 500000 1000000 2000000 4000000 8000000 16000000 32000000; do

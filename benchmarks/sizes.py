@@ -47,7 +47,8 @@ def parents(n, seed):
 	return cube.device.apply_sequences(acts, False, True)
 
 
-for n in (100_000, 250_000, 500_000, 1_000_000, 2_000_000, 4_000_000, 8_000_000, 16_000_000, 32_000_000):
+SIZES = [int(x) for x in os.environ.get("RK_SIZES", "100000,250000,500000,1000000,2000000,4000000,8000000,16000000,32000000").split(",")]
+for n in SIZES:
 	n_in = max(2, -(-640_000_000 // (20 * n)))
 	n_out = max(1, min(4, 2_000_000_000 // (252 * n)))
 	ins = [parents(n, 3 + k) for k in range(n_in)]

@@ -38,6 +38,30 @@ NAMES = {0: "nt, tile256", 1: "plain, tile256", 3: "plain, tile64",
          54: "PURE STORES: 4 KiB per wave interleaved in the workgroup, plain", 55: "PURE STORES: 15 KiB per wave interleaved, nt",
          56: "PURE STORES: 1 KiB per wave, plain", 57: "PURE STORES: 1 KiB per wave, nt", 58: "PURE STORES: 60 KiB contiguous per wave, nt",
          59: "PURE STORES: 16 KiB per wave interleaved, plain",
+         80: "PURE STORES, run-time shape (grid_blocks = stores per wave | lanes of the last store << 8 | start offset in 16 B << 16), 4 waves/WG",
+         81: "PURE STORES, run-time shape, 1 wave/WG",
+         83: "PURE STORES, one store per wave after a life (grid_blocks = sleep x 64 clocks | mode << 8 | waves per workgroup << 12; mode 0 all waves sleep, 1 wave 0 sleeps + barrier, 2 a global load first)",
+         84: "PURE STORES, run-time shape, 4 waves/WG, s_waitcnt vmcnt(0) after every store",
+         86: "PURE STORES with the waves per CU bounded by an LDS allocation (grid_blocks = stores per wave | LDS KiB per workgroup << 8 | waves per workgroup << 16)",
+         87: "PURE STORES 15 KiB per wave, stores held until a scheduled moment (grid_blocks = hold in 10 ns | stagger in 0.1 ns per wave << 12 | LDS KiB << 20 | 4 waves/WG << 28)",
+         88: "PURE STORES 15 KiB per wave on one schedule for the launch: wave w stores from t0 + lead + w x tau on (grid_blocks = lead in 10 ns | tau in 0.01 ns << 10 | LDS KiB << 20 | 4 waves/WG << 28)",
+         89: "GEOMETRY ONLY (parents in, children + flags out, no work), 64 parents per wave, stores on one schedule for the launch (grid_blocks as 88)",
+         96: "GEOMETRY ONLY: children + flags out (no parent loads), stores on one schedule (grid_blocks as 88)",
+         97: "GEOMETRY ONLY: parents in + children out (no flags), stores on one schedule (grid_blocks as 88)",
+         98: "GEOMETRY ONLY: parents in + children out, the stores NOT depending on the loads, stores on one schedule (grid_blocks as 88)",
+         99: "GEOMETRY ONLY, three streams, READ PHASE FIRST (the waves that start with the launch read all parents once), then stores on one schedule (grid_blocks as 88)",
+         300: "PACED form: read phase by the first workgroups, then one tile per wave stored on a schedule (grid_blocks = lead in 10 ns | tau in 0.01 ns << 10 | pull workgroups / 64 << 20)",
+         85: "PURE STORES, one 4 KiB page per 4-wave workgroup, pages of every aligned block visited with an odd stride (grid_blocks = log2(block pages) | stride << 8)",
+         90: "GEOMETRY ONLY: 16-wave workgroup per 64 parents, loads + barrier + ONE store per wave (15 children pieces + flags)",
+         91: "GEOMETRY ONLY: 8-wave workgroup per 64 parents, two stores per wave", 92: "GEOMETRY ONLY: 4-wave workgroup per 64 parents, four stores per wave",
+         93: "GEOMETRY ONLY: 16-wave workgroups, persistent, next parents requested ahead", 94: "GEOMETRY ONLY: 8-wave workgroups, persistent",
+         95: "GEOMETRY ONLY: 4-wave workgroups, persistent",
+         82: "PURE STORES, one 4 KiB page per 4-wave workgroup, page of workgroup i rotated inside its group (grid_blocks = rot | group << 8)",
+         60: "PURE STORES: 15 KiB per wave, nt, one-shot, back to back", 61: "PURE STORES: 15 KiB per wave, nt, s_sleep(1) between stores",
+         62: "PURE STORES: 15 KiB per wave, nt, s_sleep(2) between stores", 63: "PURE STORES: 15 KiB per wave, nt, s_sleep(4) between stores",
+         72: "GEOMETRY ONLY: 16 parents per wave (3.75 KiB), loads + stores + flags", 73: "GEOMETRY ONLY: 32 parents per wave (7.5 KiB), loads + stores + flags",
+         74: "GEOMETRY ONLY: 8 parents per wave (1.9 KiB), loads + stores + flags", 75: "GEOMETRY ONLY: 16 parents per wave, children stream alone",
+         76: "GEOMETRY ONLY: 32 parents per wave, children stream alone", 77: "GEOMETRY ONLY: 8 parents per wave, children stream alone",
          70: "GEOMETRY ONLY: one 1 KiB store per wave (16-wave workgroup per 64 parents: 15 chunk waves + 1 flag wave), nt",
          71: "GEOMETRY ONLY: one 1 KiB store per wave, plain",
          42: "GEOMETRY ONLY: plain stores from registers", 43: "GEOMETRY ONLY: LDS round trip + plain stores",
@@ -64,7 +88,7 @@ def main(variants):
 	acts = torch.randint(0, 12, (20, N), device="cuda", dtype=torch.uint8, generator=g)
 	parents = cube.device.apply_sequences(acts, False, True)
 	ref_c, ref_f = cube.device.expand12(parents)
-	counter = torch.zeros(4, dtype=torch.int32, device="cuda")
+	counter = torch.zeros(4, dtype=torch.int64, device="cuda")
 	bufs = [(torch.empty_like(ref_c), torch.empty_like(ref_f)) for _ in range(6 if N <= 2_000_000 else 2)]
 	# inputs rotate too.  Round 3: over MORE than twice the 256 MiB Infinity Cache of distinct parents (RK_TUNE_IN_MB, default
 	# 640 MB), so that a parent line cannot be a cache hit whatever the stores do to the cache; set 0 is `parents` (checked
@@ -85,6 +109,10 @@ def main(variants):
 		ok = bool(torch.equal(bufs[0][0], ref_c) and torch.equal(bufs[0][1], ref_f)) if (v[0] < 40 or v[0] >= 100) else "n/a (diagnostic)"
 		res[v] = {"variant": NAMES[v[0]], "id": v[0], "grid_blocks": v[1] or "default", "parents": N, "input_sets": len(ins), "output_sets": len(bufs),
 		          "correct": ok, "ms": []}
+		if v[0] in (80, 81, 84):
+			last = (v[1] >> 8) & 255 or 64
+			res[v]["shape"] = {"stores_per_wave": v[1] & 255, "lanes_of_last_store": last, "bytes_per_wave": ((v[1] & 255) - 1) * 1024 + last * 16,
+			                   "start_offset_bytes": ((v[1] >> 16) & 0x7fff) * 16}
 	launches = 3 * len(ins) if N <= 2_000_000 else 12
 	for rep in range(7):
 		for v in variants:
@@ -100,7 +128,7 @@ def main(variants):
 	for v in variants:
 		r = res[v]
 		ms = sorted(r["ms"])[len(r["ms"]) // 2]
-		nbytes = (240.0 if 50 <= v[0] < 60 else 272.0) * N          # the pure-store diagnostics write the children buffer only
+		nbytes = (240.0 if 50 <= v[0] < 70 or v[0] in (80, 81, 82, 83, 84, 85, 86, 87, 88) else 272.0) * N          # the pure-store diagnostics write the children buffer only
 		r.update(ms_median=ms, **{"GB/s": round(nbytes / (ms * 1e-3) / 1e9, 1), "frac_of_8TBs": round(nbytes / (ms * 1e-3) / 8e12, 4)})
 		print(json.dumps(r), flush=True)
 

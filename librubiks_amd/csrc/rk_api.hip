@@ -235,11 +235,13 @@ int rkx_expand12_variant(int variant, const int8_t *d_parents, int8_t *d_childre
                          unsigned int *d_counter, int grid_blocks, void *stream)
 {
 	if (!d_parents || !d_children || !d_solved || misaligned(d_children, 16)) return fail(RK_EINVAL, "rkx_expand12_variant: bad argument");
-	(void)d_counter;
+	tune_cell(d_counter);
 	launch_expand12_variant(variant, d_parents, d_children, d_solved, d_stats, n, grid_blocks, (hipStream_t)stream);
 	RK_HIP(hipGetLastError());
 	return RK_OK;
 }
+
+int rkx_pace_debug(void *d_buf) { tune_pace_debug(d_buf); return RK_OK; }
 
 int rkx_as_oh_variant(int tile, int grid_cap, const int8_t *d_states, void *d_out, int out_dtype, size_t n, void *stream)
 {

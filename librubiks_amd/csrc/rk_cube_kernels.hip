@@ -29,6 +29,14 @@ namespace rk {
 // ================================================================================================================
 constexpr int EXP_ROUND = 64;                  // parents per round (one per lane)
 constexpr int EXP_WAVES = 4;                   // waves per workgroup of the shipping shape
+constexpr unsigned PACE_TAU_PS = 2150;                  // store schedule of the paced fan-out: 2.15 ns per 64-parent tile (16 128 B: 7.5 TB/s)
+constexpr unsigned PACE_LEAD_TICKS = 50;                // tile 0's slot: 0.5 us after the read phase has ended
+constexpr unsigned PACE_PULL_WGS = 128;                 // workgroups of a phase that read its parents (a quarter of the resident workgroups)
+constexpr unsigned PACE_PHASE_TILES = 16384;            // tiles per phase: 1 Mi parents, 20 MiB of parents in the Infinity Cache at a time
+constexpr size_t PACE_MIN_TILES = 3072;                 // launches below 196 608 parents keep the unpaced forms (equal at 100 k, +3 % at 250 k)
+constexpr unsigned long long PACE_MAX_WAIT_TICKS = 2000; // 20 us
+constexpr unsigned long long PACE_STALE_TICKS = 1500;   // a slot more than 15 us before the wave's own start belongs to an older launch
+constexpr size_t PACE_FIRST_TILES = 4096;               // tiles whose waves may start before the read phase has ended (2 x the resident waves)
 constexpr int EXP_GRID_PERSISTENT = 3072;      // workgroups of the persistent (input-pipelined) launch
 
 template <int HALVES>
@@ -303,9 +311,11 @@ __device__ __forceinline__ void report_solved(const uint32_t fl[3], bool lane_va
 }
 
 // One FULL tile: raw[k] = dword k*64+lane of the tile's 1 280 bytes (already in registers).  No predicate anywhere.
-template <bool WITH_FLAGS, int NT>
+struct NoHold { __device__ __forceinline__ void operator()() const {} };
+
+template <bool WITH_FLAGS, int NT, class Hold = NoHold>
 __device__ __forceinline__ void expand_full_tile(const ExpandCtx &c, const uint32_t raw[5], size_t p0, u32x4 *__restrict__ children,
-                                                 uint32_t *__restrict__ solved, long long *__restrict__ stats)
+                                                 uint32_t *__restrict__ solved, long long *__restrict__ stats, Hold hold = Hold())
 {
 	uint32_t *stage_dw = reinterpret_cast<uint32_t *>(c.stage);
 	#pragma unroll
@@ -326,6 +336,7 @@ __device__ __forceinline__ void expand_full_tile(const ExpandCtx &c, const uint3
 	for (int v = 0; v < 15; v++)
 		c.stage[c.lane * 15 + v] = u32x4{out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]};
 	wave_lds_fence();
+	hold();                                                // the paced form waits here for its slot; the tile is staged, nothing is stored yet
 	u32x4 *dst = children + p0 * 15;
 	#pragma unroll
 	for (int v = 0; v < 15; v++) {
@@ -433,6 +444,30 @@ __device__ __forceinline__ void pull_parents(const uint32_t *__restrict__ parent
 	#undef RK_EAT
 }
 
+// The read phase of the paced form: `n_waves` waves read the parents once, 1 KiB pieces, wave w takes w, w + n_waves, ...; up to
+// sixteen pieces in flight per wave.  A piece past the end stands in as the wave's own first piece (a line it already holds;
+// clamping them all to the array's last word would send every wave to one L2 channel).
+__device__ __forceinline__ void pull_front(const uint32_t *__restrict__ parents, size_t n, size_t wave, size_t n_waves, int lane)
+{
+	size_t bytes = n * STATE_BYTES;
+	bytes = bytes < PULL_MAX_BYTES ? bytes : PULL_MAX_BYTES;
+	if ((reinterpret_cast<uintptr_t>(parents) & 15) != 0 || bytes < 1024) return;
+	const u32x4 *src16 = reinterpret_cast<const u32x4 *>(parents);
+	const size_t last16 = bytes / 16 - 1, n_kib = (bytes + 1023) / 1024;
+	const size_t own = wave * 64 + lane < last16 ? wave * 64 + lane : last16;
+	for (size_t c = wave; c < n_kib; c += 16 * n_waves) {
+		u32x4 a[8], b[8];
+		#pragma unroll
+		for (int j = 0; j < 8; j++) { const size_t pc = c + j * n_waves, i = pc * 64 + lane; a[j] = src16[pc < n_kib ? (i < last16 ? i : last16) : own]; }
+		#pragma unroll
+		for (int j = 0; j < 8; j++) { const size_t pc = c + (8 + j) * n_waves, i = pc * 64 + lane; b[j] = src16[pc < n_kib ? (i < last16 ? i : last16) : own]; }
+		#pragma unroll
+		for (int j = 0; j < 8; j++) asm volatile("" :: "v"(a[j].x), "v"(a[j].y), "v"(a[j].z), "v"(a[j].w) : "memory");
+		#pragma unroll
+		for (int j = 0; j < 8; j++) asm volatile("" :: "v"(b[j].x), "v"(b[j].y), "v"(b[j].z), "v"(b[j].w) : "memory");
+	}
+}
+
 template <bool WITH_FLAGS, int DEPTH, int NT = 1, bool NTL = false, int PULL = 0>
 __global__ __launch_bounds__(EXP_WAVES * WAVE)
 void k_expand12r(const uint32_t *__restrict__ parents, u32x4 *__restrict__ children, uint32_t *__restrict__ solved,
@@ -492,6 +527,110 @@ void k_expand12r(const uint32_t *__restrict__ parents, u32x4 *__restrict__ child
 	// ragged tail: the wave that would own tile n_full
 	if ((n % EXP_ROUND) != 0 && (n_full % stride) == first)
 		expand_ragged_tile<WITH_FLAGS, NT>(c, parents, n_full * EXP_ROUND, (int)(n % EXP_ROUND), children, solved, stats);
+}
+
+// ================================================================================================================
+// expand12, paced form (round 3, for launches of many tiles).  What the store-stream diagnostics of benchmarks/tune_expand.py
+// showed (profiles/r03_store_stream.json): the same 240 MB of children written as 15 KiB per wave reach 5.6 TB/s when every
+// wave stores the moment it can and 7.1 TB/s when the waves release their tiles ONE AFTER THE OTHER AT A FIXED RATE just
+// below what HBM absorbs -- the stores in flight then always cover one narrow, advancing address window instead of thousands
+// of scattered 15 KiB pieces, and the queues in front of the memory channels never fill.  And: 20 MB of parent reads mixed
+// into that stream cost 10 us of 45, however the stores are ordered; read FIRST (into the Infinity Cache, which non-temporal
+// stores leave alone) they cost 4.
+//   * the first `pull_wgs` workgroups read the parents once, front to back, and leave; the last thing each of their waves
+//     does is move the launch's time base g_pace_base up to "now" (atomic max: the base ends at the moment the read phase ended);
+//   * every other wave owns one tile: it loads its parents (cache hits now), expands and stages them exactly as k_expand12r
+//     does, then HOLDS the sixteen stores until base + lead + tile x tau on the constant-rate clock (s_memrealtime, 10 ns).
+//     A wave behind its slot stores at once; nothing moves the schedule (a first version let late waves push the base: waits
+//     then add up, and 2 048 atomics on one address held the whole launch for 50 us).  A schedule nobody can keep therefore
+//     degenerates to the unpaced kernel plus the lead.
+// Results never depend on any of this -- only the moment at which a finished tile is stored does.
+// ================================================================================================================
+__device__ unsigned long long g_pace_base;         // time base of the launch in flight (per device: one copy per loaded code object)
+
+#ifdef RK_TUNING
+__device__ unsigned long long *g_pace_dbg;         // tuning build: per tile {base read, time at the hold, due time, time after the hold}
+#endif
+
+struct PaceHold {
+	unsigned long long base, start; size_t tile; unsigned tau_ps, lead; int lane;
+	__device__ __forceinline__ void operator()() const
+	{
+		if (tau_ps == 0) return;
+		const unsigned long long slot = lead + (unsigned long long)tile * tau_ps / 10000ull;
+		unsigned long long b = base;
+		asm volatile("" ::: "memory");
+		// A wave of the first residency may have started before this launch's read phase ended: the base it read is the previous
+		// launch's then, its slot lies far in the past.  It re-reads until the base is this launch's (bounded: ~30 us).
+		if (tile < PACE_FIRST_TILES)
+			for (int i = 0; i < 20 && b + slot + PACE_STALE_TICKS < start; i++) {
+				__builtin_amdgcn_s_sleep(16);
+				b = __hip_atomic_load(&g_pace_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		const unsigned long long due = b + slot;
+		const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+#ifdef RK_TUNING
+		struct Dbg { unsigned long long *p; size_t t; int l; __device__ ~Dbg() { if (p && l == 0) p[t * 4 + 3] = __builtin_amdgcn_s_memrealtime(); } } dbg{g_pace_dbg, tile, lane};
+		if (g_pace_dbg && lane == 0) { g_pace_dbg[tile * 4] = b; g_pace_dbg[tile * 4 + 1] = now; g_pace_dbg[tile * 4 + 2] = due; }
+#endif
+		// behind its slot a wave simply goes (the schedule is never moved: a wave that waits is the only cost pacing can have,
+		// and it is bounded by the lead); ahead of it, it waits -- never more than PACE_MAX_WAIT_TICKS, whatever the base says
+		// (a wave is dispatched at most one residency, ~5 us, before its slot; a base moved by a concurrent launch on another
+		//  stream can therefore cost a launch 20 us, not more)
+		if (now < due && due - now < PACE_MAX_WAIT_TICKS)
+			while (__builtin_amdgcn_s_memrealtime() < due) __builtin_amdgcn_s_sleep(1);
+		asm volatile("" ::: "memory");
+	}
+};
+
+// The grid is a sequence of PHASES of `phase_tiles` tiles (a multiple of EXP_WAVES; what the Infinity Cache holds of parents with
+// room to spare): `pull_wgs` reading workgroups, then the phase's expanding workgroups, then the next phase's readers, ...
+// Workgroups are dispatched in that order, so a phase's readers start while the tail of the previous phase is still being
+// written and its expanders follow them.  Every phase has its own schedule: tile index and time base start again.
+template <bool WITH_FLAGS>
+__global__ __launch_bounds__(EXP_WAVES * WAVE)
+void k_expand12p(const uint32_t *__restrict__ parents, u32x4 *__restrict__ children, uint32_t *__restrict__ solved,
+                 long long *__restrict__ stats, size_t n, unsigned pull_wgs, unsigned phase_tiles, unsigned tau_ps, unsigned lead)
+{
+	__shared__ u32x4 s_rows[48];
+	__shared__ ExpandWaveLdsT<1> s_wave[EXP_WAVES];
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const unsigned wgs_per_phase = pull_wgs + phase_tiles / EXP_WAVES;
+	const unsigned phase = blockIdx.x / wgs_per_phase, r = blockIdx.x - phase * wgs_per_phase;
+	const size_t p_first = (size_t)phase * phase_tiles * EXP_ROUND;                  // first parent of the phase
+	if (r < pull_wgs) {                                                 // read phase; the whole workgroup leaves before any barrier
+		const size_t p_count = n - p_first < (size_t)phase_tiles * EXP_ROUND ? n - p_first : (size_t)phase_tiles * EXP_ROUND;
+		pull_front(parents + p_first * STATE_DWORDS, p_count, (size_t)r * EXP_WAVES + wv, (size_t)pull_wgs * EXP_WAVES, lane);
+		// the read phase ends when its last workgroups end; one wave in 256 publishes the time (atomics on one address complete
+		// one every ~25 ns chip-wide and hold the memory pipeline of the waves behind them)
+		if (lane == 0 && wv == 0 && ((r & 63) == 63 || r + 1 == pull_wgs))
+			__hip_atomic_fetch_max(&g_pace_base, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		return;
+	}
+	const unsigned long long start = __builtin_amdgcn_s_memrealtime();
+	const size_t n_full = n / EXP_ROUND;
+	const size_t t_in_phase = (size_t)(r - pull_wgs) * EXP_WAVES + wv;
+	const size_t t = (size_t)phase * phase_tiles + t_in_phase;
+	if (pull_wgs == 0 && t_in_phase == 0 && lane == 0)                  // no read phase: the time base is the start of the phase's first wave
+		__hip_atomic_fetch_max(&g_pace_base, start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	// requested now, used after the tile is staged: the base of the schedule and the tile's parents
+	const unsigned long long base = __hip_atomic_load(&g_pace_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	uint32_t raw[5] = {0, 0, 0, 0, 0};
+	if (t < n_full) {
+		const uint32_t *src = parents + t * (EXP_ROUND * STATE_DWORDS) + lane;
+		#pragma unroll
+		for (int k = 0; k < 5; k++) raw[k] = src[k * 64];
+	}
+	if (tid < 48) {
+		const uint32_t *src = reinterpret_cast<const uint32_t *>(D_TAB.rows) + 4 * tid;
+		s_rows[tid] = u32x4{src[0], src[1], src[2], src[3]};
+	}
+	__syncthreads();
+	const ExpandCtx c{s_rows, s_wave[wv].stage, s_wave[wv].flags, lane};
+	if (t < n_full)
+		expand_full_tile<WITH_FLAGS, 1>(c, raw, t * EXP_ROUND, children, solved, stats, PaceHold{base, start, t_in_phase, tau_ps, lead, lane});
+	else if (t == n_full && (n % EXP_ROUND) != 0)
+		expand_ragged_tile<WITH_FLAGS, 1>(c, parents, n_full * EXP_ROUND, (int)(n % EXP_ROUND), children, solved, stats);
 }
 
 // ================================================================================================================
@@ -1043,6 +1182,42 @@ static inline unsigned grid_for(size_t work_items, size_t per_block, unsigned ca
 	return (unsigned)b;
 }
 
+// The paced form's constants: tau = time per tile of the store schedule, the lead between the end of the read phase
+// and tile 0's slot, readers per phase, tiles per phase.  RK_PACE=0 switches the form off, RK_PACE_TAU_PS / RK_PACE_LEAD /
+// RK_PACE_PULL / RK_PACE_PHASE override (tuning).
+struct PaceConfig { bool on; unsigned tau_ps, lead, pull_wgs, phase_tiles; size_t min_tiles; };
+static const PaceConfig &pace_config()
+{
+	static const PaceConfig cfg = [] {
+		auto env = [](const char *name, long dflt) { const char *e = std::getenv(name); return e ? std::atol(e) : dflt; };
+		PaceConfig c;
+		c.on = env("RK_PACE", 1) != 0;
+		c.tau_ps = (unsigned)env("RK_PACE_TAU_PS", PACE_TAU_PS);
+		c.lead = (unsigned)env("RK_PACE_LEAD", PACE_LEAD_TICKS);
+		c.pull_wgs = (unsigned)env("RK_PACE_PULL", PACE_PULL_WGS);
+		c.phase_tiles = (unsigned)env("RK_PACE_PHASE", PACE_PHASE_TILES) / EXP_WAVES * EXP_WAVES;
+		if (c.phase_tiles < 4096) c.phase_tiles = 4096;
+		c.min_tiles = (size_t)env("RK_PACE_MIN", (long)PACE_MIN_TILES);
+		return c;
+	}();
+	return cfg;
+}
+
+static void launch_expand12_paced(const int8_t *parents, int8_t *children, uint8_t *solved, long long *stats, size_t n, const PaceConfig &pc,
+                                  unsigned tau_ps, hipStream_t st)
+{
+	const size_t n_tiles = (n + EXP_ROUND - 1) / EXP_ROUND;
+	const size_t n_phases = (n_tiles + pc.phase_tiles - 1) / pc.phase_tiles;
+	const size_t last_tiles = n_tiles - (n_phases - 1) * pc.phase_tiles;
+	const size_t grid = (n_phases - 1) * (pc.pull_wgs + pc.phase_tiles / EXP_WAVES) + pc.pull_wgs + (last_tiles + EXP_WAVES - 1) / EXP_WAVES;
+	if (solved != nullptr)
+		hipLaunchKernelGGL((k_expand12p<true>), dim3((unsigned)grid), dim3(EXP_WAVES * WAVE), 0, st, (const uint32_t *)parents, (u32x4 *)children,
+			(uint32_t *)solved, stats, n, pc.pull_wgs, pc.phase_tiles, tau_ps, pc.lead);
+	else
+		hipLaunchKernelGGL((k_expand12p<false>), dim3((unsigned)grid), dim3(EXP_WAVES * WAVE), 0, st, (const uint32_t *)parents, (u32x4 *)children,
+			(uint32_t *)nullptr, (long long *)nullptr, n, pc.pull_wgs, pc.phase_tiles, tau_ps * 15360u / 16128u, pc.lead);
+}
+
 #ifdef RK_TUNING   // tuning aids: compiled only into benchmarks/librubiks_hip_tune.so (python -m librubiks_amd.build --tune)
 // Diagnostic only (never used by the product): the fan-out kernel's memory geometry without its work.  Every wave
 // reads its tile's 1 280 B, then writes 15 KiB + 768 B of junk derived from it with the same store instructions.
@@ -1143,6 +1318,238 @@ void k_store_geometry(u32x4 *__restrict__ dst, size_t total_kib)
 	}
 }
 
+// Diagnostic only: the pure store stream again, each wave's CH stores spaced by s_sleep(SLEEP) instead of back to back.
+template <int CH, int SLEEP>
+__global__ __launch_bounds__(256)
+void k_store_geometry_paced(u32x4 *__restrict__ dst, size_t total_kib)
+{
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const size_t w = (size_t)blockIdx.x * 4 + wv;
+	const u32x4 val = u32x4{(uint32_t)w, (uint32_t)lane, 0u, 1u};
+	#pragma unroll
+	for (int v = 0; v < CH; v++) {
+		const size_t kib = w * CH + v;
+		if (kib < total_kib) __builtin_nontemporal_store(val, dst + kib * 64 + lane);
+		if (SLEEP > 0 && v + 1 < CH) __builtin_amdgcn_s_sleep(SLEEP);
+	}
+}
+
+// Diagnostic only: a pure non-temporal store stream whose shape comes at run time: every wave writes `ch` stores of 16 B/lane to
+// one contiguous span, the last of them with `last` lanes, spans packed back to back from `shift16` x 16 B into the buffer.
+__global__ __launch_bounds__(256)
+void k_store_geometry_rt(u32x4 *__restrict__ dst, size_t total16, int ch, int last, int shift16, int wait)
+{
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+	const size_t w = (size_t)blockIdx.x * wpb + wv;
+	const size_t span16 = (size_t)(ch - 1) * 64 + last;
+	const size_t base = (size_t)shift16 + w * span16;
+	const u32x4 val = u32x4{(uint32_t)w, (uint32_t)lane, 0u, 1u};
+	for (int v = 0; v < ch; v++) {
+		const size_t idx = base + (size_t)v * 64 + lane;
+		if ((v + 1 < ch || lane < last) && idx < total16) __builtin_nontemporal_store(val, dst + idx);
+		if (wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // one store in flight per wave
+	}
+}
+
+// Diagnostic only: one 16 B/lane store per wave, a 4-wave workgroup per 4 KiB page, the page of workgroup i rotated inside its
+// aligned group of `group` pages by `rot` -- does it matter WHICH workgroup (i.e. which XCD: i mod 8) writes a page?
+__global__ __launch_bounds__(256)
+void k_store_geometry_page(u32x4 *__restrict__ dst, size_t n_pages, int rot, int group)
+{
+	const size_t i = blockIdx.x;
+	const size_t page = (i / group) * group + (i + rot) % group;
+	if (page >= n_pages) return;
+	__builtin_nontemporal_store(u32x4{(uint32_t)i, threadIdx.x, 0u, 1u}, dst + page * 256 + threadIdx.x);
+}
+
+// Diagnostic only: one 16 B/lane store per wave again, but the wave has a life before it: mode 0 every wave sleeps `sleep` x 64
+// clocks first, mode 1 only wave 0 of the workgroup sleeps and the others wait for it at a barrier (a workgroup whose first
+// wave computes and whose other waves only store), mode 2 every wave first waits for a global load.  blockDim = 64 x waves.
+__global__ __launch_bounds__(1024)
+void k_store_geometry_life(u32x4 *__restrict__ dst, const uint32_t *__restrict__ src, size_t n_kib, int sleep, int mode)
+{
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+	const size_t kib = (size_t)blockIdx.x * wpb + wv;
+	uint32_t x = (uint32_t)kib;
+	if (mode == 0 || (mode == 1 && wv == 0)) for (int i = 0; i < sleep; i++) __builtin_amdgcn_s_sleep(1);
+	if (mode == 1) __syncthreads();
+	if (mode == 2) x ^= src[(kib * 5) & 0xfffff];
+	if (kib < n_kib) __builtin_nontemporal_store(u32x4{x, (uint32_t)lane, 0u, 1u}, dst + kib * 64 + lane);
+}
+
+// Diagnostic only: k_store_geometry_rt with a dynamic LDS allocation whose only job is to bound the waves per CU.
+__global__ __launch_bounds__(256)
+void k_store_geometry_occ(u32x4 *__restrict__ dst, size_t total16, int ch, int touch)
+{
+	extern __shared__ uint32_t s_dyn[];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+	if (touch) s_dyn[threadIdx.x] = 1u;                      // never taken: keeps the allocation referenced
+	const size_t w = (size_t)blockIdx.x * wpb + wv;
+	const size_t base = w * (size_t)ch * 64;
+	const u32x4 val = u32x4{(uint32_t)w, (uint32_t)lane, 0u, 1u};
+	for (int v = 0; v < ch; v++) {
+		const size_t idx = base + (size_t)v * 64 + lane;
+		if (idx < total16) __builtin_nontemporal_store(val, dst + idx);
+	}
+}
+
+// Diagnostic only: 15 KiB per wave again, the waves per CU bounded by LDS, and every wave HOLDS its stores until a scheduled
+// moment after its own start (constant-rate clock, 10 ns ticks): the first `resident` waves (those that start together
+// when the kernel starts) are staggered by `tau_ps` per wave, every later wave waits `hold` ticks.  The resident tiles
+// still span resident x 15 KiB, but the stores IN FLIGHT at any moment come from waves that started one after another.
+__global__ __launch_bounds__(256)
+void k_store_geometry_sched(u32x4 *__restrict__ dst, size_t total16, int ch, unsigned resident, unsigned tau_ps, unsigned hold)
+{
+	extern __shared__ uint32_t s_dyn[];
+	const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+	const size_t w = (size_t)blockIdx.x * wpb + wv;
+	const uint64_t wait = w < resident ? (uint64_t)w * tau_ps / 10000u : hold;
+	while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(1);
+	const size_t base = w * (size_t)ch * 64;
+	const u32x4 val = u32x4{(uint32_t)w, (uint32_t)lane, 0u, 1u};
+	for (int v = 0; v < ch; v++) {
+		const size_t idx = base + (size_t)v * 64 + lane;
+		if (idx < total16) __builtin_nontemporal_store(val, dst + idx);
+	}
+}
+
+// Diagnostic only: the same, on ONE schedule for the whole launch: wave w may store from t0 + lead + w x tau on, where t0 is
+// the moment the launch began.  The wave of tile 0 publishes its start time in `cell`; the waves that start with it
+// (w < resident) take their own start time, the later ones read the cell.  A wave behind the schedule stores at once.
+// MODE 0: 15 KiB of children per wave and nothing else; MODE 1: the fan-out's three streams (parents in, children and flags out);
+// MODE 2: children and flags; MODE 3: parents and children; MODE 4: parents and children, but the stores do not depend on the
+// loads (their values are consumed after the stores are out): the traffic of MODE 3 without its dependency.
+__device__ __forceinline__ void hold_until_slot(uint64_t start, size_t w, unsigned resident, unsigned tau_ps, unsigned lead, unsigned long long *cell)
+{
+	if (tau_ps == 0) return;
+	uint64_t t0 = start;
+	if (w >= resident) t0 = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	const uint64_t due = t0 + lead + (uint64_t)w * tau_ps / 10000u;
+	if (due - start > 100000u) return;                     // more than 1 ms away (or in the past): the cell is not this launch's
+	while (__builtin_amdgcn_s_memrealtime() < due) __builtin_amdgcn_s_sleep(1);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256)
+void k_store_geometry_slot(const uint32_t *__restrict__ parents, u32x4 *__restrict__ dst, uint32_t *__restrict__ solved, size_t n_tiles,
+                           unsigned resident, unsigned tau_ps, unsigned lead, unsigned long long *cell, unsigned rd_period, unsigned rd_window, unsigned wr_guard)
+{
+	extern __shared__ uint32_t s_dyn[];
+	const uint64_t start = __builtin_amdgcn_s_memrealtime();
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+	const size_t w = (size_t)blockIdx.x * wpb + wv;
+	if (w == 0 && lane == 0) __hip_atomic_store(cell, start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if (w >= n_tiles) return;
+	uint32_t x = (uint32_t)w, y = 0;
+	if (MODE == 5 && w < resident) {
+		// read phase: the waves that start with the launch read ALL parents once (1 KiB pieces, wave w takes w, w + resident, ...)
+		// so that every later parent load is an Infinity-Cache hit and no HBM read mixes with the store stream
+		const size_t pieces = (n_tiles * 64 * STATE_DWORDS * 4 + 1023) / 1024;
+		const u32x4 *src16 = reinterpret_cast<const u32x4 *>(parents);
+		u32x4 acc = {0, 0, 0, 0};
+		for (size_t pc = w; pc < pieces; pc += resident) {
+			const size_t idx = pc * 64 + lane;
+			if (idx * 16 < n_tiles * 64 * STATE_DWORDS * 4) { const u32x4 q = src16[idx]; acc.x ^= q.x; acc.y ^= q.y; acc.z ^= q.z; acc.w ^= q.w; }
+		}
+		y = acc.x ^ acc.y ^ acc.z ^ acc.w;
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	}
+	if (MODE == 4) {
+		const uint32_t *src = parents + w * 64 * STATE_DWORDS;
+		#pragma unroll
+		for (int k = 0; k < 5; k++) y ^= __builtin_nontemporal_load(src + k * 64 + lane);
+	}
+	if (MODE == 1 || MODE == 3 || MODE == 5) {
+		// reads in bursts: the parent loads of all waves go out in a window of `rd_window` ticks every `rd_period` ticks
+		if (rd_period > 0) while (__builtin_amdgcn_s_memrealtime() % rd_period >= rd_window) __builtin_amdgcn_s_sleep(1);
+		const uint32_t *src = parents + w * 64 * STATE_DWORDS;
+		#pragma unroll
+		for (int k = 0; k < 5; k++) x ^= src[k * 64 + lane];
+	}
+	// the hold sits where the real kernel has its staged children ready: after the loads have arrived
+	if (MODE == 1 || MODE == 3 || MODE == 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	hold_until_slot(start, w, resident, tau_ps, lead, cell);
+	// time slicing: no store goes out during the read window nor in the `wr_guard` ticks before it
+	if (rd_period > 0 && wr_guard > 0)
+		for (;;) { const unsigned ph = (unsigned)(__builtin_amdgcn_s_memrealtime() % rd_period); if (ph >= rd_window && ph < rd_period - wr_guard) break; __builtin_amdgcn_s_sleep(1); }
+	#pragma unroll
+	for (int v = 0; v < 15; v++) __builtin_nontemporal_store(u32x4{x, x + v, x ^ v, x}, dst + w * 960 + v * 64 + lane);
+	if ((MODE == 1 || MODE == 2 || MODE == 5) && lane < 48) __builtin_nontemporal_store(u32x4{x, x, x, x}, reinterpret_cast<u32x4 *>(solved + w * 192) + lane);
+	if ((MODE == 4 || MODE == 5) && y == 0x12345u) solved[0] = y;          // keeps the loads alive
+}
+
+// Diagnostic only: one 4 KiB page per 4-wave workgroup, one store per wave, the pages of every aligned block of `block` pages
+// visited in a scattered order (odd stride) instead of ascending: over what distance does the ORDER of the pages matter?
+__global__ __launch_bounds__(256)
+void k_store_geometry_scatter(u32x4 *__restrict__ dst, size_t n_pages, unsigned block, unsigned stride)
+{
+	const size_t i = blockIdx.x;
+	const size_t page = (i / block) * block + (size_t)(((i % block) * stride) % block);
+	if (page >= n_pages) return;
+	__builtin_nontemporal_store(u32x4{(uint32_t)i, threadIdx.x, 0u, 1u}, dst + page * 256 + threadIdx.x);
+}
+
+// Diagnostic only: the fan-out's three streams when a WORKGROUP of W waves owns 64 parents (junk data, real addresses): the
+// waves read the 1 280 B together, meet at a barrier (where the real kernel would have staged 15 KiB + 768 B in LDS), and
+// every wave stores 16 / W of the sixteen 1 KiB pieces (the sixteenth is the 768 B of flags).  PERSIST: the workgroup walks
+// tiles blockIdx, blockIdx + grid, ... with the next tile's parents requested before the barrier.
+template <int W, bool PERSIST>
+__global__ __launch_bounds__(W * 64)
+void k_expand12_geometry_wg(const uint32_t *__restrict__ parents, u32x4 *__restrict__ children, uint32_t *__restrict__ solved, size_t n_tiles)
+{
+	__shared__ uint32_t s_x[W];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	auto request = [&](size_t tile) -> uint32_t {           // 320 dwords over the first 320 threads
+		return (tile < n_tiles && threadIdx.x < 320) ? parents[tile * 320 + threadIdx.x] : 0u;
+	};
+	size_t tile = blockIdx.x;
+	uint32_t next = request(tile);
+	for (; tile < n_tiles; tile += gridDim.x) {
+		uint32_t x = next;
+		if (PERSIST) next = request(tile + gridDim.x);
+		#pragma unroll
+		for (int o = 32; o >= 1; o >>= 1) x ^= __shfl_xor(x, o);
+		if (lane == 0) s_x[wv] = x;
+		__syncthreads();
+		x = s_x[0] ^ s_x[W > 4 ? 4 : W - 1];
+		#pragma unroll
+		for (int k = 0; k < 16 / W; k++) {
+			const int piece = wv * (16 / W) + k;
+			const u32x4 val = u32x4{x, x + piece, x ^ piece, x};
+			if (piece < 15) __builtin_nontemporal_store(val, children + tile * 960 + piece * 64 + lane);
+			else if (lane < 48) __builtin_nontemporal_store(val, reinterpret_cast<u32x4 *>(solved + tile * 192) + lane);
+		}
+		if (!PERSIST) break;
+		__syncthreads();
+	}
+}
+
+// Diagnostic only: the fan-out's memory geometry with P parents per wave instead of 64 (junk data, real addresses): the wave
+// reads its P x 20 B, writes P x 240 B as 16 B/lane stores and P x 12 flag bytes as 4 B/lane.  MODE 0: all three streams;
+// MODE 3: the children stream alone.
+template <int P, int MODE>
+__global__ __launch_bounds__(256)
+void k_expand12_geometry_small(const uint32_t *__restrict__ parents, u32x4 *__restrict__ children, uint32_t *__restrict__ solved, size_t n_tiles)
+{
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const size_t tile = (size_t)blockIdx.x * 4 + wv;
+	if (tile >= n_tiles) return;
+	uint32_t x = (uint32_t)tile;
+	if (MODE == 0) {
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(parents + tile * P * STATE_DWORDS);
+		if (lane < P * 5 / 4) { const u32x4 q = src[lane]; x ^= q.x ^ q.y ^ q.z ^ q.w; }
+		x ^= __shfl(x, lane % (P * 5 / 4));          // every lane waits for the loads
+	}
+	u32x4 *dst = children + tile * P * 15;
+	#pragma unroll
+	for (int v = 0; v < (P * 15 + 63) / 64; v++) {
+		const int idx = v * 64 + lane;
+		if (idx < P * 15) __builtin_nontemporal_store(u32x4{x, x + v, x ^ v, x}, dst + idx);
+	}
+	if (MODE == 0 && lane < P * 3) __builtin_nontemporal_store(x, solved + tile * P * 3 + lane);
+}
+
 // Diagnostic: read `n16` 16-byte words and discard them (pulls a buffer into the Infinity Cache with a pure read stream).
 __global__ __launch_bounds__(256)
 void k_touch(const u32x4 *__restrict__ src, size_t n16)
@@ -1152,6 +1559,10 @@ void k_touch(const u32x4 *__restrict__ src, size_t n16)
 		asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
 	}
 }
+
+static unsigned long long *g_tune_cell = nullptr;
+void tune_cell(void *p) { g_tune_cell = static_cast<unsigned long long *>(p); }
+void tune_pace_debug(void *p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pace_dbg), &p, sizeof p); }
 
 // tuning aid (benchmarks/tune_expand.py): the same kernel in its other shapes; grid_blocks > 0 makes the grid persistent.
 void launch_expand12_variant(int variant, const int8_t *parents, int8_t *children, uint8_t *solved, long long *stats, size_t n,
@@ -1208,6 +1619,119 @@ void launch_expand12_variant(int variant, const int8_t *parents, int8_t *childre
 			if (variant == 58) RK_ST(60, false, true);
 			if (variant == 59) RK_ST(16, true, false);
 			#undef RK_ST
+			break;
+		}
+		case 80: case 81: case 84: {                                // run-time shaped pure store stream: grid_blocks = ch | last << 8 | shift16 << 16
+			const int ch = grid_blocks & 255, last = ((grid_blocks >> 8) & 255) ? ((grid_blocks >> 8) & 255) : 64, shift16 = (grid_blocks >> 16) & 0x7fff;
+			if (ch < 1) break;
+			const size_t total16 = n * 15, span16 = (size_t)(ch - 1) * 64 + last;
+			const size_t nw = (total16 + span16 - 1) / span16;
+			const int wpb = variant == 81 ? 1 : 4;
+			hipLaunchKernelGGL(k_store_geometry_rt, dim3((unsigned)((nw + wpb - 1) / wpb)), dim3(64 * wpb), 0, st, (u32x4 *)children, total16, ch, last, shift16, variant == 84 ? 1 : 0);
+			break;
+		}
+		case 82: {                                             // grid_blocks = rot | group << 8
+			const size_t n_pages = n * 240 / 4096;
+			int group = (grid_blocks >> 8) & 0xffff; if (group < 1) group = 8;
+			hipLaunchKernelGGL(k_store_geometry_page, dim3((unsigned)n_pages), dim3(256), 0, st, (u32x4 *)children, n_pages, grid_blocks & 255, group);
+			break;
+		}
+		case 83: {                                             // grid_blocks = sleep | mode << 8 | waves per workgroup << 12
+			const size_t n_kib = n * 240 / 1024;
+			int wpb = (grid_blocks >> 12) & 31; if (wpb < 1) wpb = 4;
+			hipLaunchKernelGGL(k_store_geometry_life, dim3((unsigned)((n_kib + wpb - 1) / wpb)), dim3(64 * wpb), 0, st, (u32x4 *)children, (const uint32_t *)parents, n_kib,
+				grid_blocks & 255, (grid_blocks >> 8) & 15);
+			break;
+		}
+		case 86: {                                             // grid_blocks = stores per wave | LDS KiB per workgroup << 8 | waves per workgroup << 16
+			const int ch = grid_blocks & 255, lds_kib = (grid_blocks >> 8) & 255; int wpb = (grid_blocks >> 16) & 15; if (wpb < 1) wpb = 1;
+			if (ch < 1) break;
+			static bool once = false;
+			if (!once) { (void)hipFuncSetAttribute((const void *)k_store_geometry_occ, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); once = true; }
+			const size_t total16 = n * 15, nw = (total16 + (size_t)ch * 64 - 1) / ((size_t)ch * 64);
+			hipLaunchKernelGGL(k_store_geometry_occ, dim3((unsigned)((nw + wpb - 1) / wpb)), dim3(64 * wpb), (size_t)lds_kib * 1024, st, (u32x4 *)children, total16, ch, 0);
+			break;
+		}
+		case 87: {                                             // grid_blocks = hold ticks | tau in 0.1 ns << 12 | LDS KiB << 20 | (waves per workgroup == 4) << 28
+			const unsigned hold = grid_blocks & 4095, tau_ps = ((grid_blocks >> 12) & 255) * 100u, lds_kib = (grid_blocks >> 20) & 255;
+			const int wpb = ((grid_blocks >> 28) & 1) ? 4 : 1, ch = 15;
+			static bool once = false;
+			if (!once) { (void)hipFuncSetAttribute((const void *)k_store_geometry_sched, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); once = true; }
+			int per_cu = 0, dev = 0, cus = 256;
+			(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_store_geometry_sched, 64 * wpb, (size_t)lds_kib * 1024);
+			(void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+			const size_t total16 = n * 15, nw = (total16 + (size_t)ch * 64 - 1) / ((size_t)ch * 64);
+			hipLaunchKernelGGL(k_store_geometry_sched, dim3((unsigned)((nw + wpb - 1) / wpb)), dim3(64 * wpb), (size_t)lds_kib * 1024, st, (u32x4 *)children, total16, ch,
+				(unsigned)(per_cu * cus * wpb), tau_ps, hold);
+			break;
+		}
+		case 300: {                                            // the paced kernel: grid_blocks = lead in 10 ns | tau in 0.01 ns << 10 | pull workgroups / 64 << 20
+			const unsigned lead = grid_blocks & 1023, tau_ps = ((grid_blocks >> 10) & 1023) * 10u, pull = ((grid_blocks >> 20) & 63) * 64u;
+			const size_t n_tiles = (n + EXP_ROUND - 1) / EXP_ROUND;
+			const char *ph = std::getenv("RK_PACE_PHASE");
+			const PaceConfig pc{true, tau_ps, lead, pull, ph ? (unsigned)std::atoi(ph) / EXP_WAVES * EXP_WAVES : (1u << 24), 0};
+			(void)n_tiles;
+			launch_expand12_paced(parents, children, solved, stats, n, pc, tau_ps, st);
+			break;
+		}
+		case 88: case 89: case 96: case 97: case 98: case 99: {                                    // grid_blocks = lead in 10 ns (10 bits) | tau in 0.01 ns << 10 (10 bits) | LDS KiB << 20 | 4 waves/WG << 28
+			const unsigned lead = grid_blocks & 1023, tau_ps = ((grid_blocks >> 10) & 1023) * 10u, lds_kib = (grid_blocks >> 20) & 255;
+			const int wpb = ((grid_blocks >> 28) & 1) ? 4 : 1;
+			const void *fn = variant == 88 ? (const void *)k_store_geometry_slot<0> : variant == 89 ? (const void *)k_store_geometry_slot<1>
+			               : variant == 96 ? (const void *)k_store_geometry_slot<2> : variant == 97 ? (const void *)k_store_geometry_slot<3>
+			               : variant == 98 ? (const void *)k_store_geometry_slot<4> : (const void *)k_store_geometry_slot<5>;
+			(void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError();
+			int per_cu = 0, dev = 0, cus = 256;
+			(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * wpb, (size_t)lds_kib * 1024);
+			(void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+			const size_t nt = n / 64;
+			const dim3 grid((unsigned)((nt + wpb - 1) / wpb)), block(64 * wpb);
+			const char *e1 = std::getenv("RK_RD_PERIOD"), *e2 = std::getenv("RK_RD_WINDOW");
+			const unsigned rd_period = e1 ? (unsigned)std::atoi(e1) : 0u, rd_window = e2 ? (unsigned)std::atoi(e2) : 0u;
+			const char *e3 = std::getenv("RK_WR_GUARD");
+			const unsigned wr_guard = e3 ? (unsigned)std::atoi(e3) : 0u;
+			#define RK_SLOT(M) hipLaunchKernelGGL(k_store_geometry_slot<M>, grid, block, (size_t)lds_kib * 1024, st, (const uint32_t *)parents, (u32x4 *)children, (uint32_t *)solved, nt, \
+				(unsigned)(per_cu * cus * wpb), tau_ps, lead, g_tune_cell, rd_period, rd_window, wr_guard)
+			if (variant == 88) RK_SLOT(0); else if (variant == 89) RK_SLOT(1); else if (variant == 96) RK_SLOT(2); else if (variant == 97) RK_SLOT(3); else if (variant == 98) RK_SLOT(4); else RK_SLOT(5);
+			#undef RK_SLOT
+			break;
+		}
+		case 85: {                                             // grid_blocks = log2(block) | stride << 8 (stride odd)
+			const size_t n_pages = n * 240 / 4096;
+			hipLaunchKernelGGL(k_store_geometry_scatter, dim3((unsigned)n_pages), dim3(256), 0, st, (u32x4 *)children, n_pages, 1u << (grid_blocks & 31), (unsigned)(grid_blocks >> 8) | 1u);
+			break;
+		}
+		case 90: case 91: case 92: case 93: case 94: case 95: {   // a workgroup of 16 / 8 / 4 waves per 64 parents; 93..95 persistent on grid_blocks workgroups
+			const size_t nt = n / 64;
+			const unsigned g1 = (unsigned)nt, gp = grid_blocks > 0 ? (unsigned)grid_blocks : 2048u;
+			if (variant == 90) hipLaunchKernelGGL((k_expand12_geometry_wg<16, false>), dim3(g1), dim3(1024), 0, st, (const uint32_t *)parents, (u32x4 *)children, (uint32_t *)solved, nt);
+			if (variant == 91) hipLaunchKernelGGL((k_expand12_geometry_wg<8, false>), dim3(g1), dim3(512), 0, st, (const uint32_t *)parents, (u32x4 *)children, (uint32_t *)solved, nt);
+			if (variant == 92) hipLaunchKernelGGL((k_expand12_geometry_wg<4, false>), dim3(g1), dim3(256), 0, st, (const uint32_t *)parents, (u32x4 *)children, (uint32_t *)solved, nt);
+			if (variant == 93) hipLaunchKernelGGL((k_expand12_geometry_wg<16, true>), dim3(gp), dim3(1024), 0, st, (const uint32_t *)parents, (u32x4 *)children, (uint32_t *)solved, nt);
+			if (variant == 94) hipLaunchKernelGGL((k_expand12_geometry_wg<8, true>), dim3(gp), dim3(512), 0, st, (const uint32_t *)parents, (u32x4 *)children, (uint32_t *)solved, nt);
+			if (variant == 95) hipLaunchKernelGGL((k_expand12_geometry_wg<4, true>), dim3(gp), dim3(256), 0, st, (const uint32_t *)parents, (u32x4 *)children, (uint32_t *)solved, nt);
+			break;
+		}
+		case 60: case 61: case 62: case 63: {                  // paced pure store streams, 15 KiB per wave
+			const size_t kib = n * 240 / 1024;
+			const size_t nw = (kib + 14) / 15;
+			const unsigned grid = (unsigned)((nw + 3) / 4);
+			if (variant == 60) hipLaunchKernelGGL((k_store_geometry_paced<15, 0>), dim3(grid), dim3(256), 0, st, (u32x4 *)children, kib);
+			if (variant == 61) hipLaunchKernelGGL((k_store_geometry_paced<15, 1>), dim3(grid), dim3(256), 0, st, (u32x4 *)children, kib);
+			if (variant == 62) hipLaunchKernelGGL((k_store_geometry_paced<15, 2>), dim3(grid), dim3(256), 0, st, (u32x4 *)children, kib);
+			if (variant == 63) hipLaunchKernelGGL((k_store_geometry_paced<15, 4>), dim3(grid), dim3(256), 0, st, (u32x4 *)children, kib);
+			break;
+		}
+		case 72: case 73: case 74: case 75: case 76: case 77: {  // P parents per wave (n must be a multiple of 64)
+			#define RK_SMALL(P, MODE) do { const size_t nt = n / (P); hipLaunchKernelGGL((k_expand12_geometry_small<P, MODE>), dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, st, \
+				(const uint32_t *)parents, (u32x4 *)children, (uint32_t *)solved, nt); } while (0)
+			if (variant == 72) RK_SMALL(16, 0);
+			if (variant == 73) RK_SMALL(32, 0);
+			if (variant == 74) RK_SMALL(8, 0);
+			if (variant == 75) RK_SMALL(16, 3);
+			if (variant == 76) RK_SMALL(32, 3);
+			if (variant == 77) RK_SMALL(8, 3);
+			#undef RK_SMALL
 			break;
 		}
 		case 70: case 71: {
@@ -1302,6 +1826,8 @@ void launch_expand12_variant(int variant, const int8_t *parents, int8_t *childre
 void launch_expand12(const int8_t *parents, int8_t *children, uint8_t *solved, long long *stats, size_t n, hipStream_t st)
 {
 	const size_t n_tiles = (n + EXP_ROUND - 1) / EXP_ROUND;
+	const PaceConfig &pc = pace_config();
+	if (pc.on && n_tiles >= pc.min_tiles) { launch_expand12_paced(parents, children, solved, stats, n, pc, pc.tau_ps, st); return; }
 	const bool ring = n_tiles >= 3000 && n_tiles < 24000;
 	unsigned grid;
 	if (!ring) grid = grid_for(n_tiles, EXP_WAVES, 1u << 22);

@@ -15,6 +15,8 @@ void launch_expand12(const int8_t *parents, int8_t *children, uint8_t *solved, l
 void launch_expand12_variant(int variant, const int8_t *parents, int8_t *children, uint8_t *solved, long long *stats, size_t n,
                              int grid_blocks, hipStream_t st);
 void launch_as_oh_variant(int tile, int grid_cap, const int8_t *states, void *out, int out_dtype, size_t n, hipStream_t st);
+void tune_cell(void *device_cell_16_bytes);
+void tune_pace_debug(void *device_buffer_32_bytes_per_tile_or_null);
 #endif
 void launch_expand12_soa(const uint32_t *parents, uint32_t *children, uint8_t *solved, long long *stats, size_t n, hipStream_t st);
 void launch_states_soa(const int8_t *states, uint32_t *planes, size_t n, bool to_soa, hipStream_t st);

@@ -422,3 +422,87 @@ def test_device_api_rejects_bad_tensors():
 	# the drop-in surface accepts strided / wider-typed input by making a dense int8 copy
 	assert (cube.multi_rotate(p[::2].cpu().numpy().astype(np.int64), np.zeros(32, int), np.ones(32, int))
 	        == orc.multi_rotate(p[::2].cpu().numpy(), np.zeros(32, int), np.ones(32, int))).all()
+
+
+# ------------------------------------------------------------------------------------------------- the paced fan-out
+_PACED_CHILD = r"""
+import sys, torch
+from librubiks_amd import _ffi, cube
+n = int(sys.argv[1])
+assert _ffi.lib().rk_init(0) == 0
+g = torch.Generator(device="cuda"); g.manual_seed(11)
+parents = cube.device.apply_sequences(torch.randint(0, 12, (7, n), device="cuda", dtype=torch.uint8, generator=g), False, True)
+solved = torch.from_numpy(cube.get_solved()).cuda()
+for i, a in ((0, 0), (n // 2, 5), (n - 1, 10)):                       # three parents one move from the goal
+	parents[i] = cube.device.multi_rotate(solved[None], torch.tensor([a], dtype=torch.uint8, device="cuda"))[0]
+stats = torch.tensor([0, _ffi.INT64_MAX], dtype=torch.int64, device="cuda")
+ch, fl = cube.device.expand12(parents, stats=stats)
+# row by row with the per-state kernels: child 12 i + a = parent i turned by a
+ref = cube.device.multi_rotate(parents.repeat_interleave(12, 0), torch.arange(12, dtype=torch.uint8, device="cuda").repeat(n))
+assert torch.equal(ch, ref), "children"
+ref_fl = cube.device.multi_is_solved(ref)
+assert torch.equal(fl, ref_fl), "flags"
+assert int(ref_fl.sum()) == stats[0].item() >= 3 and stats[1].item() == int(torch.nonzero(ref_fl)[0]), "stats"
+ch2, none = cube.device.expand12(parents, want_flags=False)
+assert none is None and torch.equal(ch2, ref), "children without flags"
+print("paced ok", n)
+"""
+
+
+@pytest.mark.parametrize("env", [
+	{"RK_PACE_MIN": "1", "RK_PACE_PHASE": "4096", "RK_PACE_PULL": "64"},      # several short phases
+	{"RK_PACE_MIN": "1", "RK_PACE_PHASE": "4096", "RK_PACE_PULL": "0"},       # no read phase: the first wave of a phase sets the time base
+	{"RK_PACE_MIN": "1", "RK_PACE_TAU_PS": "20000", "RK_PACE_LEAD": "1000"},  # a schedule far slower than the memory: every wave waits
+	{"RK_PACE_MIN": "1", "RK_PACE_TAU_PS": "100"},                            # a schedule nobody can keep: every wave is behind it
+	{"RK_PACE": "0"},                                                         # the unpaced forms
+])
+@pytest.mark.parametrize("n", [300_003, 4096 * 64 * 2])
+def test_paced_fanout_in_every_shape(env, n):
+	"""
+	The paced form of the fan-out (a read phase, then one tile per wave stored on a schedule) decides only WHEN a
+	finished tile is stored.  Its constants are read from the environment once per process, so every shape runs in a process
+	of its own: phases that end inside the batch and exactly at its end, a ragged last tile, no read phase, a schedule far
+	too slow and one far too fast -- children, flags and statistics equal the per-state kernels' every time.
+	"""
+	import os
+	import subprocess
+	import sys
+	root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+	out = subprocess.run([sys.executable, "-c", _PACED_CHILD, str(n)], env={**os.environ, **env}, cwd=root, capture_output=True, text=True, timeout=300)
+	assert out.returncode == 0 and f"paced ok {n}" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_paced_fanout_replayed_from_a_hipgraph_and_on_two_streams():
+	"""Nothing of the paced launch lives on the host: a captured launch replays, and two launches in flight at once (they share
+	the device-side time base, so each may shift the other's schedule by microseconds) still write the right children."""
+	n = 400_000
+	g = torch.Generator(device="cuda")
+	g.manual_seed(13)
+	a = cube.device.apply_sequences(torch.randint(0, 12, (9, n), device="cuda", dtype=torch.uint8, generator=g), False, True)
+	b = cube.device.apply_sequences(torch.randint(0, 12, (9, n), device="cuda", dtype=torch.uint8, generator=g), False, True)
+	ref_a, fl_a = cube.device.expand12(a)
+	ref_b, fl_b = cube.device.expand12(b)
+	src = a.clone()
+	ch, fl = torch.empty_like(ref_a), torch.empty_like(fl_a)
+	graph = torch.cuda.CUDAGraph()
+	s = torch.cuda.Stream()
+	with torch.cuda.stream(s):
+		cube.device.expand12(src, ch, fl)                               # warm-up outside the capture
+		torch.cuda.synchronize()
+		with torch.cuda.graph(graph, stream=s):
+			cube.device.expand12(src, ch, fl)
+	for want_ch, want_fl, inp in ((ref_a, fl_a, a), (ref_b, fl_b, b), (ref_a, fl_a, a)):
+		src.copy_(inp); ch.zero_(); fl.fill_(7)
+		graph.replay()
+		torch.cuda.synchronize()
+		assert torch.equal(ch, want_ch) and torch.equal(fl, want_fl)
+	s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+	out1, out2 = (torch.empty_like(ref_a), torch.empty_like(fl_a)), (torch.empty_like(ref_b), torch.empty_like(fl_b))
+	torch.cuda.synchronize()
+	for _ in range(3):
+		with torch.cuda.stream(s1):
+			cube.device.expand12(a, *out1)
+		with torch.cuda.stream(s2):
+			cube.device.expand12(b, *out2)
+	torch.cuda.synchronize()
+	assert torch.equal(out1[0], ref_a) and torch.equal(out1[1], fl_a) and torch.equal(out2[0], ref_b) and torch.equal(out2[1], fl_b)
