@@ -143,7 +143,10 @@ def pmc_traffic():
 	if rec.get("kernel") != KERNEL:
 		return None, {"source": PMC_FILE, "stale": f"recorded for {rec.get('kernel')}"}
 	return rec.get("hbm_bytes_per_launch"), {"source": PMC_FILE, "kernel": rec.get("kernel"), "commit": rec.get("commit"),
-	                                         "fetch_bytes": rec.get("fetch_bytes_per_launch"), "write_bytes": rec.get("write_bytes_per_launch")}
+	                                         "fetch_bytes": rec.get("fetch_bytes_per_launch"), "write_bytes": rec.get("write_bytes_per_launch"),
+	                                         "reading": "fabric-side bytes (FETCH_SIZE / WRITE_SIZE count Infinity-Cache hits like HBM accesses): the paced kernel "
+	                                                    "fetches every parent twice over the fabric by design -- its read phase from HBM, then the expanding wave "
+	                                                    "from the Infinity Cache -- so fetch = 2 x 20 B per parent where HBM serves 1 x 20 B; writes are exact"}
 
 
 def max_over_ranks(elapsed: float, dist, device) -> float:

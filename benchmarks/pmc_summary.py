@@ -102,7 +102,11 @@ def main():
 			"WRITE_SIZE_KiB_mean": statistics.fmean(wv), "WRITE_SIZE_dispatches": len(wv),
 			"fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
 			"algorithmic_bytes_per_launch": args.algorithmic, "traffic_over_algorithmic": (fetch + write) / args.algorithmic,
-			"note": "the bench rotates the parents over 32 sets (640 MB of distinct input) and the outputs over 4 sets (1 GB), so these fabric-side bytes cannot be Infinity-Cache hits of a previous launch",
+			"note": "FETCH_SIZE / WRITE_SIZE count requests between the L2s and the fabric; a request served by the memory-side Infinity Cache counts like one "
+			        "served by HBM (MI355X_MICROARCH.md).  The bench rotates the parents over 32 sets (640 MB of distinct input) and the outputs over 4 sets "
+			        "(1 GB), so nothing can be a cache hit of a PREVIOUS launch.  The paced fan-out (k_expand12p, DESIGN 3) fetches every parent twice over "
+			        "the fabric BY DESIGN: once in its read phase (from HBM, into the Infinity Cache) and once by the wave that expands the tile (an Infinity-Cache "
+			        "hit of the same launch) -- 2 x 20 B per parent on the fabric, 1 x 20 B per parent from HBM; the write side is exact.",
 		}
 		with open(args.out_pmc, "w") as f:
 			json.dump(rec, f, indent=1)
