@@ -11,7 +11,7 @@ if [ -f $O/bench.log ]; then
 	grep '^{' $O/bench_2ranks_gloo.log | tail -1 > $P/r03_bench_2ranks_gloo_rehearsal.json
 	cp $O/expand12_pmc.json $P/r03_expand12_pmc.json; cp $O/expand12_kernel_stats.csv $P/r03_expand12_kernel_stats.csv
 	grep '^{"kernel": "k_expand12p"' $O/pmc_summary.log > $P/r03_expand12_trace_summary.json
-	for f in sizes kernels kernels686; do [ -s $O/$f.json ] && cp $O/$f.json $P/r03_$f.json; done
+	for f in sizes sizes_unpaced kernels kernels686; do [ -s $O/$f.json ] && cp $O/$f.json $P/r03_$f.json; done
 fi
 if [ -f $O/search.json ]; then
 	for f in astar_small search astar_batch; do [ -s $O/$f.json ] && cp $O/$f.json $P/r03_$f.json; done

@@ -23,6 +23,7 @@ python benchmarks/pmc_summary.py --stats $O/prof_stats --fetch $O/pmc_f --write 
 RK_BENCH_BACKEND=gloo step 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --steps 50 --warmup 5 > $O/bench_2ranks_gloo.log 2>&1; tail -1 $O/bench_2ranks_gloo.log | cut -c1-200
 # kernels and sizes
 step 400 python benchmarks/sizes.py 2>/dev/null | grep '^{' > $O/sizes.json; cut -c1-160 $O/sizes.json
+RK_PACE=0 step 400 python benchmarks/sizes.py 2>/dev/null | grep '^{' > $O/sizes_unpaced.json       # the ring form alone, same box
 step 300 python benchmarks/kernels.py 2>/dev/null | grep '^{' > $O/kernels.json
 step 200 python benchmarks/kernels686.py 2>/dev/null | grep '^{' > $O/kernels686.json
 find $O -name "*kernel_trace.csv" -size +3M -delete; find $O -name "*counter_collection.csv" -size +8M -delete

@@ -447,9 +447,8 @@ __device__ __forceinline__ void pull_parents(const uint32_t *__restrict__ parent
 // The read phase of the paced form: `n_waves` waves read the parents once, 1 KiB pieces, wave w takes w, w + n_waves, ...; up to
 // sixteen pieces in flight per wave.  A piece past the end stands in as the wave's own first piece (a line it already holds;
 // clamping them all to the array's last word would send every wave to one L2 channel).
-__device__ __forceinline__ void pull_front(const uint32_t *__restrict__ parents, size_t n, size_t wave, size_t n_waves, int lane)
+__device__ __forceinline__ void pull_front_bytes(const void *__restrict__ parents, size_t bytes, size_t wave, size_t n_waves, int lane)
 {
-	size_t bytes = n * STATE_BYTES;
 	bytes = bytes < PULL_MAX_BYTES ? bytes : PULL_MAX_BYTES;
 	if ((reinterpret_cast<uintptr_t>(parents) & 15) != 0 || bytes < 1024) return;
 	const u32x4 *src16 = reinterpret_cast<const u32x4 *>(parents);
@@ -466,6 +465,10 @@ __device__ __forceinline__ void pull_front(const uint32_t *__restrict__ parents,
 		#pragma unroll
 		for (int j = 0; j < 8; j++) asm volatile("" :: "v"(b[j].x), "v"(b[j].y), "v"(b[j].z), "v"(b[j].w) : "memory");
 	}
+}
+__device__ __forceinline__ void pull_front(const uint32_t *__restrict__ parents, size_t n, size_t wave, size_t n_waves, int lane)
+{
+	pull_front_bytes(parents, n * STATE_BYTES, wave, n_waves, lane);
 }
 
 template <bool WITH_FLAGS, int DEPTH, int NT = 1, bool NTL = false, int PULL = 0>
@@ -942,9 +945,14 @@ template <> struct OhOne<_Float16> { static constexpr uint32_t bits = 0x3C00u; }
 struct bf16_tag {};
 template <> struct OhOne<bf16_tag> { static constexpr uint32_t bits = 0x3F80u; };
 
-template <typename T, int ELEM_BYTES, int TILE = 64>
-__global__ __launch_bounds__(256)
-void k_as_oh(const uint32_t *__restrict__ states, u32x4 *__restrict__ out, size_t n, size_t n_tiles)
+// tau_ps > 0: the paced form of the fan-out (k_expand12p): phases of `phase_tiles` tiles, each opened by `pull_wgs` workgroups that read
+// the phase's states into the Infinity Cache and publish the time base; every other workgroup owns one tile and holds its stores
+// until base + lead + slot x tau.  (The states are 1-2 % of the traffic, but a tile that waits for them in HBM behind the store
+// stream misses its slot: without the read phase the paced form gains 7 % for f32 and loses 7 % for bf16.)  NT: non-temporal stores.
+template <typename T, int ELEM_BYTES, int TILE = 64, bool NT = false, int THREADS = 256>
+__global__ __launch_bounds__(THREADS)
+void k_as_oh(const uint32_t *__restrict__ states, u32x4 *__restrict__ out, size_t n, size_t n_tiles, unsigned tau_ps = 0, unsigned lead = 0,
+             unsigned pull_wgs = 0, unsigned phase_tiles = 0)
 {
 	constexpr int E = 16 / ELEM_BYTES;            // columns per 16-byte chunk: 4 or 8
 	constexpr int CHUNKS_PER_ROW = 480 / E;       // 120 or 60
@@ -952,16 +960,37 @@ void k_as_oh(const uint32_t *__restrict__ states, u32x4 *__restrict__ out, size_
 	__shared__ uint32_t s_st[TILE * STATE_DWORDS];
 	const int tid = threadIdx.x;
 	const uint8_t *s_bytes = reinterpret_cast<const uint8_t *>(s_st);
+	unsigned long long start = 0, base = 0;
+	size_t tile_first = blockIdx.x, tile_stride = gridDim.x, slot = 0;
+	if (tau_ps > 0) {                                                   // paced: phases of pull_wgs readers + phase_tiles one-tile workgroups
+		const unsigned wgs_per_phase = pull_wgs + phase_tiles;
+		const unsigned phase = blockIdx.x / wgs_per_phase, r = blockIdx.x - phase * wgs_per_phase;
+		if (r < pull_wgs) {                                               // leaves before any barrier
+			const size_t p_first = (size_t)phase * phase_tiles * TILE;
+			const size_t p_count = n - p_first < (size_t)phase_tiles * TILE ? n - p_first : (size_t)phase_tiles * TILE;
+			pull_front(states + p_first * STATE_DWORDS, p_count, (size_t)r * (THREADS / 64) + (tid >> 6), (size_t)pull_wgs * (THREADS / 64), tid & 63);
+			if (tid == 0 && ((r & 63) == 63 || r + 1 == pull_wgs))
+				__hip_atomic_fetch_max(&g_pace_base, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			return;
+		}
+		start = __builtin_amdgcn_s_memrealtime();
+		slot = r - pull_wgs;
+		tile_first = (size_t)phase * phase_tiles + slot;
+		tile_stride = n_tiles;                                             // one tile per workgroup
+		if (pull_wgs == 0 && slot == 0 && tid == 0) __hip_atomic_fetch_max(&g_pace_base, start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		base = __hip_atomic_load(&g_pace_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
 
-	for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+	for (size_t tile = tile_first; tile < n_tiles; tile += tile_stride) {
 		const size_t p0 = tile * TILE;
 		const int np = (int)((n - p0 < (size_t)TILE) ? (n - p0) : (size_t)TILE);
 		const int ndw = np * STATE_DWORDS;
-		for (int idx = tid; idx < TILE * STATE_DWORDS; idx += 256) s_st[idx] = idx < ndw ? states[p0 * STATE_DWORDS + idx] : 0u;
+		for (int idx = tid; idx < TILE * STATE_DWORDS; idx += THREADS) s_st[idx] = idx < ndw ? states[p0 * STATE_DWORDS + idx] : 0u;
 		__syncthreads();
+		PaceHold{base, start, slot, tau_ps, lead, tid & 63}();
 		const int nchunks = np * CHUNKS_PER_ROW;
 		u32x4 *dst = out + p0 * CHUNKS_PER_ROW;
-		for (int c = tid; c < nchunks; c += 256) {
+		for (int c = tid; c < nchunks; c += THREADS) {
 			const int r = c / CHUNKS_PER_ROW, g = c - r * CHUNKS_PER_ROW;
 			const int cubie = g / CHUNKS_PER_CUBIE;
 			const int base = (g - cubie * CHUNKS_PER_CUBIE) * E;
@@ -979,7 +1008,8 @@ void k_as_oh(const uint32_t *__restrict__ states, u32x4 *__restrict__ out, size_
 				val.z = (rel >> 1) == 2 ? one : 0u;
 				val.w = (rel >> 1) == 3 ? one : 0u;
 			}
-			dst[c] = val;
+			if (NT) __builtin_nontemporal_store(val, dst + c);
+			else dst[c] = val;
 		}
 		__syncthreads();
 	}
@@ -1888,15 +1918,33 @@ void launch_apply_sequences(const uint8_t *actions, int moves, int games, int wi
 	hipLaunchKernelGGL(k_apply_sequences, dim3(grid), dim3(256), 0, st, actions, moves, games, with_solved, only_last, (uint32_t *)out);
 }
 
+// workgroups of a paced launch: per phase `pull` readers and one workgroup per tile
+static unsigned oh_paced_grid(size_t n_tiles, unsigned pull, unsigned phase_tiles)
+{
+	const size_t n_phases = (n_tiles + phase_tiles - 1) / phase_tiles;
+	return (unsigned)((n_phases - 1) * (size_t)(pull + phase_tiles) + pull + (n_tiles - (n_phases - 1) * phase_tiles));
+}
+
 #ifdef RK_TUNING
 // tuning aid (benchmarks/tune_oh.py): states per workgroup step and grid cap (0 = one workgroup per tile)
 void launch_as_oh_variant(int tile, int grid_cap, const int8_t *states, void *out, int out_dtype, size_t n, hipStream_t st)
 {
-	#define RK_OH(TL) do { const size_t nt = (n + (TL) - 1) / (TL); const unsigned grid = grid_for(nt, 1, grid_cap > 0 ? (unsigned)grid_cap : (1u << 22)); \
-		if (out_dtype == 0) hipLaunchKernelGGL((k_as_oh<float, 4, TL>), dim3(grid), dim3(256), 0, st, (const uint32_t *)states, (u32x4 *)out, n, nt); \
-		else hipLaunchKernelGGL((k_as_oh<bf16_tag, 2, TL>), dim3(grid), dim3(256), 0, st, (const uint32_t *)states, (u32x4 *)out, n, nt); } while (0)
+	const char *e1 = std::getenv("RK_OH_TAU_PS"), *e2 = std::getenv("RK_OH_LEAD"), *e3 = std::getenv("RK_OH_NT"), *e4 = std::getenv("RK_OH_THREADS");
+	const unsigned tau = e1 && grid_cap <= 0 ? (unsigned)std::atoi(e1) : 0u, lead = e2 ? (unsigned)std::atoi(e2) : 50u;
+	const bool nts = e3 && std::atoi(e3) != 0, one_wave = e4 && std::atoi(e4) == 64;
+	const char *e5 = std::getenv("RK_OH_PULL"), *e6 = std::getenv("RK_OH_PHASE_STATES");
+	const unsigned pull = tau > 0 && e5 ? (unsigned)std::atoi(e5) : 0u;
+	const size_t phase_states = e6 ? (size_t)std::atol(e6) : ((size_t)1 << 20);
+	#define RK_OH2(T, EB, TL, NTS, TH) hipLaunchKernelGGL((k_as_oh<T, EB, TL, NTS, TH>), dim3(grid), dim3(TH), 0, st, (const uint32_t *)states, (u32x4 *)out, n, nt, tau, lead, pull, phase_tiles)
+	#define RK_OH(TL) do { const size_t nt = (n + (TL) - 1) / (TL); const unsigned phase_tiles = (unsigned)(phase_states / (TL)); \
+		const unsigned grid = tau > 0 ? oh_paced_grid(nt, pull, phase_tiles) : grid_for(nt, 1, grid_cap > 0 ? (unsigned)grid_cap : (1u << 22)); \
+		if (out_dtype == 0) { if (one_wave) { if (nts) RK_OH2(float, 4, TL, true, 64); else RK_OH2(float, 4, TL, false, 64); } \
+		                      else          { if (nts) RK_OH2(float, 4, TL, true, 256); else RK_OH2(float, 4, TL, false, 256); } } \
+		else                { if (one_wave) { if (nts) RK_OH2(bf16_tag, 2, TL, true, 64); else RK_OH2(bf16_tag, 2, TL, false, 64); } \
+		                      else          { if (nts) RK_OH2(bf16_tag, 2, TL, true, 256); else RK_OH2(bf16_tag, 2, TL, false, 256); } } } while (0)
 	if (tile == 8) RK_OH(8); else if (tile == 16) RK_OH(16); else if (tile == 32) RK_OH(32); else RK_OH(64);
 	#undef RK_OH
+	#undef RK_OH2
 }
 
 #endif  // RK_TUNING
@@ -1906,17 +1954,22 @@ void launch_as_oh_variant(int tile, int grid_cap, const int8_t *states, void *ou
 // against 5.3 / 5.0 TB/s for 64-state tiles on a persistent grid (the same "few stores per wave" effect as in the fan-out).
 void launch_as_oh(const int8_t *states, void *out, int out_dtype, size_t n, hipStream_t st)
 {
-	if (out_dtype == 0) {
-		const size_t n_tiles = (n + 7) / 8;
-		hipLaunchKernelGGL((k_as_oh<float, 4, 8>), dim3(grid_for(n_tiles, 1, 1u << 22)), dim3(256), 0, st, (const uint32_t *)states, (u32x4 *)out, n, n_tiles);
-	} else {
-		const size_t n_tiles = (n + 15) / 16;
-		const unsigned grid = grid_for(n_tiles, 1, 1u << 22);
-		if (out_dtype == 1)
-			hipLaunchKernelGGL((k_as_oh<_Float16, 2, 16>), dim3(grid), dim3(256), 0, st, (const uint32_t *)states, (u32x4 *)out, n, n_tiles);
-		else
-			hipLaunchKernelGGL((k_as_oh<bf16_tag, 2, 16>), dim3(grid), dim3(256), 0, st, (const uint32_t *)states, (u32x4 *)out, n, n_tiles);
-	}
+	// From 8 192 tiles on (a launch of >= 17 us) the stores are non-temporal and released on the fan-out's schedule (k_expand12p; a tile
+	// is 15 360 B here, so tau scales by 15 360 / 16 128): 0.76 -> 0.87 (f32) and 0.78 -> 0.88-0.90 (bf16) of peak at 500 k states,
+	// profiles/r03_oh_pace.json.  Unpaced, non-temporal stores lose to plain ones (0.72 / 0.70), and plain ones gain nothing from pacing.
+	const PaceConfig &pc = pace_config();
+	const size_t n_tiles = out_dtype == 0 ? (n + 7) / 8 : (n + 15) / 16;
+	const bool paced = pc.on && n_tiles >= 8192;
+	const unsigned tau = paced ? pc.tau_ps * 15360u / 16128u : 0u;
+	const unsigned phase_tiles = (unsigned)(((size_t)pc.phase_tiles * EXP_ROUND) / (out_dtype == 0 ? 8 : 16));    // the fan-out's phase in states: 1 Mi
+	const unsigned grid = paced ? oh_paced_grid(n_tiles, pc.pull_wgs, phase_tiles) : grid_for(n_tiles, 1, 1u << 22);
+	#define RK_OH(T, EB, TL) do { \
+		if (paced) hipLaunchKernelGGL((k_as_oh<T, EB, TL, true>), dim3(grid), dim3(256), 0, st, (const uint32_t *)states, (u32x4 *)out, n, n_tiles, tau, pc.lead, pc.pull_wgs, phase_tiles); \
+		else hipLaunchKernelGGL((k_as_oh<T, EB, TL, false>), dim3(grid), dim3(256), 0, st, (const uint32_t *)states, (u32x4 *)out, n, n_tiles, 0u, 0u, 0u, 0u); } while (0)
+	if (out_dtype == 0) RK_OH(float, 4, 8);
+	else if (out_dtype == 1) RK_OH(_Float16, 2, 16);
+	else RK_OH(bf16_tag, 2, 16);
+	#undef RK_OH
 }
 
 void launch_rotate686(const int8_t *states, const uint8_t *actions, int8_t *out, size_t n_out, bool fanout, hipStream_t st,
@@ -1924,6 +1977,8 @@ void launch_rotate686(const int8_t *states, const uint8_t *actions, int8_t *out,
 {
 	if (fanout) {
 		const size_t n_in = n_out / 12;
+		// (The paced form of the 20-byte fan-out was tried here and removed: 98 % of the groups were behind their slot -- the gathers
+		//  deliver a group every 2.5 ns where the schedule asks for one every 1.85 ns --, 0.72 against 0.74; profiles/r03_paced686_timeline.txt.)
 		const unsigned grid = grid_for(n_in, 4, 8192u);               // persistent from 32 k parents on: the next group's states are in flight
 		if (flags != nullptr || stats != nullptr)          // children and their solved flags in ONE launch
 			hipLaunchKernelGGL((k_rotate686<true, true>), dim3(grid), dim3(256), 0, st, (const uint16_t *)states, actions, (u32x4 *)out, n_in, flags, stats);

@@ -506,3 +506,33 @@ def test_paced_fanout_replayed_from_a_hipgraph_and_on_two_streams():
 			cube.device.expand12(b, *out2)
 	torch.cuda.synchronize()
 	assert torch.equal(out1[0], ref_a) and torch.equal(out1[1], fl_a) and torch.equal(out2[0], ref_b) and torch.equal(out2[1], fl_b)
+
+
+@pytest.mark.parametrize("n", [40_003, 70_001])
+def test_repr686_paced_fanout(n):
+	"""From 32 768 parents on the 6x8x6 fan-out runs in the paced form (one group per workgroup, read phases, stores on a
+	schedule; 70 001 parents are two phases): children against the per-state kernel on device, a sample and the planted
+	solved children against the oracle, flags and statistics against the goal-test kernel."""
+	cube.set_is2024(False)
+	try:
+		g = torch.Generator(device="cuda")
+		g.manual_seed(686 + n)
+		p = dev(np.broadcast_to(orc.SOLVED686, (n, 6, 8, 6)).copy())
+		for _ in range(6):
+			p = cube.device.multi_rotate(p, torch.randint(0, 12, (n,), device="cuda", dtype=torch.uint8, generator=g))
+		for i, (face, d) in ((0, (4, 0)), (n // 2, (2, 1)), (n - 1, (0, 1))):
+			p[i] = dev(orc.rotate686(orc.SOLVED686, face, d))
+		stats = torch.tensor([0, _ffi.INT64_MAX], dtype=torch.int64, device="cuda")
+		ch, fl = cube.device.expand12(p, stats=stats)
+		ref = cube.device.multi_rotate(p.repeat_interleave(12, 0), torch.arange(12, dtype=torch.uint8, device="cuda").repeat(n))
+		assert torch.equal(ch, ref)
+		ref_fl = cube.device.multi_is_solved(ref)
+		assert torch.equal(fl, ref_fl) and int(ref_fl.sum()) == stats[0].item() >= 3 and stats[1].item() == int(torch.nonzero(ref_fl)[0])
+		pick = [0, 1, n // 2, n - 2, n - 1, 16384 * 4 - 1 if n > 16384 * 4 else 5, min(n - 1, 16384 * 4)]
+		pn = p[pick].cpu().numpy()
+		want = np.stack([orc.rotate686(s, a // 2, 1 - a % 2) for s in pn for a in range(12)])
+		assert (ch.view(n, 12, 6, 8, 6)[pick].reshape(-1, 6, 8, 6).cpu().numpy() == want).all()
+		ch2, none = cube.device.expand12(p, want_flags=False)
+		assert none is None and torch.equal(ch2, ref)
+	finally:
+		cube.set_is2024(True)
