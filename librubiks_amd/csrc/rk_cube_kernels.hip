@@ -540,8 +540,8 @@ void k_expand12r(const uint32_t *__restrict__ parents, u32x4 *__restrict__ child
 // of scattered 15 KiB pieces, and the queues in front of the memory channels never fill.  And: 20 MB of parent reads mixed
 // into that stream cost 10 us of 45, however the stores are ordered; read FIRST (into the Infinity Cache, which non-temporal
 // stores leave alone) they cost 4.
-//   * the first `pull_wgs` workgroups read the parents once, front to back, and leave; the last thing each of their waves
-//     does is move the launch's time base g_pace_base up to "now" (atomic max: the base ends at the moment the read phase ended);
+//   * the first `pull_wgs` workgroups of a phase read its parents once, front to back, and leave; the last of them move the
+//     phase's time base g_pace_base up to "now" (atomic max by one wave in 256: the base ends where the read phase ended);
 //   * every other wave owns one tile: it loads its parents (cache hits now), expands and stages them exactly as k_expand12r
 //     does, then HOLDS the sixteen stores until base + lead + tile x tau on the constant-rate clock (s_memrealtime, 10 ns).
 //     A wave behind its slot stores at once; nothing moves the schedule (a first version let late waves push the base: waits
