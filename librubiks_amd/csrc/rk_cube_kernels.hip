@@ -32,6 +32,7 @@ constexpr int EXP_WAVES = 4;                   // waves per workgroup of the shi
 constexpr unsigned PACE_TAU_PS = 2150;                  // store schedule of the paced fan-out: 2.15 ns per 64-parent tile (16 128 B: 7.5 TB/s)
 constexpr unsigned PACE_LEAD_TICKS = 50;                // tile 0's slot: 0.5 us after the read phase has ended
 constexpr unsigned PACE_PULL_WGS = 128;                 // workgroups of a phase that read its parents (a quarter of the resident workgroups)
+constexpr unsigned PACE_PULL_WGS_FIRST = 256;           // ... of the first phase
 constexpr unsigned PACE_PHASE_TILES = 16384;            // tiles per phase: 1 Mi parents, 20 MiB of parents in the Infinity Cache at a time
 constexpr size_t PACE_MIN_TILES = 3072;                 // launches below 196 608 parents keep the unpaced forms (equal at 100 k, +3 % at 250 k)
 constexpr unsigned long long PACE_MAX_WAIT_TICKS = 2000; // 20 us
@@ -445,7 +446,7 @@ __device__ __forceinline__ void pull_parents(const uint32_t *__restrict__ parent
 }
 
 // The read phase of the paced form: `n_waves` waves read the parents once, 1 KiB pieces, wave w takes w, w + n_waves, ...; up to
-// sixteen pieces in flight per wave.  A piece past the end stands in as the wave's own first piece (a line it already holds;
+// twenty-four pieces in flight per wave.  A piece past the end stands in as the wave's own first piece (a line it already holds;
 // clamping them all to the array's last word would send every wave to one L2 channel).
 __device__ __forceinline__ void pull_front_bytes(const void *__restrict__ parents, size_t bytes, size_t wave, size_t n_waves, int lane)
 {
@@ -454,16 +455,16 @@ __device__ __forceinline__ void pull_front_bytes(const void *__restrict__ parent
 	const u32x4 *src16 = reinterpret_cast<const u32x4 *>(parents);
 	const size_t last16 = bytes / 16 - 1, n_kib = (bytes + 1023) / 1024;
 	const size_t own = wave * 64 + lane < last16 ? wave * 64 + lane : last16;
-	for (size_t c = wave; c < n_kib; c += 16 * n_waves) {
-		u32x4 a[8], b[8];
-		#pragma unroll
-		for (int j = 0; j < 8; j++) { const size_t pc = c + j * n_waves, i = pc * 64 + lane; a[j] = src16[pc < n_kib ? (i < last16 ? i : last16) : own]; }
-		#pragma unroll
-		for (int j = 0; j < 8; j++) { const size_t pc = c + (8 + j) * n_waves, i = pc * 64 + lane; b[j] = src16[pc < n_kib ? (i < last16 ? i : last16) : own]; }
-		#pragma unroll
-		for (int j = 0; j < 8; j++) asm volatile("" :: "v"(a[j].x), "v"(a[j].y), "v"(a[j].z), "v"(a[j].w) : "memory");
-		#pragma unroll
-		for (int j = 0; j < 8; j++) asm volatile("" :: "v"(b[j].x), "v"(b[j].y), "v"(b[j].z), "v"(b[j].w) : "memory");
+	// 24 pieces in flight per wave: with 256 reading workgroups a phase's 20 MiB are requested in ONE round (20 pieces per wave)
+	// instead of three rounds of 16 + 16 + 6 with 128 of them, each a full memory latency
+	for (size_t c = wave; c < n_kib; c += 24 * n_waves) {
+		u32x4 a[8], b[8], d[8];
+		#define RK_ISSUE(r, o) _Pragma("unroll") for (int j = 0; j < 8; j++) { const size_t pc = c + ((o) + j) * n_waves, i = pc * 64 + lane; r[j] = src16[pc < n_kib ? (i < last16 ? i : last16) : own]; }
+		#define RK_EAT(r) _Pragma("unroll") for (int j = 0; j < 8; j++) asm volatile("" :: "v"(r[j].x), "v"(r[j].y), "v"(r[j].z), "v"(r[j].w) : "memory");
+		RK_ISSUE(a, 0) RK_ISSUE(b, 8) RK_ISSUE(d, 16)
+		RK_EAT(a) RK_EAT(b) RK_EAT(d)
+		#undef RK_ISSUE
+		#undef RK_EAT
 	}
 }
 __device__ __forceinline__ void pull_front(const uint32_t *__restrict__ parents, size_t n, size_t wave, size_t n_waves, int lane)
@@ -593,28 +594,34 @@ struct PaceHold {
 template <bool WITH_FLAGS>
 __global__ __launch_bounds__(EXP_WAVES * WAVE)
 void k_expand12p(const uint32_t *__restrict__ parents, u32x4 *__restrict__ children, uint32_t *__restrict__ solved,
-                 long long *__restrict__ stats, size_t n, unsigned pull_wgs, unsigned phase_tiles, unsigned tau_ps, unsigned lead)
+                 long long *__restrict__ stats, size_t n, unsigned pull_wgs, unsigned pull_extra, unsigned phase_tiles, unsigned tau_ps, unsigned lead)
 {
 	__shared__ u32x4 s_rows[48];
 	__shared__ ExpandWaveLdsT<1> s_wave[EXP_WAVES];
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	// the first phase has `pull_extra` more reading workgroups than the others (nothing else runs yet: 256 of them request the
+	// phase's 20 MiB in one round; a later phase's readers share the chip with the tail of the phase before and 128 do better)
 	const unsigned wgs_per_phase = pull_wgs + phase_tiles / EXP_WAVES;
-	const unsigned phase = blockIdx.x / wgs_per_phase, r = blockIdx.x - phase * wgs_per_phase;
+	unsigned phase = 0, r = blockIdx.x, pullers = pull_wgs + pull_extra;             // r: index inside the phase, readers first
+	if (blockIdx.x >= pull_extra + wgs_per_phase) {
+		const unsigned b = blockIdx.x - pull_extra;
+		phase = b / wgs_per_phase; r = b - phase * wgs_per_phase; pullers = pull_wgs;
+	}
 	const size_t p_first = (size_t)phase * phase_tiles * EXP_ROUND;                  // first parent of the phase
-	if (r < pull_wgs) {                                                 // read phase; the whole workgroup leaves before any barrier
+	if (r < pullers) {                                                  // read phase; the whole workgroup leaves before any barrier
 		const size_t p_count = n - p_first < (size_t)phase_tiles * EXP_ROUND ? n - p_first : (size_t)phase_tiles * EXP_ROUND;
-		pull_front(parents + p_first * STATE_DWORDS, p_count, (size_t)r * EXP_WAVES + wv, (size_t)pull_wgs * EXP_WAVES, lane);
+		pull_front(parents + p_first * STATE_DWORDS, p_count, (size_t)r * EXP_WAVES + wv, (size_t)pullers * EXP_WAVES, lane);
 		// the read phase ends when its last workgroups end; one wave in 256 publishes the time (atomics on one address complete
 		// one every ~25 ns chip-wide and hold the memory pipeline of the waves behind them)
-		if (lane == 0 && wv == 0 && ((r & 63) == 63 || r + 1 == pull_wgs))
+		if (lane == 0 && wv == 0 && ((r & 63) == 63 || r + 1 == pullers))
 			__hip_atomic_fetch_max(&g_pace_base, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		return;
 	}
 	const unsigned long long start = __builtin_amdgcn_s_memrealtime();
 	const size_t n_full = n / EXP_ROUND;
-	const size_t t_in_phase = (size_t)(r - pull_wgs) * EXP_WAVES + wv;
+	const size_t t_in_phase = (size_t)(r - pullers) * EXP_WAVES + wv;
 	const size_t t = (size_t)phase * phase_tiles + t_in_phase;
-	if (pull_wgs == 0 && t_in_phase == 0 && lane == 0)                  // no read phase: the time base is the start of the phase's first wave
+	if (pullers == 0 && t_in_phase == 0 && lane == 0)                   // no read phase: the time base is the start of the phase's first wave
 		__hip_atomic_fetch_max(&g_pace_base, start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	// requested now, used after the tile is staged: the base of the schedule and the tile's parents
 	const unsigned long long base = __hip_atomic_load(&g_pace_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1215,7 +1222,7 @@ static inline unsigned grid_for(size_t work_items, size_t per_block, unsigned ca
 // The paced form's constants: tau = time per tile of the store schedule, the lead between the end of the read phase
 // and tile 0's slot, readers per phase, tiles per phase.  RK_PACE=0 switches the form off, RK_PACE_TAU_PS / RK_PACE_LEAD /
 // RK_PACE_PULL / RK_PACE_PHASE override (tuning).
-struct PaceConfig { bool on; unsigned tau_ps, lead, pull_wgs, phase_tiles; size_t min_tiles; };
+struct PaceConfig { bool on; unsigned tau_ps, lead, pull_wgs, phase_tiles; size_t min_tiles; unsigned pull_first; };
 static const PaceConfig &pace_config()
 {
 	static const PaceConfig cfg = [] {
@@ -1228,6 +1235,8 @@ static const PaceConfig &pace_config()
 		c.phase_tiles = (unsigned)env("RK_PACE_PHASE", PACE_PHASE_TILES) / EXP_WAVES * EXP_WAVES;
 		if (c.phase_tiles < 4096) c.phase_tiles = 4096;
 		c.min_tiles = (size_t)env("RK_PACE_MIN", (long)PACE_MIN_TILES);
+		c.pull_first = (unsigned)env("RK_PACE_PULL_FIRST", c.pull_wgs == PACE_PULL_WGS ? (long)PACE_PULL_WGS_FIRST : (long)c.pull_wgs);
+		if (c.pull_first < c.pull_wgs) c.pull_first = c.pull_wgs;
 		return c;
 	}();
 	return cfg;
@@ -1239,13 +1248,14 @@ static void launch_expand12_paced(const int8_t *parents, int8_t *children, uint8
 	const size_t n_tiles = (n + EXP_ROUND - 1) / EXP_ROUND;
 	const size_t n_phases = (n_tiles + pc.phase_tiles - 1) / pc.phase_tiles;
 	const size_t last_tiles = n_tiles - (n_phases - 1) * pc.phase_tiles;
-	const size_t grid = (n_phases - 1) * (pc.pull_wgs + pc.phase_tiles / EXP_WAVES) + pc.pull_wgs + (last_tiles + EXP_WAVES - 1) / EXP_WAVES;
+	const unsigned extra = pc.pull_first - pc.pull_wgs;
+	const size_t grid = extra + (n_phases - 1) * (pc.pull_wgs + pc.phase_tiles / EXP_WAVES) + pc.pull_wgs + (last_tiles + EXP_WAVES - 1) / EXP_WAVES;
 	if (solved != nullptr)
 		hipLaunchKernelGGL((k_expand12p<true>), dim3((unsigned)grid), dim3(EXP_WAVES * WAVE), 0, st, (const uint32_t *)parents, (u32x4 *)children,
-			(uint32_t *)solved, stats, n, pc.pull_wgs, pc.phase_tiles, tau_ps, pc.lead);
+			(uint32_t *)solved, stats, n, pc.pull_wgs, extra, pc.phase_tiles, tau_ps, pc.lead);
 	else
 		hipLaunchKernelGGL((k_expand12p<false>), dim3((unsigned)grid), dim3(EXP_WAVES * WAVE), 0, st, (const uint32_t *)parents, (u32x4 *)children,
-			(uint32_t *)nullptr, (long long *)nullptr, n, pc.pull_wgs, pc.phase_tiles, tau_ps * 15360u / 16128u, pc.lead);
+			(uint32_t *)nullptr, (long long *)nullptr, n, pc.pull_wgs, extra, pc.phase_tiles, tau_ps * 15360u / 16128u, pc.lead);
 }
 
 #ifdef RK_TUNING   // tuning aids: compiled only into benchmarks/librubiks_hip_tune.so (python -m librubiks_amd.build --tune)
@@ -1699,7 +1709,7 @@ void launch_expand12_variant(int variant, const int8_t *parents, int8_t *childre
 			const unsigned lead = grid_blocks & 1023, tau_ps = ((grid_blocks >> 10) & 1023) * 10u, pull = ((grid_blocks >> 20) & 63) * 64u;
 			const size_t n_tiles = (n + EXP_ROUND - 1) / EXP_ROUND;
 			const char *ph = std::getenv("RK_PACE_PHASE");
-			const PaceConfig pc{true, tau_ps, lead, pull, ph ? (unsigned)std::atoi(ph) / EXP_WAVES * EXP_WAVES : (1u << 24), 0};
+			const PaceConfig pc{true, tau_ps, lead, pull, ph ? (unsigned)std::atoi(ph) / EXP_WAVES * EXP_WAVES : (1u << 24), 0, pull};
 			(void)n_tiles;
 			launch_expand12_paced(parents, children, solved, stats, n, pc, tau_ps, st);
 			break;
