@@ -29,7 +29,8 @@ namespace rk {
 // ================================================================================================================
 constexpr int EXP_ROUND = 64;                  // parents per round (one per lane)
 constexpr int EXP_WAVES = 4;                   // waves per workgroup of the shipping shape
-constexpr unsigned PACE_TAU_PS = 2150;                  // store schedule of the paced fan-out: 2.15 ns per 64-parent tile (16 128 B: 7.5 TB/s)
+constexpr unsigned PACE_TAU_PS = 2100;                  // store schedule of the paced fan-out: 2.10 ns per 64-parent tile (16 128 B: 7.68 TB/s, 96 % of the
+                                                        // HBM peak; at 2.05 ns no box keeps the schedule: 0.79 of peak instead of 0.83-0.84, profiles/r03_paced_tau.json)
 constexpr unsigned PACE_LEAD_TICKS = 50;                // tile 0's slot: 0.5 us after the read phase has ended
 constexpr unsigned PACE_PULL_WGS = 128;                 // workgroups of a phase that read its parents (a quarter of the resident workgroups)
 constexpr unsigned PACE_PULL_WGS_FIRST = 256;           // ... of the first phase
