@@ -93,7 +93,11 @@ int rk_multi_rotate_fd(int repr, const int8_t *d_states, const uint8_t *d_faces,
  * :540; train.py:292).  d_children is (12 n, state) parent-major / action-minor and must be 16-byte
  * aligned.  d_solved (nullable) gets one byte per child.  d_stats (nullable) is int64[2] that the
  * caller zero/initialises: [0] += number of solved children, [1] = min(index of a solved child,
- * previous value) -- initialise [1] to INT64_MAX. */
+ * previous value) -- initialise [1] to INT64_MAX.  The statistics are meant for RARE hits (a search
+ * looking for its goal): every wave that has a solved child reports with two device-scope atomics
+ * on these two words, and atomics on one address complete about one every 25 ns chip-wide -- 12 M
+ * states of which 4 000 are solved take 0.24 ms with d_stats and 0.04 ms without.  Use d_solved
+ * when hits are common. */
 int rk_expand12(int repr, const int8_t *d_parents, int8_t *d_children, uint8_t *d_solved,
                 long long *d_stats, size_t n, void *stream);
 
