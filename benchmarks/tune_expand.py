@@ -51,6 +51,8 @@ NAMES = {0: "nt, tile256", 1: "plain, tile256", 3: "plain, tile64",
          98: "GEOMETRY ONLY: parents in + children out, the stores NOT depending on the loads, stores on one schedule (grid_blocks as 88)",
          99: "GEOMETRY ONLY, three streams, READ PHASE FIRST (the waves that start with the launch read all parents once), then stores on one schedule (grid_blocks as 88)",
          300: "PACED form: read phase by the first workgroups, then one tile per wave stored on a schedule (grid_blocks = lead in 10 ns | tau in 0.01 ns << 10 | pull workgroups / 64 << 20)",
+         310: "PURE READS of the 240 MB children buffer (rotating over the output sets), 5 KiB per wave, one-shot grid, loads released on a schedule (grid_blocks = tau in 0.01 ns | LDS KiB << 12 | 4 waves/WG << 20)",
+         311: "PURE READS, 1 KiB per wave (grid_blocks as 310)", 312: "PURE READS, 16 KiB per wave (grid_blocks as 310)",
          85: "PURE STORES, one 4 KiB page per 4-wave workgroup, pages of every aligned block visited with an odd stride (grid_blocks = log2(block pages) | stride << 8)",
          90: "GEOMETRY ONLY: 16-wave workgroup per 64 parents, loads + barrier + ONE store per wave (15 children pieces + flags)",
          91: "GEOMETRY ONLY: 8-wave workgroup per 64 parents, two stores per wave", 92: "GEOMETRY ONLY: 4-wave workgroup per 64 parents, four stores per wave",
@@ -128,7 +130,7 @@ def main(variants):
 	for v in variants:
 		r = res[v]
 		ms = sorted(r["ms"])[len(r["ms"]) // 2]
-		nbytes = (240.0 if 50 <= v[0] < 70 or v[0] in (80, 81, 82, 83, 84, 85, 86, 87, 88) else 272.0) * N          # the pure-store diagnostics write the children buffer only
+		nbytes = (240.0 if 50 <= v[0] < 70 or v[0] in (80, 81, 82, 83, 84, 85, 86, 87, 88, 310, 311, 312) else 272.0) * N          # the pure-store diagnostics write the children buffer only
 		r.update(ms_median=ms, **{"GB/s": round(nbytes / (ms * 1e-3) / 1e9, 1), "frac_of_8TBs": round(nbytes / (ms * 1e-3) / 8e12, 4)})
 		print(json.dumps(r), flush=True)
 

@@ -31,6 +31,9 @@ constexpr int EXP_ROUND = 64;                  // parents per round (one per lan
 constexpr int EXP_WAVES = 4;                   // waves per workgroup of the shipping shape
 constexpr unsigned PACE_TAU_PS = 2100;                  // store schedule of the paced fan-out: 2.10 ns per 64-parent tile (16 128 B: 7.68 TB/s, 96 % of the
                                                         // HBM peak; at 2.05 ns no box keeps the schedule: 0.79 of peak instead of 0.83-0.84, profiles/r03_paced_tau.json)
+constexpr unsigned PACE_ROT_TAU_PS = 1200;              // multi_rotate from 2 Mi states on: 1.2 ns per 256-state tile and non-temporal stores, 0.71 -> 0.76 of peak
+                                                        // at 12 M rows (1.0-1.3 ns alike, 0.75 at 1.4-1.5, 0.70 at 1.7; non-temporal stores unpaced: 0.61), profiles/r03_rows_pace.json
+constexpr unsigned PACE_SOLVED_TAU_PS = 0;              // multi_is_solved: unpaced -- with its flag stream 0.72-0.73 at every tau (a pure read stream gains 9 %)
 constexpr unsigned PACE_LEAD_TICKS = 50;                // tile 0's slot: 0.5 us after the read phase has ended
 constexpr unsigned PACE_PULL_WGS = 128;                 // workgroups of a phase that read its parents (a quarter of the resident workgroups)
 constexpr unsigned PACE_PULL_WGS_FIRST = 256;           // ... of the first phase
@@ -38,7 +41,7 @@ constexpr unsigned PACE_PHASE_TILES = 16384;            // tiles per phase: 1 Mi
 constexpr size_t PACE_MIN_TILES = 3072;                 // launches below 196 608 parents keep the unpaced forms (equal at 100 k, +3 % at 250 k)
 constexpr unsigned long long PACE_MAX_WAIT_TICKS = 2000; // 20 us
 constexpr unsigned long long PACE_STALE_TICKS = 1500;   // a slot more than 15 us before the wave's own start belongs to an older launch
-constexpr size_t PACE_FIRST_TILES = 4096;               // tiles whose waves may start before the read phase has ended (2 x the resident waves)
+constexpr size_t PACE_FIRST_TILES = 16384;              // tiles whose waves may start before the time base is this launch's (2 x the most waves a launch has resident)
 constexpr int EXP_GRID_PERSISTENT = 3072;      // workgroups of the persistent (input-pipelined) launch
 
 template <int HALVES>
@@ -720,16 +723,31 @@ void k_states_to_soa(const uint32_t *__restrict__ states, uint32_t *__restrict__
 constexpr int ROW_TILE = 256;     // states per wave tile
 constexpr int ROW_WAVES = 4;
 
+// Reads, too, go faster in order and at a fixed rate (profiles/r03_store_stream.json, ids 310-312: a pure read stream of 5 KiB per
+// wave runs at 6.27 TB/s when every wave loads the moment it starts and at 6.85 TB/s when wave w loads at t0 + w x 0.70 ns; at
+// 0.66 ns it is back at 6.3).  A paced per-row launch has one tile per wave; the wave of tile 0 sets the time base (there is no read
+// phase here), and every wave waits for its slot BEFORE it requests its states.
+__device__ __forceinline__ void row_pace_hold(size_t tile, unsigned tau_ps, unsigned lead, int lane)
+{
+	if (tau_ps == 0) return;
+	const unsigned long long start = __builtin_amdgcn_s_memrealtime();
+	if (tile == 0 && lane == 0) __hip_atomic_fetch_max(&g_pace_base, start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	const unsigned long long base = __hip_atomic_load(&g_pace_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	PaceHold{base, start, tile, tau_ps, lead, lane}();
+}
+
 template <bool SPLIT_FD>
 __global__ __launch_bounds__(ROW_WAVES * WAVE)
 void k_multi_rotate(const uint32_t *__restrict__ states, const uint8_t *__restrict__ act_or_faces,
-                    const uint8_t *__restrict__ dirs, uint32_t *__restrict__ out, size_t n, size_t n_tiles)
+                    const uint8_t *__restrict__ dirs, uint32_t *__restrict__ out, size_t n, size_t n_tiles,
+                    unsigned tau_ps, unsigned lead, unsigned nt_stores)
 {
 	__shared__ u32x4 s_act[36];
 	__shared__ u32x4 s_buf[ROW_WAVES][320];       // 5 120 B per wave
 
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const size_t first_tile = (size_t)blockIdx.x * ROW_WAVES + wv;
+	row_pace_hold(first_tile, tau_ps, lead, lane);    // paced launches (one tile per wave): the wave's LOADS wait for its slot
 	// the first tile's states are requested before the move tables are staged (a wave of the usual one-tile grid would
 	// otherwise wait for the table's round trip and only then start its own) ...
 	// ... and on a persistent grid every further tile's states are requested while the previous tile is moved and stored.
@@ -811,8 +829,13 @@ void k_multi_rotate(const uint32_t *__restrict__ states, const uint8_t *__restri
 
 		if (full) {
 			u32x4 *dst4 = reinterpret_cast<u32x4 *>(dst);
-			#pragma unroll
-			for (int k = 0; k < 5; k++) dst4[k * 64 + lane] = buf[k * 64 + lane];
+			if (nt_stores) {
+				#pragma unroll
+				for (int k = 0; k < 5; k++) __builtin_nontemporal_store(buf[k * 64 + lane], dst4 + k * 64 + lane);
+			} else {
+				#pragma unroll
+				for (int k = 0; k < 5; k++) dst4[k * 64 + lane] = buf[k * 64 + lane];
+			}
 		} else {
 			const int ndw = np * STATE_DWORDS;
 			#pragma unroll
@@ -833,10 +856,11 @@ void k_multi_rotate(const uint32_t *__restrict__ states, const uint8_t *__restri
 // ================================================================================================================
 __global__ __launch_bounds__(ROW_WAVES * WAVE)
 void k_multi_is_solved(const uint32_t *__restrict__ states, uint8_t *__restrict__ flags, long long *__restrict__ stats,
-                       size_t n, size_t n_tiles)
+                       size_t n, size_t n_tiles, unsigned tau_ps, unsigned lead)
 {
 	__shared__ u32x4 s_buf[ROW_WAVES][320];
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	row_pace_hold((size_t)blockIdx.x * ROW_WAVES + wv, tau_ps, lead, lane);
 	u32x4 *buf = s_buf[wv];
 	uint32_t *buf_dw = reinterpret_cast<uint32_t *>(buf);
 	// on a persistent grid the next tile's states are requested while the current tile is tested (whole, aligned tiles)
@@ -1520,6 +1544,26 @@ void k_store_geometry_slot(const uint32_t *__restrict__ parents, u32x4 *__restri
 	if ((MODE == 4 || MODE == 5) && y == 0x12345u) solved[0] = y;          // keeps the loads alive
 }
 
+// Diagnostic only: a pure READ stream, CH KiB per wave (16 B/lane loads, values thrown away), one-shot grid; with tau_ps > 0 wave w
+// issues its loads not before t0 + w x tau (same clock and base protocol as k_store_geometry_slot).  Do ordered, rate-limited
+// reads do for HBM what ordered, rate-limited stores do?
+template <int CH>
+__global__ __launch_bounds__(256)
+void k_read_geometry_slot(const u32x4 *__restrict__ src, size_t total16, unsigned resident, unsigned tau_ps, unsigned long long *cell)
+{
+	extern __shared__ uint32_t s_dyn[];
+	const uint64_t start = __builtin_amdgcn_s_memrealtime();
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+	const size_t w = (size_t)blockIdx.x * wpb + wv;
+	if (w == 0 && lane == 0) __hip_atomic_store(cell, start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	hold_until_slot(start, w, resident, tau_ps, 0, cell);
+	u32x4 r[CH];
+	#pragma unroll
+	for (int v = 0; v < CH; v++) { const size_t i = (w * CH + v) * 64 + lane; r[v] = src[i < total16 ? i : total16 - 1]; }
+	#pragma unroll
+	for (int v = 0; v < CH; v++) asm volatile("" :: "v"(r[v].x), "v"(r[v].y), "v"(r[v].z), "v"(r[v].w) : "memory");
+}
+
 // Diagnostic only: one 4 KiB page per 4-wave workgroup, one store per wave, the pages of every aligned block of `block` pages
 // visited in a scattered order (odd stride) instead of ascending: over what distance does the ORDER of the pages matter?
 __global__ __launch_bounds__(256)
@@ -1737,6 +1781,22 @@ void launch_expand12_variant(int variant, const int8_t *parents, int8_t *childre
 			#undef RK_SLOT
 			break;
 		}
+		case 310: case 311: case 312: {                        // paced pure read of the children buffer: grid_blocks = tau in 0.01 ns | LDS KiB << 12 | 4 waves/WG << 20
+			const unsigned tau_ps = (grid_blocks & 4095) * 10u, lds_kib = (grid_blocks >> 12) & 255;
+			const int wpb = ((grid_blocks >> 20) & 1) ? 4 : 1, ch = variant == 310 ? 5 : variant == 311 ? 1 : 16;
+			const void *fn = variant == 310 ? (const void *)k_read_geometry_slot<5> : variant == 311 ? (const void *)k_read_geometry_slot<1> : (const void *)k_read_geometry_slot<16>;
+			(void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError();
+			int per_cu = 0, dev = 0, cus = 256;
+			(void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * wpb, (size_t)lds_kib * 1024);
+			(void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+			const size_t total16 = n * 15, nw = (total16 + (size_t)ch * 64 - 1) / ((size_t)ch * 64);
+			const dim3 grid((unsigned)((nw + wpb - 1) / wpb)), block(64 * wpb);
+			const unsigned res = (unsigned)(per_cu * cus * wpb);
+			if (variant == 310) hipLaunchKernelGGL(k_read_geometry_slot<5>, grid, block, (size_t)lds_kib * 1024, st, (const u32x4 *)children, total16, res, tau_ps, g_tune_cell);
+			else if (variant == 311) hipLaunchKernelGGL(k_read_geometry_slot<1>, grid, block, (size_t)lds_kib * 1024, st, (const u32x4 *)children, total16, res, tau_ps, g_tune_cell);
+			else hipLaunchKernelGGL(k_read_geometry_slot<16>, grid, block, (size_t)lds_kib * 1024, st, (const u32x4 *)children, total16, res, tau_ps, g_tune_cell);
+			break;
+		}
 		case 85: {                                             // grid_blocks = log2(block) | stride << 8 (stride odd)
 			const size_t n_pages = n * 240 / 4096;
 			hipLaunchKernelGGL(k_store_geometry_scatter, dim3((unsigned)n_pages), dim3(256), 0, st, (u32x4 *)children, n_pages, 1u << (grid_blocks & 31), (unsigned)(grid_blocks >> 8) | 1u);
@@ -1904,23 +1964,35 @@ static unsigned row_grid_cap()
 	return cap > 0 ? cap : (1u << 22);
 }
 
+// Paced per-row launches (from 8 192 tiles = 2 Mi states on, one tile per wave): RK_PACE_ROT_TAU_PS / RK_PACE_ROT_NT for multi_rotate,
+// RK_PACE_SOLVED_TAU_PS for multi_is_solved override the constants (0 = unpaced).
+static unsigned env_u(const char *name, unsigned dflt) { const char *e = std::getenv(name); return e ? (unsigned)std::atol(e) : dflt; }
+
 void launch_multi_rotate(const int8_t *states, const uint8_t *actions, const uint8_t *dirs, int8_t *out, size_t n, hipStream_t st)
 {
+	static const unsigned tau_cfg = env_u("RK_PACE_ROT_TAU_PS", PACE_ROT_TAU_PS), nt_cfg = env_u("RK_PACE_ROT_NT", 1);
 	const size_t n_tiles = (n + ROW_TILE - 1) / ROW_TILE;
 	const unsigned grid = grid_for(n_tiles, ROW_WAVES, row_grid_cap());
+	const PaceConfig &pc = pace_config();
+	const bool paced = pc.on && tau_cfg > 0 && n_tiles >= 8192 && (size_t)grid * ROW_WAVES >= n_tiles;
+	const unsigned tau = paced ? tau_cfg : 0u, nt = paced ? nt_cfg : 0u;
 	if (dirs != nullptr)
 		hipLaunchKernelGGL(k_multi_rotate<true>, dim3(grid), dim3(ROW_WAVES * WAVE), 0, st, (const uint32_t *)states, actions, dirs,
-		                   (uint32_t *)out, n, n_tiles);
+		                   (uint32_t *)out, n, n_tiles, tau, pc.lead, nt);
 	else
 		hipLaunchKernelGGL(k_multi_rotate<false>, dim3(grid), dim3(ROW_WAVES * WAVE), 0, st, (const uint32_t *)states, actions,
-		                   (const uint8_t *)nullptr, (uint32_t *)out, n, n_tiles);
+		                   (const uint8_t *)nullptr, (uint32_t *)out, n, n_tiles, tau, pc.lead, nt);
 }
 
 void launch_multi_is_solved(const int8_t *states, uint8_t *flags, long long *stats, size_t n, hipStream_t st)
 {
+	static const unsigned tau_cfg = env_u("RK_PACE_SOLVED_TAU_PS", PACE_SOLVED_TAU_PS);
 	const size_t n_tiles = (n + ROW_TILE - 1) / ROW_TILE;
 	const unsigned grid = grid_for(n_tiles, ROW_WAVES, row_grid_cap());
-	hipLaunchKernelGGL(k_multi_is_solved, dim3(grid), dim3(ROW_WAVES * WAVE), 0, st, (const uint32_t *)states, flags, stats, n, n_tiles);
+	const PaceConfig &pc = pace_config();
+	const bool paced = pc.on && tau_cfg > 0 && n_tiles >= 8192 && (size_t)grid * ROW_WAVES >= n_tiles;
+	hipLaunchKernelGGL(k_multi_is_solved, dim3(grid), dim3(ROW_WAVES * WAVE), 0, st, (const uint32_t *)states, flags, stats, n, n_tiles,
+	                   paced ? tau_cfg : 0u, pc.lead);
 }
 
 void launch_apply_sequences(const uint8_t *actions, int moves, int games, int with_solved, int only_last, int8_t *out, hipStream_t st)

@@ -536,3 +536,25 @@ def test_repr686_paced_fanout(n):
 		assert none is None and torch.equal(ch2, ref)
 	finally:
 		cube.set_is2024(True)
+
+
+def test_paced_multi_rotate_large_batch():
+	"""From 2 Mi states on multi_rotate runs with its loads released on a schedule and non-temporal stores (one tile per wave):
+	same results as below that size -- a sample against the oracle, everything against the inverse move, in place, with a
+	ragged last tile, and through the faces / directions entry."""
+	n = 2_100_003
+	g = torch.Generator(device="cuda")
+	g.manual_seed(21)
+	states = cube.device.apply_sequences(torch.randint(0, 12, (15, n), device="cuda", dtype=torch.uint8, generator=g), False, True)
+	acts = torch.randint(0, 12, (n,), device="cuda", dtype=torch.uint8, generator=g)
+	out = cube.device.multi_rotate(states, acts)
+	pick = torch.cat([torch.arange(0, 2048), torch.randint(0, n, (4096,)), torch.arange(n - 2048, n)]).cuda()
+	ref = c_oracle.multi_rotate(states[pick].cpu().numpy(), acts[pick].cpu().numpy())
+	assert (out[pick].cpu().numpy() == ref).all()
+	assert torch.equal(cube.device.multi_rotate(out, acts ^ 1), states)
+	small = torch.cat([cube.device.multi_rotate(states[i:i + 700_001], acts[i:i + 700_001]) for i in range(0, n, 700_001)])   # unpaced launches
+	assert torch.equal(small, out)
+	inplace = states.clone()
+	assert cube.device.multi_rotate(inplace, acts, inplace) is inplace and torch.equal(inplace, out)
+	faces, dirs = (acts // 2).cpu().numpy(), (1 - acts % 2).cpu().numpy()
+	assert torch.equal(cube.multi_rotate(states, faces, dirs), out)
