@@ -39,6 +39,7 @@ constexpr unsigned PACE_PULL_WGS = 128;                 // workgroups of a phase
 constexpr unsigned PACE_PULL_WGS_FIRST = 256;           // ... of the first phase
 constexpr unsigned PACE_PHASE_TILES = 16384;            // tiles per phase: 1 Mi parents, 20 MiB of parents in the Infinity Cache at a time
 constexpr size_t PACE_MIN_TILES = 3072;                 // launches below 196 608 parents keep the unpaced forms (equal at 100 k, +3 % at 250 k)
+constexpr unsigned PACE686_MIN_PARENTS = 65536;          // 6x8x6 fan-out: paced from 65 536 parents on
 constexpr unsigned long long PACE_MAX_WAIT_TICKS = 2000; // 20 us
 constexpr unsigned long long PACE_STALE_TICKS = 1500;   // a slot more than 15 us before the wave's own start belongs to an older launch
 constexpr size_t PACE_FIRST_TILES = 16384;              // tiles whose waves may start before the time base is this launch's (2 x the most waves a launch has resident)
@@ -1195,6 +1196,96 @@ void k_is_solved686(const u32x4 *__restrict__ states, uint8_t *__restrict__ flag
 	}
 }
 
+// The 6x8x6 fan-out in the paced form of k_expand12p: phases of `phase_groups` groups of GROUP parents, each opened by `pull_wgs`
+// reading workgroups; every other workgroup owns ONE group -- stages it, reduces it to slot colours for the goal test, HOLDS until
+// base + lead + slot x tau, then gathers and stores its GROUP x 12 children (GROUP x 3 456 B).  GROUP = 8: with four parents per
+// workgroup the 2 048 resident workgroups hold 28 MB of children, which at this kernel's 5 us from start to last store is 5.6 TB/s
+// -- 98 % of the groups missed their slots (profiles/r03_paced686_timeline.txt); eight parents per workgroup double what is in flight.
+template <bool FLAGS, int GROUP>
+__global__ __launch_bounds__(256)
+void k_fanout686p(const uint16_t *__restrict__ states, u32x4 *__restrict__ out, size_t n_in, uint8_t *__restrict__ flags, long long *__restrict__ stats,
+                  unsigned pull_wgs, unsigned phase_groups, unsigned tau_ps, unsigned lead)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t s_src[N_ACTIONS * 144];
+	__shared__ __attribute__((aligned(16))) uint16_t s_in[GROUP * 144];
+	__shared__ __attribute__((aligned(16))) uint8_t s_near[FLAGS ? N_ACTIONS * S686_SLOTS : 16];
+	__shared__ __attribute__((aligned(16))) uint8_t s_col[FLAGS ? GROUP * S686_SLOTS : 16];
+	const int tid = threadIdx.x;
+	const unsigned wgs_per_phase = pull_wgs + phase_groups;
+	const unsigned phase = blockIdx.x / wgs_per_phase, r = blockIdx.x - phase * wgs_per_phase;
+	if (r < pull_wgs) {                                                 // read phase; leaves before any barrier
+		const size_t p_first = (size_t)phase * phase_groups * GROUP;
+		const size_t p_count = n_in - p_first < (size_t)phase_groups * GROUP ? n_in - p_first : (size_t)phase_groups * GROUP;
+		pull_front_bytes(states + p_first * 144, p_count * S686_BYTES, (size_t)r * 4 + (tid >> 6), (size_t)pull_wgs * 4, tid & 63);
+		if (tid == 0 && ((r & 63) == 63 || r + 1 == pull_wgs))
+			__hip_atomic_fetch_max(&g_pace_base, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		return;
+	}
+	const unsigned long long start = __builtin_amdgcn_s_memrealtime();
+	const size_t slot = r - pull_wgs, g = (size_t)phase * phase_groups + slot;
+	if (pull_wgs == 0 && slot == 0 && tid == 0) __hip_atomic_fetch_max(&g_pace_base, start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	const unsigned long long base = __hip_atomic_load(&g_pace_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	const size_t first = g * GROUP;
+	const int ng = first >= n_in ? 0 : (int)((n_in - first < (size_t)GROUP) ? (n_in - first) : (size_t)GROUP);
+	// the group's states (ng x 18 16-byte words) and the tables travel together
+	constexpr int PW = (GROUP * 18 + 255) / 256;
+	u32x4 pre[PW];
+	const u32x4 *all4 = reinterpret_cast<const u32x4 *>(states) + first * 18;
+	#pragma unroll
+	for (int k = 0; k < PW; k++) { const int i = k * 256 + tid; if (i < ng * 18) pre[k] = all4[i]; }
+	if (tid < N_ACTIONS * 144 / 16)
+		reinterpret_cast<u32x4 *>(s_src)[tid] = reinterpret_cast<const u32x4 *>(&D_TAB.src686[0][0])[tid];
+	if (FLAGS && tid >= 128 && tid < 128 + N_ACTIONS * S686_SLOTS / 16)
+		reinterpret_cast<u32x4 *>(s_near)[tid - 128] = reinterpret_cast<const u32x4 *>(&D_TAB.near686[0][0])[tid - 128];
+	#pragma unroll
+	for (int k = 0; k < PW; k++) { const int i = k * 256 + tid; if (i < ng * 18) reinterpret_cast<u32x4 *>(s_in)[i] = pre[k]; }
+	__syncthreads();
+	if (FLAGS)
+		for (int i = tid; i < ng * S686_SLOTS; i += 256) {                  // slot colours of the staged parents (k_rotate686)
+			const uint16_t *h = s_in + i * 3;
+			const uint32_t lo = (uint32_t)h[0] | ((uint32_t)h[1] << 16), hi = h[2];
+			uint32_t col = 255u;
+			if (hi == 0u) {
+				if (lo == 0x00000001u) col = 0; else if (lo == 0x00000100u) col = 1;
+				else if (lo == 0x00010000u) col = 2; else if (lo == 0x01000000u) col = 3;
+			} else if (lo == 0u) {
+				if (hi == 0x0001u) col = 4; else if (hi == 0x0100u) col = 5;
+			}
+			s_col[i] = (uint8_t)col;
+		}
+	PaceHold{base, start, slot, tau_ps, lead, tid & 63}();
+	u32x4 *dst = out + first * 12 * 18;
+	const int n_chunks = ng * 12 * 18;
+	for (int q = tid; q < n_chunks; q += 256) {
+		const int row_i = q / 18, k = q - row_i * 18;
+		const int local = row_i / 12;
+		const uint32_t a = (uint32_t)(row_i - local * 12);
+		const uint16_t *row = s_in + local * 144;
+		const u32x2 offs = *reinterpret_cast<const u32x2 *>(&s_src[a * 144 + k * 8]);
+		uint32_t h[8];
+		#pragma unroll
+		for (int i = 0; i < 8; i++) h[i] = row[((i < 4 ? offs.x : offs.y) >> (8 * (i & 3))) & 0xFFu];
+		__builtin_nontemporal_store(u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)}, dst + q);
+	}
+	if (FLAGS) {
+		__syncthreads();                                                  // s_col complete
+		for (int i = tid; i < ng * N_ACTIONS; i += 256) {
+			const int local = i / N_ACTIONS, a = i - local * N_ACTIONS;
+			const uint32_t *c = reinterpret_cast<const uint32_t *>(s_col + local * S686_SLOTS);
+			const uint32_t *w = reinterpret_cast<const uint32_t *>(s_near + a * S686_SLOTS);
+			uint32_t diff = 0;
+			#pragma unroll
+			for (int k = 0; k < S686_SLOTS / 4; k++) diff |= c[k] ^ w[k];
+			const size_t o = first * N_ACTIONS + i;
+			if (flags != nullptr) flags[o] = diff == 0u ? 1 : 0;
+			if (diff == 0u && stats != nullptr) {
+				atomicAdd(reinterpret_cast<unsigned long long *>(&stats[0]), 1ull);
+				atomicMin(&stats[1], (long long)o);
+			}
+		}
+	}
+}
+
 // int8 one-hot -> T one-hot, elementwise widening (cube.py:363-369)
 template <typename T, int ELEM_BYTES>
 __global__ __launch_bounds__(256)
@@ -2060,8 +2151,27 @@ void launch_rotate686(const int8_t *states, const uint8_t *actions, int8_t *out,
 {
 	if (fanout) {
 		const size_t n_in = n_out / 12;
-		// (The paced form of the 20-byte fan-out was tried here and removed: 98 % of the groups were behind their slot -- the gathers
-		//  deliver a group every 2.5 ns where the schedule asks for one every 1.85 ns --, 0.72 against 0.74; profiles/r03_paced686_timeline.txt.)
+		// Paced form (k_fanout686p, eight parents per workgroup) from 65 536 parents on; phases of 65 536 parents = 18.9 MB:
+		// 0.71 -> 0.79-0.80 of peak cache-neutral at 200 k parents (four parents per workgroup 0.68, sixteen 0.74-0.76; profiles/r03_paced686.json).
+		{
+			static const unsigned min_parents = env_u("RK_PACE686_MIN", PACE686_MIN_PARENTS);
+			const PaceConfig &pc = pace_config();
+			if (pc.on && n_in >= min_parents) {
+				constexpr unsigned G = 8;
+				const size_t n_groups = (n_in + G - 1) / G;
+				const unsigned phase_groups = (unsigned)(((size_t)pc.phase_tiles * 4) / G);
+				const unsigned tau = (unsigned)((unsigned long long)pc.tau_ps * (G * 12 * S686_BYTES + G * 12) / 16128u);
+				const size_t n_phases = (n_groups + phase_groups - 1) / phase_groups;
+				const unsigned grid = (unsigned)((n_phases - 1) * (size_t)(pc.pull_wgs + phase_groups) + pc.pull_wgs + (n_groups - (n_phases - 1) * phase_groups));
+				if (flags != nullptr || stats != nullptr)
+					hipLaunchKernelGGL((k_fanout686p<true, G>), dim3(grid), dim3(256), 0, st, (const uint16_t *)states, (u32x4 *)out, n_in, flags, stats,
+					                   pc.pull_wgs, phase_groups, tau, pc.lead);
+				else
+					hipLaunchKernelGGL((k_fanout686p<false, G>), dim3(grid), dim3(256), 0, st, (const uint16_t *)states, (u32x4 *)out, n_in, (uint8_t *)nullptr,
+					                   (long long *)nullptr, pc.pull_wgs, phase_groups, tau, pc.lead);
+				return;
+			}
+		}
 		const unsigned grid = grid_for(n_in, 4, 8192u);               // persistent from 32 k parents on: the next group's states are in flight
 		if (flags != nullptr || stats != nullptr)          // children and their solved flags in ONE launch
 			hipLaunchKernelGGL((k_rotate686<true, true>), dim3(grid), dim3(256), 0, st, (const uint16_t *)states, actions, (u32x4 *)out, n_in, flags, stats);

@@ -510,9 +510,10 @@ def test_paced_fanout_replayed_from_a_hipgraph_and_on_two_streams():
 
 @pytest.mark.parametrize("n", [40_003, 70_001])
 def test_repr686_paced_fanout(n):
-	"""From 32 768 parents on the 6x8x6 fan-out runs in the paced form (one group per workgroup, read phases, stores on a
-	schedule; 70 001 parents are two phases): children against the per-state kernel on device, a sample and the planted
-	solved children against the oracle, flags and statistics against the goal-test kernel."""
+	"""From 65 536 parents on the 6x8x6 fan-out runs in the paced form (k_fanout686p: eight parents per workgroup, read phases,
+	stores on a schedule; 70 001 parents are two phases and a ragged last group), below that on the persistent grid (40 003):
+	children against the per-state kernel on device, a sample and the planted solved children against the oracle, flags and
+	statistics against the goal-test kernel."""
 	cube.set_is2024(False)
 	try:
 		g = torch.Generator(device="cuda")
