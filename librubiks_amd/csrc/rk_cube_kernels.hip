@@ -570,9 +570,14 @@ struct PaceHold {
 		unsigned long long b = base;
 		asm volatile("" ::: "memory");
 		// A wave of the first residency may have started before this launch's read phase ended: the base it read is the previous
-		// launch's then, its slot lies far in the past.  It re-reads until the base is this launch's (bounded: ~30 us).
+		// launch's then, its slot lies far in the past.  It re-reads until the base is this launch's -- at most eight times
+		// (~15 us; a read phase lasts 4-8).  The test cannot tell "another phase's base" from "this launch is more than 15 us
+		// behind its schedule" (two processes sharing the GPU): every wave then polls before it goes, which is why the bound is
+		// tight.  Three sharper tests were tried -- a phase tag riding in the low bits of the base, first-residency waves only,
+		// the first reader publishing an estimate of the read phase's end -- and each lost 1-4 % at 2-32 M parents or more in the
+		// 6x8x6 fan-out on the boxes they were measured on; this one is what the records of profiles/ were taken with.
 		if (tile < PACE_FIRST_TILES)
-			for (int i = 0; i < 20 && b + slot + PACE_STALE_TICKS < start; i++) {
+			for (int i = 0; i < 8 && b + slot + PACE_STALE_TICKS < start; i++) {
 				__builtin_amdgcn_s_sleep(16);
 				b = __hip_atomic_load(&g_pace_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
