@@ -559,3 +559,24 @@ def test_paced_multi_rotate_large_batch():
 	assert cube.device.multi_rotate(inplace, acts, inplace) is inplace and torch.equal(inplace, out)
 	faces, dirs = (acts // 2).cpu().numpy(), (1 - acts % 2).cpu().numpy()
 	assert torch.equal(cube.multi_rotate(states, faces, dirs), out)
+
+
+def test_paced_fanout_misaligned_views():
+	"""The paced fan-out on views that are only 4-byte aligned (parents one row into a tensor: the read phase needs 16-byte
+	alignment and is skipped) and with a flag buffer four bytes into a tensor (the 768-byte flag blocks go out as dwords)."""
+	n = 250_000
+	g = torch.Generator(device="cuda")
+	g.manual_seed(17)
+	base = cube.device.apply_sequences(torch.randint(0, 12, (6, n + 1), device="cuda", dtype=torch.uint8, generator=g), False, True)
+	parents = base[1:]
+	assert parents.data_ptr() % 16 != 0
+	ref_ch, ref_fl = cube.device.expand12(parents.clone())
+	flag_store = torch.empty(12 * n + 4, dtype=torch.uint8, device="cuda")
+	ch, fl = cube.device.expand12(parents, solved=flag_store[4:])
+	assert torch.equal(ch, ref_ch) and torch.equal(fl, ref_fl)
+	with pytest.raises(_ffi.RubiksHipError, match="4-byte aligned"):                     # refused loudly, not mis-stored
+		cube.device.expand12(parents, solved=flag_store[1:12 * n + 1])
+	pick = torch.randint(0, n, (2048,)).cuda()
+	want_ch, want_fl = c_oracle.expand12(parents[pick].cpu().numpy())
+	assert (ref_ch.view(n, 12, 20)[pick].reshape(-1, 20).cpu().numpy() == want_ch).all()
+	assert (ref_fl.view(n, 12)[pick].reshape(-1).cpu().numpy() == want_fl).all()
