@@ -43,7 +43,8 @@ BYTES_PER_PARENT = 20 + 240 + 12          # read parent, write 12 children, writ
 READ_BYTES_PER_PARENT = 20
 N_IN_SETS = 32                            # rotating parent sets: 32 x 20 MB = 640 MB of distinct input (> 2 x 256 MiB)
 N_OUT_SETS = 4                            # rotating children/flag sets: 3 x 252 MB pass between two writes of a line
-KERNEL = "rk::k_expand12p<true>"                            # the instantiation launch_expand12 picks at 1 M parents (rocprofv3's spelling)
+PACED = os.environ.get("RK_PACE", "1") != "0"
+KERNEL = "rk::k_expand12p<true>" if PACED else "rk::k_expand12r<true, 2, 1, false, 0>"                            # the instantiation launch_expand12 picks at 1 M parents (rocprofv3's spelling)
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8.0 TB/s spec (about 6.3 TB/s achievable)
 
 
@@ -282,7 +283,9 @@ def main():
 			"roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
 			             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_provenance": traffic_src,
 			             "achieved_read": achieved_read, "frac_read": achieved_read / HBM_PEAK_GBS,
-			             "kernel": KERNEL, "kernel_ms_back_to_back": kernel_ms,
+			             "kernel": KERNEL, "kernel_form": "paced: a read phase (parents -> Infinity Cache), then one 64-parent tile per wave stored on a 2.10 ns/tile "
+			                                    "schedule (DESIGN 3 step 3; RK_PACE=0 runs the unpaced ring form)" if PACED else "ring form (RK_PACE=0)",
+			             "kernel_ms_back_to_back": kernel_ms,
 			             "per_launch_event_pairs_ms": {"min": per[0], "median": per[len(per) // 2], "mean": sum(per) / len(per)},
 			             "kernel_ms_4_input_sets": kernel_ms_4in, "frac_4_input_sets": BYTES_PER_PARENT * N_PARENTS / (kernel_ms_4in * 1e-3) / 1e9 / HBM_PEAK_GBS,
 			             "algorithmic_bytes_per_launch": BYTES_PER_PARENT * N_PARENTS,
