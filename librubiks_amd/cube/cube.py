@@ -147,6 +147,28 @@ def _actions_from(faces, dirs, n: int) -> torch.Tensor:
 	return torch.from_numpy((2 * f + (1 - d)).astype(np.uint8)).to(gpu)
 
 
+_PINNED_FROM = 1 << 20      # device -> host results from 1 MiB on land in page-locked memory
+
+
+def _to_host(t: torch.Tensor) -> np.ndarray:
+	"""
+	Device tensor -> NumPy array.  Large results (the 240 MB of children of a 1 M-state fan-out) are copied into page-locked
+	memory from torch's caching host allocator: a fresh pageable array costs its first-touch page faults on top of a staged
+	copy -- 36-45 ms per 1 M parents against 8-9 ms this way (benchmarks/kernels.py, host_path).  The array keeps its tensor
+	alive; a refused page-locked allocation falls back to the pageable copy.
+	"""
+	if t.numel() * t.element_size() >= _PINNED_FROM:
+		try:
+			host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+		except RuntimeError:
+			host = None
+		if host is not None:
+			host.copy_(t, non_blocking=True)
+			torch.cuda.current_stream().synchronize()
+			return host.numpy()
+	return t.cpu().numpy()
+
+
 def _new_stats() -> torch.Tensor:
 	return torch.tensor([0, INT64_MAX], dtype=torch.int64, device=gpu)
 
@@ -348,7 +370,7 @@ def multi_rotate(states: np.ndarray, faces: np.ndarray, directions: np.ndarray) 
 		return out
 	acts = _actions_from(faces, directions, n)
 	out = device.multi_rotate(_to_dev_states(states), acts)
-	return out if _is_dev(states) else out.cpu().numpy()
+	return out if _is_dev(states) else _to_host(out)
 
 
 def expand(states: np.ndarray, return_solved: bool = False):
@@ -361,7 +383,7 @@ def expand(states: np.ndarray, return_solved: bool = False):
 	dev_in = _is_dev(states)
 	children, solved = device.expand12(_to_dev_states(states), want_flags=return_solved)
 	if not dev_in:
-		children = children.cpu().numpy()
+		children = _to_host(children)
 		solved = solved.cpu().numpy().astype(bool) if return_solved else None
 	elif return_solved:
 		solved = solved.bool()
@@ -447,7 +469,7 @@ def rev_actions(actions: np.ndarray) -> np.ndarray:
 ##################
 def _apply(actions_dg: np.ndarray, with_solved: bool, only_last: bool) -> np.ndarray:
 	acts = torch.from_numpy(np.ascontiguousarray(actions_dg, dtype=np.uint8)).to(gpu)
-	return device.apply_sequences(acts, with_solved, only_last).cpu().numpy()
+	return _to_host(device.apply_sequences(acts, with_solved, only_last))
 
 
 def scramble(depth: int, force_not_solved=False):
