@@ -85,6 +85,12 @@ int rk_stream_synchronize(void *stream);
 int rk_multi_rotate(int repr, const int8_t *d_states, const uint8_t *d_actions, int8_t *d_out,
                     size_t n, void *stream);
 /* Same with the reference's (faces, directions) pair as two uint8 arrays. */
+/* The device-pointer entries (rk_multi_rotate, rk_multi_rotate_fd, rk_apply_sequences) take action codes as they are: a code
+ * >= 12 is treated as action 0 -- the kernels never index past the move table -- and leaves a sticky mark on the device.
+ * This reads the mark into *h_seen (1: some launch since the last call saw such a code) and clears it; it synchronises
+ * `stream`.  The host entries (rk_*_host) validate their arrays and fail with RK_EINVAL instead, like the reference's
+ * table indexing raises IndexError (cube.py:33-34, 256-263). */
+int rk_bad_actions_seen(int *h_seen, void *stream);
 int rk_multi_rotate_fd(int repr, const int8_t *d_states, const uint8_t *d_faces, const uint8_t *d_dirs,
                        int8_t *d_out, size_t n, void *stream);
 

@@ -37,6 +37,7 @@ SIGNATURES = {
 	"rk_memset": (_i, [_vp, _i, _sz, _vp]),
 	"rk_stream_synchronize": (_i, [_vp]),
 	"rk_multi_rotate": (_i, [_i, _vp, _vp, _vp, _sz, _vp]),
+	"rk_bad_actions_seen": (_i, [C.POINTER(C.c_int), _vp]),
 	"rk_multi_rotate_fd": (_i, [_i, _vp, _vp, _vp, _vp, _sz, _vp]),
 	"rk_expand12": (_i, [_i, _vp, _vp, _vp, _vp, _sz, _vp]),
 	"rk_expand12_soa": (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),

@@ -166,6 +166,15 @@ int rk_multi_rotate(int repr, const int8_t *d_states, const uint8_t *d_actions, 
 	return RK_OK;
 }
 
+int rk_bad_actions_seen(int *h_seen, void *stream)
+{
+	if (!h_seen) return fail(RK_EINVAL, "rk_bad_actions_seen: null pointer");
+	const int r = read_bad_actions((hipStream_t)stream);
+	if (r < 0) return fail(RK_EHIP, "rk_bad_actions_seen: could not read the device flag");
+	*h_seen = r;
+	return RK_OK;
+}
+
 int rk_multi_rotate_fd(int repr, const int8_t *d_states, const uint8_t *d_faces, const uint8_t *d_dirs, int8_t *d_out,
                        size_t n, void *stream)
 {

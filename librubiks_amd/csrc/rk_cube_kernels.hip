@@ -729,6 +729,15 @@ void k_states_to_soa(const uint32_t *__restrict__ states, uint32_t *__restrict__
 constexpr int ROW_TILE = 256;     // states per wave tile
 constexpr int ROW_WAVES = 4;
 
+// Device-pointer entries take action codes as they are.  A code >= 12 is treated as action 0 (the kernels never index past the
+// move table) AND leaves a mark: g_bad_actions becomes non-zero and stays so until rk_bad_actions_seen() reads and clears it, so
+// that a caller who passes garbage can find out without paying a reduction and a synchronisation on every call.
+__device__ unsigned g_bad_actions;
+__device__ __forceinline__ void note_bad_action(bool bad)
+{
+	if (__ballot(bad) != 0ull && bad) atomicOr(&g_bad_actions, 1u);      // never taken on valid input
+}
+
 // Reads, too, go faster in order and at a fixed rate (profiles/r03_store_stream.json, ids 310-312: a pure read stream of 5 KiB per
 // wave runs at 6.27 TB/s when every wave loads the moment it starts and at 6.85 TB/s when wave w loads at t0 + w x 0.70 ns; at
 // 0.66 ns it is back at 6.3).  A paced per-row launch has one tile per wave; the wave of tile 0 sets the time base (there is no read
@@ -807,14 +816,18 @@ void k_multi_rotate(const uint32_t *__restrict__ states, const uint8_t *__restri
 				const uint32_t a = (w >> (8 * q)) & 0xFFu;
 				act[q] = a < 12u ? a : 0u;
 			}
+			note_bad_action(((w | (w >> 1)) & (w >> 2) & 0x08080808u) != 0u || (w & 0xF0F0F0F0u) != 0u);     // any byte >= 12
 		} else {
+			bool bad_any = false;
 			#pragma unroll
 			for (int q = 0; q < 4; q++) {
 				const size_t i = p0 + 4 * lane + q;
 				uint32_t a = 0;
 				if (4 * lane + q < np) a = SPLIT_FD ? (2u * act_or_faces[i] + (1u - dirs[i])) : act_or_faces[i];
+				bad_any |= a >= 12u;
 				act[q] = a < 12u ? a : 0u;            // out-of-range actions are rejected on the host; never index past the table
 			}
+			note_bad_action(bad_any);
 		}
 		wave_lds_fence();
 
@@ -954,8 +967,10 @@ void k_apply_sequences(const uint8_t *__restrict__ actions, int moves, int games
 		for (int j = 0; j < 5; j++) o[j] = s[j];
 		o += STATE_DWORDS;
 	}
+	uint32_t worst = 0;
 	for (int d = 0; d < moves; d++) {
 		uint32_t a = actions[(size_t)d * games + g];
+		worst = a > worst ? a : worst;
 		a = a < 12u ? a : 0u;
 		uint32_t tab[12];
 		load_action_table(s_act, a, tab);
@@ -970,6 +985,7 @@ void k_apply_sequences(const uint8_t *__restrict__ actions, int moves, int games
 		#pragma unroll
 		for (int j = 0; j < 5; j++) o[j] = s[j];
 	}
+	if (worst >= 12u) atomicOr(&g_bad_actions, 1u);                      // never taken on valid input
 }
 
 // ================================================================================================================
@@ -1137,7 +1153,7 @@ void k_rotate686(const uint16_t *__restrict__ states, const uint8_t *__restrict_
 			int local;
 			uint32_t a;
 			if (FANOUT) { local = r / 12; a = (uint32_t)(r - local * 12); }
-			else        { local = r; a = actions[first + r]; a = a < 12u ? a : 0u; }
+			else        { local = r; a = actions[first + r]; if (a >= 12u) atomicOr(&g_bad_actions, 1u); a = a < 12u ? a : 0u; }
 			const uint16_t *row = s_in + local * 144;
 			const u32x2 offs = *reinterpret_cast<const u32x2 *>(&s_src[a * 144 + k * 8]);
 			uint32_t h[8];
@@ -2078,6 +2094,16 @@ void launch_multi_rotate(const int8_t *states, const uint8_t *actions, const uin
 	else
 		hipLaunchKernelGGL(k_multi_rotate<false>, dim3(grid), dim3(ROW_WAVES * WAVE), 0, st, (const uint32_t *)states, actions,
 		                   (const uint8_t *)nullptr, (uint32_t *)out, n, n_tiles, tau, pc.lead, nt);
+}
+
+// reads and clears the mark bad action codes leave (synchronises `st`); negative on a HIP error
+int read_bad_actions(hipStream_t st)
+{
+	unsigned h = 0, zero = 0;
+	if (hipMemcpyFromSymbolAsync(&h, HIP_SYMBOL(g_bad_actions), sizeof h, 0, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+	if (hipMemcpyToSymbolAsync(HIP_SYMBOL(g_bad_actions), &zero, sizeof zero, 0, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+	if (hipStreamSynchronize(st) != hipSuccess) return -1;
+	return h != 0 ? 1 : 0;
 }
 
 void launch_multi_is_solved(const int8_t *states, uint8_t *flags, long long *stats, size_t n, hipStream_t st)

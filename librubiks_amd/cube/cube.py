@@ -14,6 +14,8 @@ from __future__ import annotations
 
 import functools
 
+import ctypes as C
+
 import numpy as np
 import torch
 
@@ -188,8 +190,18 @@ class device:
 
 	#: Device-pointer entries take action codes as they are: the kernels treat a code >= 12 as action 0 so that they
 	#: never index past the move table, but the result is then meaningless (the host paths raise IndexError, as the
-	#: reference's table indexing would).  Set to True to pay one reduction + sync per call and get the IndexError.
+	#: reference's table indexing would).  Such a code leaves a sticky mark on the device: `device.bad_actions_seen()`
+	#: reads and clears it (one synchronisation, whenever the caller likes).  Set `check_actions` to True to pay one
+	#: reduction + sync per call and get the IndexError at once.
 	check_actions = False
+
+	@staticmethod
+	def bad_actions_seen() -> bool:
+		"""True if a device-pointer call since the last check was given an action code outside 0..11 (clears the mark)."""
+		_ffi.require_gpu()
+		seen = C.c_int(0)
+		_ffi.check(_ffi.lib().rk_bad_actions_seen(C.byref(seen), _ffi.stream_ptr()))
+		return bool(seen.value)
 
 	@staticmethod
 	def _validate(actions: torch.Tensor):

@@ -580,3 +580,40 @@ def test_paced_fanout_misaligned_views():
 	want_ch, want_fl = c_oracle.expand12(parents[pick].cpu().numpy())
 	assert (ref_ch.view(n, 12, 20)[pick].reshape(-1, 20).cpu().numpy() == want_ch).all()
 	assert (ref_fl.view(n, 12)[pick].reshape(-1).cpu().numpy() == want_fl).all()
+
+
+def test_bad_action_codes_leave_a_mark():
+	"""Device-pointer entries do not validate action codes (no reduction, no synchronisation per call): a code >= 12 acts as
+	action 0 and sets a sticky mark that `cube.device.bad_actions_seen()` reads and clears -- on the aligned fast path, on the
+	ragged path, in the scrambler and in the 6x8x6 move kernel."""
+	g = torch.Generator(device="cuda")
+	g.manual_seed(3)
+	cube.device.bad_actions_seen()
+	for n, pos in ((1024, 700), (1001, 1000)):
+		states = cube.device.apply_sequences(torch.randint(0, 12, (5, n), device="cuda", dtype=torch.uint8, generator=g), False, True)
+		acts = torch.randint(0, 12, (n,), device="cuda", dtype=torch.uint8, generator=g)
+		good = cube.device.multi_rotate(states, acts)
+		assert not cube.device.bad_actions_seen()
+		bad = acts.clone()
+		bad[pos] = 200
+		out = cube.device.multi_rotate(states, bad)
+		zero = acts.clone()
+		zero[pos] = 0
+		assert torch.equal(out, cube.device.multi_rotate(states, zero))        # treated as action 0
+		assert cube.device.bad_actions_seen() and not cube.device.bad_actions_seen()
+		assert torch.equal(cube.device.multi_rotate(states, acts), good) and not cube.device.bad_actions_seen()
+	seq = torch.randint(0, 12, (6, 300), device="cuda", dtype=torch.uint8, generator=g)
+	seq[3, 17] = 12
+	cube.device.apply_sequences(seq, False, True)
+	assert cube.device.bad_actions_seen()
+	cube.set_is2024(False)
+	try:
+		s6 = dev(np.broadcast_to(orc.SOLVED686, (500, 6, 8, 6)).copy())
+		a6 = torch.randint(0, 12, (500,), device="cuda", dtype=torch.uint8, generator=g)
+		cube.device.multi_rotate(s6, a6)
+		assert not cube.device.bad_actions_seen()
+		a6[499] = 13
+		cube.device.multi_rotate(s6, a6)
+		assert cube.device.bad_actions_seen()
+	finally:
+		cube.set_is2024(True)
