@@ -816,7 +816,7 @@ void k_multi_rotate(const uint32_t *__restrict__ states, const uint8_t *__restri
 				const uint32_t a = (w >> (8 * q)) & 0xFFu;
 				act[q] = a < 12u ? a : 0u;
 			}
-			note_bad_action(((w | (w >> 1)) & (w >> 2) & 0x08080808u) != 0u || (w & 0xF0F0F0F0u) != 0u);     // any byte >= 12
+			note_bad_action(((w & (w << 1)) & 0x08080808u) != 0u || (w & 0xF0F0F0F0u) != 0u);                // any byte >= 12: bits 3 and 2, or a high nibble
 		} else {
 			bool bad_any = false;
 			#pragma unroll

@@ -589,13 +589,14 @@ def test_bad_action_codes_leave_a_mark():
 	g = torch.Generator(device="cuda")
 	g.manual_seed(3)
 	cube.device.bad_actions_seen()
-	for n, pos in ((1024, 700), (1001, 1000)):
+	for n, pos, code in ((1024, 700, 200), (1024, 3, 12), (1024, 1023, 15), (1001, 1000, 12), (777, 0, 255)):
 		states = cube.device.apply_sequences(torch.randint(0, 12, (5, n), device="cuda", dtype=torch.uint8, generator=g), False, True)
 		acts = torch.randint(0, 12, (n,), device="cuda", dtype=torch.uint8, generator=g)
+		acts[:12] = torch.arange(12, dtype=torch.uint8, device="cuda")      # every valid code, 8..11 included
 		good = cube.device.multi_rotate(states, acts)
 		assert not cube.device.bad_actions_seen()
 		bad = acts.clone()
-		bad[pos] = 200
+		bad[pos] = code
 		out = cube.device.multi_rotate(states, bad)
 		zero = acts.clone()
 		zero[pos] = 0
