@@ -618,3 +618,22 @@ def test_bad_action_codes_leave_a_mark():
 		assert cube.device.bad_actions_seen()
 	finally:
 		cube.set_is2024(True)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_paced_as_oh_every_dtype(dtype):
+	"""From 8 192 tiles on (65 536 states for f32, 131 072 for the 16-bit types) `as_oh` runs in the paced form (read phases,
+	non-temporal stores on a schedule).  300 007 states: a ragged last tile; two phases for bf16/f16 need more than 1 Mi
+	states, which the second size provides.  Against the index of the one and against the unpaced kernel on slices."""
+	g = torch.Generator(device="cuda")
+	g.manual_seed(480)
+	for n in (300_007, 1_100_003):
+		states = cube.device.apply_sequences(torch.randint(0, 12, (9, n), device="cuda", dtype=torch.uint8, generator=g), False, True)
+		oh = cube.device.as_oh(states, dtype=dtype)
+		assert oh.shape == (n, 480) and oh.dtype == dtype
+		idx = (states.to(torch.int64) + 24 * torch.arange(20, device="cuda")).reshape(n, 20)
+		assert bool((oh.view(n, 20, 24).argmax(-1).reshape(n, 20) + 24 * torch.arange(20, device="cuda") == idx).all())
+		assert float(oh.float().sum()) == 20.0 * n
+		for lo in (0, n // 2, n - 5000):
+			assert torch.equal(cube.device.as_oh(states[lo:lo + 5000], dtype=dtype), oh[lo:lo + 5000])      # unpaced launches
+		del oh
