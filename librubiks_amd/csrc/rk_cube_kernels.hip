@@ -6,6 +6,12 @@
 //   registers --v_perm_b32 table look-ups / byte transposes--> LDS --16 B/lane coalesced--> global
 // The move tables (576..768 B) and the solved state live in the constant segment and are staged in LDS once per
 // workgroup.  LDS staging areas are private to a wave, so the streaming loops contain no s_barrier.
+//
+// The large launches of the write-heavy kernels (fan-out, as_oh, 6x8x6 fan-out, multi_rotate) run in a PACED form (round 3,
+// DESIGN 3 steps 3-4; "expand12, paced form" below has the reasons): the inputs of a phase are read first, into the Infinity
+// Cache, and every tile's stores are then held until the tile's slot on a fixed-rate schedule of the constant 100 MHz clock,
+// because HBM takes an ordered, rate-limited store stream 25 % faster than the same bytes from thousands of independent waves
+// and reads mixed into it cost 2.5 x their share.  Only WHEN a finished tile is stored depends on any of that (RK_PACE=0: never).
 #include <cstdlib>
 
 #include "rk_device.h"
