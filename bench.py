@@ -31,12 +31,34 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
 	sys.path.insert(0, ROOT)
+
+
+def parse_args(argv=None):
+	ap = argparse.ArgumentParser()
+	ap.add_argument("--gpus", type=int, default=1)
+	ap.add_argument("--steps", type=int, default=300)
+	ap.add_argument("--warmup", type=int, default=30)
+	ap.add_argument("--no-cpu-baseline", action="store_true")
+	ap.add_argument("--no-search-legs", action="store_true", help="skip the configs[2] / configs[3] legs behind the timed region (N = 1 only)")
+	ap.add_argument("--dry-run", action="store_true", help="launch path only: rendezvous, barrier and the MAX over ranks, no GPU work "
+	                "(what the CPU test of `--gpus N` without a launcher runs)")
+	return ap.parse_args(argv)
+
+
+if __name__ == "__main__":
+	# `python bench.py --gpus N` without a launcher: start the N ranks here, BEFORE torch or anything that touches the GPU is
+	# imported (benchmarks/spawn.py: fresh child processes with the launcher's environment, rank 0's JSON line relayed, the
+	# exit code of the first rank that fails).  Under torch.distributed.run WORLD_SIZE is set and this is skipped.
+	_a = parse_args()
+	if _a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+		from benchmarks import spawn
+		sys.exit(spawn.run_ranks(os.path.abspath(__file__), sys.argv[1:], _a.gpus))
+
+import numpy as np
+import torch
 
 N_PARENTS = 1_000_000
 BYTES_PER_PARENT = 20 + 240 + 12          # read parent, write 12 children, write 12 solved flags
@@ -158,20 +180,34 @@ def max_over_ranks(elapsed: float, dist, device) -> float:
 	return float(t.item())
 
 
+def dry_run(args, rank, world):
+	"""The launch path without the GPU: process group over gloo, the barrier and the MAX-over-ranks reduction of the timed
+	region, one JSON line from rank 0.  No kernel runs, `value` is null: this checks that N ranks start, meet and report."""
+	dist = None
+	if world > 1:
+		import torch.distributed as dist
+		dist.init_process_group("gloo")
+		dist.barrier()
+	t = max_over_ranks(0.001 * (rank + 1), dist, torch.device("cpu"))
+	if rank == 0:
+		print(json.dumps({"metric": "cube node-expansions/sec (12-child fan-out) at 1M-state batch", "value": None, "dry_run": True,
+		                  "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "max_over_ranks_s": t,
+		                  "self_spawned": os.environ.get("RK_SELF_SPAWNED") == "1"}), flush=True)
+	if dist is not None:
+		dist.barrier()
+		dist.destroy_process_group()
+
+
 def main():
-	ap = argparse.ArgumentParser()
-	ap.add_argument("--gpus", type=int, default=1)
-	ap.add_argument("--steps", type=int, default=300)
-	ap.add_argument("--warmup", type=int, default=30)
-	ap.add_argument("--no-cpu-baseline", action="store_true")
-	args = ap.parse_args()
+	args = parse_args()
 
 	rank = int(os.environ.get("RANK", "0"))
 	local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 	world = int(os.environ.get("WORLD_SIZE", "1"))
 	if world != args.gpus:
-		if world == 1 and args.gpus > 1:
-			sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+		sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus must agree")
+	if args.dry_run:
+		return dry_run(args, rank, world)
 	# One rank per GPU.  RK_BENCH_BACKEND=gloo is a rehearsal mode for a one-GPU box (several ranks share cuda:0 and
 	# the only collectives -- barrier and the MAX of the elapsed times -- go through the host); the driver uses nccl (= RCCL).
 	backend = os.environ.get("RK_BENCH_BACKEND", "nccl")

@@ -5,7 +5,9 @@ over xGMI, depth-20 scrambles.  One process per GPU:
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \
         benchmarks/sharded.py --depth 20 --expansions 700 --max-states 4000000 --games 3
 
-(also runs with one process and no launcher: world = 1, the collectives short-circuit.)  RK_BENCH_BACKEND=gloo rehearses the
+or, without a launcher, `python benchmarks/sharded.py --world 8 ...`: the script then starts its own ranks (benchmarks/spawn.py:
+fresh child processes, before torch or the GPU is touched).  With one process and no --world: world = 1, the collectives
+short-circuit.  RK_BENCH_BACKEND=gloo rehearses the
 protocol with several ranks sharing one GPU (host-staged collectives).  Rank 0 prints one JSON object per game with the
 iteration time split into all-gather / select+expand / all-to-all / insert / net / push (device time between HIP events on the
 search stream) and one summary object.  No 8-GPU node was available to the build: the harness exists so that the number can be
@@ -17,14 +19,12 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def main():
+def parse_args():
 	ap = argparse.ArgumentParser()
+	ap.add_argument("--world", type=int, default=0, help="ranks to start when no launcher did (WORLD_SIZE unset); 0 = run as launched")
 	ap.add_argument("--depth", type=int, default=20)
 	ap.add_argument("--expansions", type=int, default=700)          # configs/main_eval.ini:9
 	ap.add_argument("--lam", type=float, default=0.16)              # configs/main_eval.ini:8
@@ -38,9 +38,25 @@ def main():
 	                "over the ranks (PartitionedMCTS: no collective in the loop, one all-gather of results at the end)")
 	ap.add_argument("--sims", type=int, default=4096)
 	ap.add_argument("--fused", default="", choices=["", "epilogue", "folded"], help="fused first layer mode of the net (not for the stub)")
-	args = ap.parse_args()
+	return ap.parse_args()
+
+
+if __name__ == "__main__":
+	_a = parse_args()
+	if _a.world > 1 and "WORLD_SIZE" not in os.environ:              # no launcher: start the ranks here, before any GPU call
+		from benchmarks import spawn
+		sys.exit(spawn.run_ranks(os.path.abspath(__file__), sys.argv[1:], _a.world))
+
+import numpy as np
+import torch
+
+
+def main():
+	args = parse_args()
 
 	rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+	if args.world and args.world != world:
+		sys.exit(f"--world {args.world} but WORLD_SIZE={world}")
 	local = int(os.environ.get("LOCAL_RANK", "0"))
 	backend = os.environ.get("RK_BENCH_BACKEND", "nccl")
 	dev = local % max(1, torch.cuda.device_count())

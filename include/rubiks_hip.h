@@ -84,15 +84,23 @@ int rk_stream_synchronize(void *stream);
  * applied to d_states[i].  d_out may equal d_states. */
 int rk_multi_rotate(int repr, const int8_t *d_states, const uint8_t *d_actions, int8_t *d_out,
                     size_t n, void *stream);
-/* Same with the reference's (faces, directions) pair as two uint8 arrays. */
-/* The device-pointer entries (rk_multi_rotate, rk_multi_rotate_fd, rk_apply_sequences) take action codes as they are: a code
- * >= 12 is treated as action 0 -- the kernels never index past the move table -- and leaves a sticky mark on the device.
- * This reads the mark into *h_seen (1: some launch since the last call saw such a code) and clears it; it synchronises
- * `stream`.  The host entries (rk_*_host) validate their arrays and fail with RK_EINVAL instead, like the reference's
- * table indexing raises IndexError (cube.py:33-34, 256-263). */
-int rk_bad_actions_seen(int *h_seen, void *stream);
+/* multi_rotate + multi_is_solved of the MOVED states in one launch -- the pair the reference's per-row callers always run back
+ * to back (agents.py:157-159 ValueSearch, :696-703 EGVM, train.py:277-281): d_out[i] = move d_actions[i] of d_states[i] (d_out
+ * may equal d_states), d_flags[i] (nullable) = d_out[i] is solved, d_stats (nullable, int64[2], initialised by the caller as for
+ * rk_expand12: [0] += solved rows, [1] = min(first solved row, previous value)); at least one of the two outputs.  20-byte
+ * states: 21 B read + 21 B written per state, the moved states are never read back.  (6x8x6: two launches inside.) */
+int rk_multi_rotate_solved(int repr, const int8_t *d_states, const uint8_t *d_actions, int8_t *d_out, uint8_t *d_flags,
+                           long long *d_stats, size_t n, void *stream);
+/* Same as rk_multi_rotate with the reference's (faces, directions) pair as two uint8 arrays (20-byte states only). */
 int rk_multi_rotate_fd(int repr, const int8_t *d_states, const uint8_t *d_faces, const uint8_t *d_dirs,
                        int8_t *d_out, size_t n, void *stream);
+/* The device-pointer entries (rk_multi_rotate, rk_multi_rotate_solved, rk_multi_rotate_fd, rk_apply_sequences) take action
+ * codes as they are: a code >= 12 is treated as action 0 -- the kernels never index past the move table -- and leaves a sticky
+ * mark on the device.  This reads the mark into *h_seen (1: some launch since the last call saw such a code) and clears it
+ * in ONE atomic exchange on the device, and synchronises `stream`.  The mark is per device, not per stream: it reports the
+ * launches of every stream.  The host entries (rk_*_host) validate their arrays and fail with RK_EINVAL instead, like the
+ * reference's table indexing raises IndexError (cube.py:33-34, 256-263). */
+int rk_bad_actions_seen(int *h_seen, void *stream);
 
 /* The 12-child fan-out `multi_rotate(repeat(S,12), *iter_actions(n))` (agents.py:277-281, :513,
  * :605; train.py:285) fused with `multi_is_solved` of the children (cube.py:88-89; agents.py:321,
@@ -186,6 +194,14 @@ int rk_astar_destroy(rk_astar_t *h);
 int rk_astar_reset(rk_astar_t *h, const int8_t *h_start_state, double lambda, void *stream);
 /* max_states of agents.py:236 (default: the capacity). */
 int rk_astar_set_budget(rk_astar_t *h, long long max_states, void *stream);
+/* increase_stack_size (agents.py:396-402, called from :273-274): grows the node pool to new_capacity states IN PLACE -- new
+ * arrays, device-to-device copies, one kernel that rebuilds the larger hash table; the open queue's sorted runs stay as they
+ * are (only the top run, which can hold the whole pool, moves to a larger buffer).  States, G, parents, actions, the open
+ * queue, the next pop list and every counter survive: a search that stopped at its loop guard because the pool was its
+ * budget continues after rk_astar_set_budget, and ends with the arrays of a search that started in the larger pool.  Call
+ * between iterations; synchronises `stream`; a hipGraph captured from this engine must be captured again (it holds the old
+ * arrays).  RK_ECAPACITY when the device has no room (the engine is untouched then). */
+int rk_astar_grow(rk_astar_t *h, size_t new_capacity, void *stream);
 int rk_astar_step_expand(rk_astar_t *h, void *d_onehot, int out_dtype, void *stream);
 int rk_astar_step_commit(rk_astar_t *h, const float *d_values, void *stream);
 /* The value vectors handed to rk_astar_step_commit / rk_astar_commit / rk_astar_shard_push are float32 (default) or, after
@@ -342,7 +358,14 @@ int rk_mcts_reset(rk_mcts_t *h, const int8_t *h_start_states, const long long *h
 int rk_mcts_roots_oh(rk_mcts_t *h, void *d_out, int out_dtype, void *stream);
 int rk_mcts_set_root_pv(rk_mcts_t *h, const float *d_probs, const float *d_values, void *stream);
 int rk_mcts_expand(rk_mcts_t *h, void *stream);
-/* Expand ahead: with sim_limit != 0 the backup + select launch ends by expanding the leaf it has just found (the first half
+/* rk_mcts_expand and hipGraphs: whether the path's leaf still has to be expanded is decided ON THE DEVICE (a per-tree word the
+ * expanding kernel sets and the backup consumes).  Called eagerly, rk_mcts_expand skips its launch when the previous backup +
+ * select call has expanded ahead; called on a stream that is being captured it always records the kernel, which leaves at once
+ * for trees that are expanded already -- so a step captured at ANY point (straight after rk_mcts_reset, or in the middle of
+ * a search) replays correctly from any state.  A captured step may also leave rk_mcts_expand out altogether once expand-ahead
+ * is on and one eager step has run (what MCTSBatch does: one launch less per replay); a backup that finds no expansion pending
+ * stops its tree with error 3 in rk_mcts_status instead of backing up stale children.
+ * Expand ahead: with sim_limit != 0 the backup + select launch ends by expanding the leaf it has just found (the first half
  * of the NEXT simulation's expand_leaf, agents.py:505-543), and the rk_mcts_expand call that follows it is then a no-op
  * without a launch: one launch and its dependent start-up less per simulation, same order of steps (select, expand, net,
  * backup).  sim_limit > 0: only while the simulation just backed up has a number below sim_limit (so that a search of
@@ -361,7 +384,8 @@ int rk_mcts_backup_select_logits(rk_mcts_t *h, const void *d_logits, int logits_
 /* Device pointer to the (T*12, 20) int8 child states of the pending simulation (what rk_mcts_children_oh encodes): a net
  * whose first layer reads states (rk_ohl_forward) can take them where they lie. */
 const int8_t *rk_mcts_children(rk_mcts_t *h);
-/* Synchronises.  h_status is (T, 6) int64: done, solved, n_states, simulations, path_len, error. */
+/* Synchronises.  h_status is (T, 6) int64: done, solved, n_states, simulations, path_len, error (1: path longer than max_path,
+ * 2: broken neighbour link, 3: backup without a pending expansion). */
 int rk_mcts_status(rk_mcts_t *h, long long *h_status, void *stream);
 /* Rows [first, first+count) of one tree's arrays to HOST buffers in the reference's dtypes (any may be NULL):
  * states int8 (count,20), neighbors int64 (count,12), leaves uint8, P/W/L float64 (count,12), V float64, N int64. */
@@ -370,6 +394,22 @@ int rk_mcts_export(rk_mcts_t *h, int tree, size_t first, size_t count, int8_t *h
 /* The tree's action queue: the solving actions if it solved (agents.py:483), else the actions of its current
  * descent (agents.py:492).  Also the visited node indices if h_nodes != NULL.  Returns the number of actions. */
 long long rk_mcts_path(rk_mcts_t *h, int tree, long long *h_actions, long long *h_nodes, size_t max_len, void *stream);
+
+/* increase_stack_size (agents.py:450-460, called from :503-504): every tree's pool grows to new_capacity states (and the path
+ * arrays to new_max_path entries) IN PLACE: new arrays, device-to-device copies, the hash tables rebuilt by one kernel.
+ * h_max_states (T, host, nullable = new_capacity) are the new state budgets; a tree that had stopped only at the loop guard
+ * `len + 12 <= max_states` (agents.py:476) and has room again continues with the expansion it was about to do.  Synchronises;
+ * a hipGraph captured from this engine must be captured again. */
+int rk_mcts_grow(rk_mcts_t *h, size_t new_capacity, size_t new_max_path, const long long *h_max_states, void *stream);
+/* The graph post-processing of a solved search (agents.py:483-486) on the device, for every tree that has solved:
+ * _complete_graph (agents.py:597-611: every leaf linked, both ways, to those of its 12 children that are in the graph -- one
+ * launch: fan-out, hash probe, neighbour writes) and the breadth-first search of _shorten_action_queue (agents.py:613-633)
+ * from the root to the solved state's index, one workgroup per tree, level by level in the reference's queue order (so the
+ * path found is the reference's, not just one of the same length).  Stream-ordered; rk_mcts_export afterwards shows the
+ * completed `neighbors`.  rk_mcts_graph_path (synchronises) returns the shortened action queue of `tree` -- its length, or -1
+ * when there is none (tree not solved: the queue of rk_mcts_path stands). */
+int rk_mcts_search_graph(rk_mcts_t *h, void *stream);
+long long rk_mcts_graph_path(rk_mcts_t *h, int tree, long long *h_actions, size_t max_len, void *stream);
 
 /* ---- host-pointer conveniences (allocate scratch, copy, launch, copy back, synchronise) ---- */
 int rk_multi_rotate_host(int repr, const int8_t *h_states, const uint8_t *h_actions, int8_t *h_out,

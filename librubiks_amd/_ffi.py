@@ -37,6 +37,7 @@ SIGNATURES = {
 	"rk_memset": (_i, [_vp, _i, _sz, _vp]),
 	"rk_stream_synchronize": (_i, [_vp]),
 	"rk_multi_rotate": (_i, [_i, _vp, _vp, _vp, _sz, _vp]),
+	"rk_multi_rotate_solved": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 	"rk_bad_actions_seen": (_i, [C.POINTER(C.c_int), _vp]),
 	"rk_multi_rotate_fd": (_i, [_i, _vp, _vp, _vp, _vp, _sz, _vp]),
 	"rk_expand12": (_i, [_i, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -55,6 +56,7 @@ SIGNATURES = {
 	"rk_astar_destroy": (_i, [_vp]),
 	"rk_astar_reset": (_i, [_vp, _vp, C.c_double, _vp]),
 	"rk_astar_set_budget": (_i, [_vp, C.c_longlong, _vp]),
+	"rk_astar_grow": (_i, [_vp, _sz, _vp]),
 	"rk_astar_step_expand": (_i, [_vp, _vp, _i, _vp]),
 	"rk_astar_step_commit": (_i, [_vp, _vp, _vp]),
 	"rk_astar_set_values_dtype": (_i, [_vp, _i]),
@@ -116,6 +118,9 @@ SIGNATURES = {
 	"rk_mcts_status": (_i, [_vp, _vp, _vp]),
 	"rk_mcts_export": (_i, [_vp, _i, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 	"rk_mcts_path": (C.c_longlong, [_vp, _i, _vp, _vp, _sz, _vp]),
+	"rk_mcts_grow": (_i, [_vp, _sz, _sz, _vp, _vp]),
+	"rk_mcts_search_graph": (_i, [_vp, _vp]),
+	"rk_mcts_graph_path": (C.c_longlong, [_vp, _i, _vp, _sz, _vp]),
 	"rk_multi_rotate_host": (_i, [_i, _vp, _vp, _vp, _sz, _vp]),
 	"rk_expand12_host": (_i, [_i, _vp, _vp, _vp, _vp, _sz, _vp]),
 	"rk_multi_is_solved_host": (_i, [_i, _vp, _vp, _vp, _sz, _vp]),

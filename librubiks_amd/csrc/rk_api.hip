@@ -166,6 +166,28 @@ int rk_multi_rotate(int repr, const int8_t *d_states, const uint8_t *d_actions, 
 	return RK_OK;
 }
 
+int rk_multi_rotate_solved(int repr, const int8_t *d_states, const uint8_t *d_actions, int8_t *d_out, uint8_t *d_flags, long long *d_stats,
+                           size_t n, void *stream)
+{
+	if (int e = check_repr(repr)) return e;
+	if (n == 0) return RK_OK;
+	if (!d_states || !d_actions || !d_out) return fail(RK_EINVAL, "rk_multi_rotate_solved: null pointer");
+	if (!d_flags && !d_stats) return fail(RK_EINVAL, "rk_multi_rotate_solved: flags or stats (or both) must be given");
+	if (misaligned(d_states, 4) || misaligned(d_out, 4)) return fail(RK_EINVAL, "rk_multi_rotate_solved: state arrays must be 4-byte aligned");
+	if (d_stats && misaligned(d_stats, 8)) return fail(RK_EINVAL, "rk_multi_rotate_solved: stats must be 8-byte aligned");
+	if (repr == RK_REPR_2024) {
+		launch_multi_rotate(d_states, d_actions, nullptr, d_out, n, (hipStream_t)stream, d_flags, d_stats, true);
+	} else {
+		// 6x8x6: the goal test reads the moved states back (two launches; the fused form exists for the 20-byte states)
+		if (misaligned(d_out, 16) || misaligned(d_states, 16)) return fail(RK_EINVAL, "rk_multi_rotate_solved: 6x8x6 state arrays must be 16-byte aligned");
+		if (d_out == d_states) return fail(RK_EINVAL, "rk_multi_rotate_solved: in-place not supported for the 6x8x6 representation");
+		launch_rotate686(d_states, d_actions, d_out, n, false, (hipStream_t)stream);
+		launch_is_solved686(d_out, d_flags, d_stats, n, (hipStream_t)stream);
+	}
+	RK_HIP(hipGetLastError());
+	return RK_OK;
+}
+
 int rk_bad_actions_seen(int *h_seen, void *stream)
 {
 	if (!h_seen) return fail(RK_EINVAL, "rk_bad_actions_seen: null pointer");

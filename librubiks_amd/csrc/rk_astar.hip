@@ -892,6 +892,22 @@ __global__ void k_set_budget(AstarDev d, int budget)
 	}
 }
 
+
+// After a growth (rk_astar_grow): every stored state back into the larger, cleared hash table.  Between iterations no slot is
+// tentative, so this is a plain insert of indices 1..n; the slot a state lands in may differ from the one it would have had
+// in a pool created at this size, which no result depends on (look-ups compare states).
+__global__ __launch_bounds__(256)
+void k_astar_rehash(AstarDev d)
+{
+	const int n = d.ctr[C_NSTATES];
+	for (int idx = 1 + blockIdx.x * blockDim.x + threadIdx.x; idx <= n; idx += gridDim.x * blockDim.x) {
+		uint32_t s[5];
+		load5(d.states + (size_t)idx * 5, s);
+		uint32_t slot = hash_state(s) & d.mask;
+		while (atomicCAS(&d.table[slot], 0u, (uint32_t)idx) != 0u) slot = (slot + 1) & d.mask;
+	}
+}
+
 // action indices from the root to node `index` by walking parents on the device (agents.py:244-251)
 __global__ void k_astar_walk(AstarDev d, int index, int32_t *out /* [0] = length or -1, then actions root -> node */, int max_len)
 {
@@ -1338,6 +1354,83 @@ int rk_astar_set_budget(rk_astar_t *h, long long max_states, void *stream)
 	hipLaunchKernelGGL(k_set_budget, dim3(1), dim3(64), 0, (hipStream_t)stream, h->d, (int)b);
 	RK_HIP(hipGetLastError());
 	h->budget_explicit = true;
+	return RK_OK;
+}
+
+
+/* increase_stack_size (agents.py:396-402; called from expand_batch, :273-274): the node pool grows to new_capacity states IN
+ * PLACE -- new arrays, device-to-device copies of the old ones, one kernel that rebuilds the (larger) hash table; the open
+ * queue's levels stay where they are, only the top level (which holds up to the whole pool) and any level above it get
+ * larger buffers.  Everything the search holds survives: states, G, parents, actions, the open queue, the pop list of the
+ * next iteration and every counter.  A search that had stopped at its loop guard because the pool was its budget goes on
+ * after rk_astar_set_budget.  Call between iterations (nothing pending); synchronises `stream`.  A hipGraph captured from
+ * this engine holds the old arrays and must be captured again. */
+int rk_astar_grow(rk_astar_t *h, size_t new_capacity, void *stream)
+{
+	if (!h || !h->ready) return fail(RK_ESTATE, "rk_astar_grow: reset the engine first");
+	if (h->pending) return fail(RK_ESTATE, "rk_astar_grow: an iteration is pending");
+	if (new_capacity <= h->cap) return new_capacity == h->cap ? RK_OK : fail(RK_EINVAL, "rk_astar_grow: %zu is below the current capacity %zu", new_capacity, h->cap);
+	if (new_capacity > 0x3FFFFFF0ull) return fail(RK_EINVAL, "rk_astar_grow: capacity %zu out of range", new_capacity);
+	hipStream_t st = (hipStream_t)stream;
+	const AstarDev old = h->d;
+	AstarDev d = old;
+	const size_t C1 = new_capacity + 1, C1_old = h->cap + 1;
+	d.cap1 = (uint32_t)C1;
+	uint64_t t = 1024;
+	while (t < 2 * (uint64_t)new_capacity + 2) t <<= 1;
+	d.mask = (uint32_t)(t - 1);
+	std::vector<void *> fresh, stale;
+	auto get = [&](size_t bytes) -> void * { void *q = nullptr; if (hipMalloc(&q, bytes + 64) != hipSuccess) return nullptr; fresh.push_back(q); return q; };
+	bool ok = true;
+	#define RK_GROW(ptr, type, cnt) do { d.ptr = (type *)get((cnt) * sizeof(type)); ok = ok && d.ptr != nullptr; stale.push_back(old.ptr); } while (0)
+	RK_GROW(states, uint32_t, C1 * 5); RK_GROW(G, int32_t, C1); RK_GROW(parents, int32_t, C1); RK_GROW(pact, uint8_t, C1); RK_GROW(prank, uint8_t, C1);
+	RK_GROW(table, uint32_t, (size_t)t); RK_GROW(mark, uint32_t, C1);
+	#undef RK_GROW
+	// queue levels: capacities 4 K, 16 K, ... as at creation; a level whose capacity is unchanged keeps its buffers
+	const int kin = d.world == 1 ? d.K : d.KI;
+	uint64_t c = std::max<uint64_t>(4ull * (uint64_t)kin, 4096ull);
+	int levels = 0;
+	for (; levels < QL && ok; levels++) {
+		const bool top = c >= C1 || levels == QL - 1;
+		const uint64_t cap_l = top ? C1 : c;
+		if (levels >= old.q.levels || old.q.cap[levels] != (uint32_t)cap_l) {
+			d.q.cap[levels] = (uint32_t)cap_l;
+			for (int k = 0; k < 2; k++) {
+				d.q.buf[levels][k] = (Rec *)get(((size_t)cap_l + 16) * sizeof(Rec));
+				ok = ok && d.q.buf[levels][k] != nullptr;
+				if (levels < old.q.levels) stale.push_back(old.q.buf[levels][k]);
+			}
+		}
+		if (top) { levels++; break; }
+		c *= 4;
+	}
+	d.q.levels = levels;
+	if (!ok) {
+		for (void *q : fresh) (void)hipFree(q);
+		(void)hipGetLastError();
+		return fail(RK_ECAPACITY, "rk_astar_grow: no device memory for a pool of %zu states", new_capacity);
+	}
+	RK_HIP(hipMemcpyAsync(d.states, old.states, C1_old * STATE_BYTES, hipMemcpyDeviceToDevice, st));
+	RK_HIP(hipMemcpyAsync(d.G, old.G, C1_old * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+	RK_HIP(hipMemcpyAsync(d.parents, old.parents, C1_old * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+	RK_HIP(hipMemcpyAsync(d.pact, old.pact, C1_old, hipMemcpyDeviceToDevice, st));
+	RK_HIP(hipMemcpyAsync(d.prank, old.prank, C1_old, hipMemcpyDeviceToDevice, st));
+	RK_HIP(hipMemsetAsync(d.table, 0, (size_t)t * sizeof(uint32_t), st));
+	RK_HIP(hipMemsetAsync(d.mark, 0xFF, C1 * sizeof(uint32_t), st));        // between iterations every mark is NO_MARK
+	for (int j = 0; j < old.q.levels; j++)                                  // a level that moved: both halves as they are
+		for (int k = 0; k < 2; k++)
+			if (d.q.buf[j][k] != old.q.buf[j][k])
+				RK_HIP(hipMemcpyAsync(d.q.buf[j][k], old.q.buf[j][k], (size_t)old.q.cap[j] * sizeof(Rec), hipMemcpyDeviceToDevice, st));
+	hipLaunchKernelGGL(k_astar_rehash, dim3(std::min<unsigned>(blocks(C1_old), 4096u)), dim3(256), 0, st, d);
+	RK_HIP(hipGetLastError());
+	RK_HIP(hipStreamSynchronize(st));
+	for (void *q : stale) {
+		for (size_t i = 0; i < h->allocs.size(); i++) if (h->allocs[i] == q) { h->allocs.erase(h->allocs.begin() + (long)i); break; }
+		(void)hipFree(q);
+	}
+	for (void *q : fresh) h->allocs.push_back(q);
+	h->d = d;
+	h->cap = new_capacity;
 	return RK_OK;
 }
 

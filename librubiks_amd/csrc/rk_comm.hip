@@ -10,7 +10,28 @@
 // torch.distributed already loaded an RCCL keeps its own for torch.  RK_RCCL_LIB overrides the library name.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>          // types and prototypes only (decltype below); no symbol of it is referenced at link time
+#else
+// A ROCm install without the RCCL development headers still builds the library: the handful of declarations this file
+// needs, as RCCL's public header states them (the library itself is looked up at run time either way).
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0 } ncclDataType_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId *uniqueId);
+ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId commId, int rank);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclAllGather(const void *sendbuff, void *recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclBroadcast(const void *sendbuff, void *recvbuff, size_t count, ncclDataType_t datatype, int root, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclSend(const void *sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclRecv(void *recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclGroupStart(void);
+ncclResult_t ncclGroupEnd(void);
+const char *ncclGetErrorString(ncclResult_t result);
+}
+#endif
 
 #include <cstdlib>
 #include <cstring>
@@ -125,12 +146,22 @@ int rk_comm_all_to_all(rk_comm_t *c, const void *d_send, void *d_recv, size_t by
 	if (d_send == d_recv) return fail(RK_EINVAL, "rk_comm_all_to_all: send and receive buffers must differ");
 	const char *s = static_cast<const char *>(d_send);
 	char *r = static_cast<char *>(d_recv);
+	// Between group_start and group_end nothing may return: RCCL's group depth is thread-local, and a raised depth makes every
+	// later collective of this thread wait for a group_end that never comes.  The first error is remembered, the group is
+	// always closed, then the error is reported.
 	RK_NCCL(g.group_start());
-	for (int p = 0; p < c->world; p++) {
-		RK_NCCL(g.send(s + (size_t)p * bytes_per_peer, bytes_per_peer, ncclChar, p, c->comm, (hipStream_t)stream));
-		RK_NCCL(g.recv(r + (size_t)p * bytes_per_peer, bytes_per_peer, ncclChar, p, c->comm, (hipStream_t)stream));
+	ncclResult_t first = ncclSuccess;
+	const char *what = "";
+	for (int p = 0; p < c->world && first == ncclSuccess; p++) {
+		first = g.send(s + (size_t)p * bytes_per_peer, bytes_per_peer, ncclChar, p, c->comm, (hipStream_t)stream);
+		what = "ncclSend";
+		if (first != ncclSuccess) break;
+		first = g.recv(r + (size_t)p * bytes_per_peer, bytes_per_peer, ncclChar, p, c->comm, (hipStream_t)stream);
+		what = "ncclRecv";
 	}
-	RK_NCCL(g.group_end());
+	const ncclResult_t end = g.group_end();
+	if (first != ncclSuccess) return fail(RK_EHIP, "rk_comm_all_to_all: %s -> %s", what, g.error_string(first));
+	if (end != ncclSuccess) return fail(RK_EHIP, "rk_comm_all_to_all: ncclGroupEnd -> %s", g.error_string(end));
 	return RK_OK;
 }
 

@@ -12,6 +12,7 @@
 // Cache, and every tile's stores are then held until the tile's slot on a fixed-rate schedule of the constant 100 MHz clock,
 // because HBM takes an ordered, rate-limited store stream 25 % faster than the same bytes from thousands of independent waves
 // and reads mixed into it cost 2.5 x their share.  Only WHEN a finished tile is stored depends on any of that (RK_PACE=0: never).
+#include <atomic>
 #include <cstdlib>
 
 #include "rk_device.h"
@@ -553,7 +554,7 @@ void k_expand12r(const uint32_t *__restrict__ parents, u32x4 *__restrict__ child
 // into that stream cost 10 us of 45, however the stores are ordered; read FIRST (into the Infinity Cache, which non-temporal
 // stores leave alone) they cost 4.
 //   * the first `pull_wgs` workgroups of a phase read its parents once, front to back, and leave; the last of them move the
-//     phase's time base g_pace_base up to "now" (atomic max by one wave in 256: the base ends where the read phase ended);
+//     phase's time base (the launch's cell of g_pace_cells) up to "now" (atomic max by one wave in 256: the base ends where the read phase ended);
 //   * every other wave owns one tile: it loads its parents (cache hits now), expands and stages them exactly as k_expand12r
 //     does, then HOLDS the sixteen stores until base + lead + tile x tau on the constant-rate clock (s_memrealtime, 10 ns).
 //     A wave behind its slot stores at once; nothing moves the schedule (a first version let late waves push the base: waits
@@ -561,14 +562,22 @@ void k_expand12r(const uint32_t *__restrict__ parents, u32x4 *__restrict__ child
 //     degenerates to the unpaced kernel plus the lead.
 // Results never depend on any of this -- only the moment at which a finished tile is stored does.
 // ================================================================================================================
-__device__ unsigned long long g_pace_base;         // time base of the launch in flight (per device: one copy per loaded code object)
+// Time bases of the paced launches.  Every paced launch gets ITS OWN cell (a kernel argument: the host hands out the cells of this
+// ring in turn, next_pace_cell), so two paced launches in flight on two streams -- fan-out beside as_oh, a search's fan-out
+// beside an exchange -- never move each other's schedule (round 3 had one global word for all kernels on all streams: results
+// never depended on it, but each phase's readers moved the base under the other launch's waves, up to the 20 us cap per
+// residency).  A cell is 128 bytes apart from the next, so the atomics of two launches do not share a line.  A hipGraph replays
+// a launch with the cell it was captured with: it then finds the base of its own previous replay, far in the past, which the
+// hold's stale test handles exactly as it handled round 3's global word.
+constexpr int PACE_CELLS = 64, PACE_CELL_STRIDE = 16;
+__device__ unsigned long long g_pace_cells[PACE_CELLS * PACE_CELL_STRIDE];
 
 #ifdef RK_TUNING
 __device__ unsigned long long *g_pace_dbg;         // tuning build: per tile {base read, time at the hold, due time, time after the hold}
 #endif
 
 struct PaceHold {
-	unsigned long long base, start; size_t tile; unsigned tau_ps, lead; int lane;
+	unsigned long long base, start; size_t tile; unsigned tau_ps, lead; int lane; const unsigned long long *cell;
 	__device__ __forceinline__ void operator()() const
 	{
 		if (tau_ps == 0) return;
@@ -585,7 +594,7 @@ struct PaceHold {
 		if (tile < PACE_FIRST_TILES)
 			for (int i = 0; i < 8 && b + slot + PACE_STALE_TICKS < start; i++) {
 				__builtin_amdgcn_s_sleep(16);
-				b = __hip_atomic_load(&g_pace_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				b = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
 		const unsigned long long due = b + slot;
 		const unsigned long long now = __builtin_amdgcn_s_memrealtime();
@@ -610,7 +619,8 @@ struct PaceHold {
 template <bool WITH_FLAGS>
 __global__ __launch_bounds__(EXP_WAVES * WAVE)
 void k_expand12p(const uint32_t *__restrict__ parents, u32x4 *__restrict__ children, uint32_t *__restrict__ solved,
-                 long long *__restrict__ stats, size_t n, unsigned pull_wgs, unsigned pull_extra, unsigned phase_tiles, unsigned tau_ps, unsigned lead)
+                 long long *__restrict__ stats, size_t n, unsigned pull_wgs, unsigned pull_extra, unsigned phase_tiles, unsigned tau_ps, unsigned lead,
+                 unsigned long long *pace)
 {
 	__shared__ u32x4 s_rows[48];
 	__shared__ ExpandWaveLdsT<1> s_wave[EXP_WAVES];
@@ -630,7 +640,7 @@ void k_expand12p(const uint32_t *__restrict__ parents, u32x4 *__restrict__ child
 		// the read phase ends when its last workgroups end; one wave in 256 publishes the time (atomics on one address complete
 		// one every ~25 ns chip-wide and hold the memory pipeline of the waves behind them)
 		if (lane == 0 && wv == 0 && ((r & 63) == 63 || r + 1 == pullers))
-			__hip_atomic_fetch_max(&g_pace_base, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_fetch_max(pace, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		return;
 	}
 	const unsigned long long start = __builtin_amdgcn_s_memrealtime();
@@ -638,9 +648,9 @@ void k_expand12p(const uint32_t *__restrict__ parents, u32x4 *__restrict__ child
 	const size_t t_in_phase = (size_t)(r - pullers) * EXP_WAVES + wv;
 	const size_t t = (size_t)phase * phase_tiles + t_in_phase;
 	if (pullers == 0 && t_in_phase == 0 && lane == 0)                   // no read phase: the time base is the start of the phase's first wave
-		__hip_atomic_fetch_max(&g_pace_base, start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__hip_atomic_fetch_max(pace, start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	// requested now, used after the tile is staged: the base of the schedule and the tile's parents
-	const unsigned long long base = __hip_atomic_load(&g_pace_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	const unsigned long long base = __hip_atomic_load(pace, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	uint32_t raw[5] = {0, 0, 0, 0, 0};
 	if (t < n_full) {
 		const uint32_t *src = parents + t * (EXP_ROUND * STATE_DWORDS) + lane;
@@ -654,7 +664,7 @@ void k_expand12p(const uint32_t *__restrict__ parents, u32x4 *__restrict__ child
 	__syncthreads();
 	const ExpandCtx c{s_rows, s_wave[wv].stage, s_wave[wv].flags, lane};
 	if (t < n_full)
-		expand_full_tile<WITH_FLAGS, 1>(c, raw, t * EXP_ROUND, children, solved, stats, PaceHold{base, start, t_in_phase, tau_ps, lead, lane});
+		expand_full_tile<WITH_FLAGS, 1>(c, raw, t * EXP_ROUND, children, solved, stats, PaceHold{base, start, t_in_phase, tau_ps, lead, lane, pace});
 	else if (t == n_full && (n % EXP_ROUND) != 0)
 		expand_ragged_tile<WITH_FLAGS, 1>(c, parents, n_full * EXP_ROUND, (int)(n % EXP_ROUND), children, solved, stats);
 }
@@ -748,27 +758,31 @@ __device__ __forceinline__ void note_bad_action(bool bad)
 // wave runs at 6.27 TB/s when every wave loads the moment it starts and at 6.85 TB/s when wave w loads at t0 + w x 0.70 ns; at
 // 0.66 ns it is back at 6.3).  A paced per-row launch has one tile per wave; the wave of tile 0 sets the time base (there is no read
 // phase here), and every wave waits for its slot BEFORE it requests its states.
-__device__ __forceinline__ void row_pace_hold(size_t tile, unsigned tau_ps, unsigned lead, int lane)
+__device__ __forceinline__ void row_pace_hold(size_t tile, unsigned tau_ps, unsigned lead, int lane, unsigned long long *pace)
 {
 	if (tau_ps == 0) return;
 	const unsigned long long start = __builtin_amdgcn_s_memrealtime();
-	if (tile == 0 && lane == 0) __hip_atomic_fetch_max(&g_pace_base, start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	const unsigned long long base = __hip_atomic_load(&g_pace_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	PaceHold{base, start, tile, tau_ps, lead, lane}();
+	if (tile == 0 && lane == 0) __hip_atomic_fetch_max(pace, start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	const unsigned long long base = __hip_atomic_load(pace, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	PaceHold{base, start, tile, tau_ps, lead, lane, pace}();
 }
 
-template <bool SPLIT_FD>
+// WITH_FLAGS: the goal test of the MOVED states in the same launch (the pair every per-row caller runs back to back:
+// agents.py:157-159, :696-703; train.py:277-281) -- flags (one byte per state, nullable) and the count / first index in
+// `stats` as k_multi_is_solved reports them; 21 B read + 21 B written per state instead of 41 + 21 in two launches.
+template <bool SPLIT_FD, bool WITH_FLAGS = false>
 __global__ __launch_bounds__(ROW_WAVES * WAVE)
 void k_multi_rotate(const uint32_t *__restrict__ states, const uint8_t *__restrict__ act_or_faces,
                     const uint8_t *__restrict__ dirs, uint32_t *__restrict__ out, size_t n, size_t n_tiles,
-                    unsigned tau_ps, unsigned lead, unsigned nt_stores)
+                    unsigned tau_ps, unsigned lead, unsigned nt_stores, unsigned long long *pace, uint8_t *__restrict__ flags = nullptr,
+                    long long *__restrict__ stats = nullptr)
 {
 	__shared__ u32x4 s_act[36];
 	__shared__ u32x4 s_buf[ROW_WAVES][320];       // 5 120 B per wave
 
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const size_t first_tile = (size_t)blockIdx.x * ROW_WAVES + wv;
-	row_pace_hold(first_tile, tau_ps, lead, lane);    // paced launches (one tile per wave): the wave's LOADS wait for its slot
+	row_pace_hold(first_tile, tau_ps, lead, lane, pace);    // paced launches (one tile per wave): the wave's LOADS wait for its slot
 	// the first tile's states are requested before the move tables are staged (a wave of the usual one-tile grid would
 	// otherwise wait for the table's round trip and only then start its own) ...
 	// ... and on a persistent grid every further tile's states are requested while the previous tile is moved and stored.
@@ -848,6 +862,26 @@ void k_multi_rotate(const uint32_t *__restrict__ states, const uint8_t *__restri
 			load_action_table(s_act, act[q], tab);
 			move5(&s[5 * q], tab);
 		}
+		if (WITH_FLAGS) {                                                  // cube.py:88-89 on the moved states
+			uint32_t fl = 0;
+			#pragma unroll
+			for (int q = 0; q < 4; q++)
+				if (4 * lane + q < np && is_solved5(&s[5 * q])) fl |= 1u << (8 * q);
+			if (flags != nullptr) {
+				uint8_t *fdst = flags + p0;
+				if (np == ROW_TILE && ((reinterpret_cast<uintptr_t>(fdst) & 3) == 0)) {
+					reinterpret_cast<uint32_t *>(fdst)[lane] = fl;
+				} else {
+					#pragma unroll
+					for (int q = 0; q < 4; q++)
+						if (4 * lane + q < np) fdst[4 * lane + q] = (uint8_t)((fl >> (8 * q)) & 1u);
+				}
+			}
+			if (stats != nullptr && __ballot(fl != 0u) != 0ull && fl != 0u) {
+				atomicAdd(reinterpret_cast<unsigned long long *>(&stats[0]), (unsigned long long)__popc(fl));
+				atomicMin(&stats[1], (long long)(p0 + 4 * lane + ((__ffs(fl) - 1) >> 3)));
+			}
+		}
 		#pragma unroll
 		for (int k = 0; k < 5; k++) buf[lane * 5 + k] = u32x4{s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]};
 		wave_lds_fence();
@@ -881,11 +915,11 @@ void k_multi_rotate(const uint32_t *__restrict__ states, const uint8_t *__restri
 // ================================================================================================================
 __global__ __launch_bounds__(ROW_WAVES * WAVE)
 void k_multi_is_solved(const uint32_t *__restrict__ states, uint8_t *__restrict__ flags, long long *__restrict__ stats,
-                       size_t n, size_t n_tiles, unsigned tau_ps, unsigned lead)
+                       size_t n, size_t n_tiles, unsigned tau_ps, unsigned lead, unsigned long long *pace)
 {
 	__shared__ u32x4 s_buf[ROW_WAVES][320];
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-	row_pace_hold((size_t)blockIdx.x * ROW_WAVES + wv, tau_ps, lead, lane);
+	row_pace_hold((size_t)blockIdx.x * ROW_WAVES + wv, tau_ps, lead, lane, pace);
 	u32x4 *buf = s_buf[wv];
 	uint32_t *buf_dw = reinterpret_cast<uint32_t *>(buf);
 	// on a persistent grid the next tile's states are requested while the current tile is tested (whole, aligned tiles)
@@ -1012,7 +1046,7 @@ template <> struct OhOne<bf16_tag> { static constexpr uint32_t bits = 0x3F80u; }
 template <typename T, int ELEM_BYTES, int TILE = 64, bool NT = false, int THREADS = 256>
 __global__ __launch_bounds__(THREADS)
 void k_as_oh(const uint32_t *__restrict__ states, u32x4 *__restrict__ out, size_t n, size_t n_tiles, unsigned tau_ps = 0, unsigned lead = 0,
-             unsigned pull_wgs = 0, unsigned phase_tiles = 0)
+             unsigned pull_wgs = 0, unsigned phase_tiles = 0, unsigned long long *pace = nullptr)
 {
 	constexpr int E = 16 / ELEM_BYTES;            // columns per 16-byte chunk: 4 or 8
 	constexpr int CHUNKS_PER_ROW = 480 / E;       // 120 or 60
@@ -1030,15 +1064,15 @@ void k_as_oh(const uint32_t *__restrict__ states, u32x4 *__restrict__ out, size_
 			const size_t p_count = n - p_first < (size_t)phase_tiles * TILE ? n - p_first : (size_t)phase_tiles * TILE;
 			pull_front(states + p_first * STATE_DWORDS, p_count, (size_t)r * (THREADS / 64) + (tid >> 6), (size_t)pull_wgs * (THREADS / 64), tid & 63);
 			if (tid == 0 && ((r & 63) == 63 || r + 1 == pull_wgs))
-				__hip_atomic_fetch_max(&g_pace_base, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_fetch_max(pace, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			return;
 		}
 		start = __builtin_amdgcn_s_memrealtime();
 		slot = r - pull_wgs;
 		tile_first = (size_t)phase * phase_tiles + slot;
 		tile_stride = n_tiles;                                             // one tile per workgroup
-		if (pull_wgs == 0 && slot == 0 && tid == 0) __hip_atomic_fetch_max(&g_pace_base, start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		base = __hip_atomic_load(&g_pace_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (pull_wgs == 0 && slot == 0 && tid == 0) __hip_atomic_fetch_max(pace, start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		base = __hip_atomic_load(pace, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 
 	for (size_t tile = tile_first; tile < n_tiles; tile += tile_stride) {
@@ -1047,7 +1081,7 @@ void k_as_oh(const uint32_t *__restrict__ states, u32x4 *__restrict__ out, size_
 		const int ndw = np * STATE_DWORDS;
 		for (int idx = tid; idx < TILE * STATE_DWORDS; idx += THREADS) s_st[idx] = idx < ndw ? states[p0 * STATE_DWORDS + idx] : 0u;
 		__syncthreads();
-		PaceHold{base, start, slot, tau_ps, lead, tid & 63}();
+		PaceHold{base, start, slot, tau_ps, lead, tid & 63, pace}();
 		const int nchunks = np * CHUNKS_PER_ROW;
 		u32x4 *dst = out + p0 * CHUNKS_PER_ROW;
 		for (int c = tid; c < nchunks; c += THREADS) {
@@ -1231,7 +1265,7 @@ void k_is_solved686(const u32x4 *__restrict__ states, uint8_t *__restrict__ flag
 template <bool FLAGS, int GROUP>
 __global__ __launch_bounds__(256)
 void k_fanout686p(const uint16_t *__restrict__ states, u32x4 *__restrict__ out, size_t n_in, uint8_t *__restrict__ flags, long long *__restrict__ stats,
-                  unsigned pull_wgs, unsigned phase_groups, unsigned tau_ps, unsigned lead)
+                  unsigned pull_wgs, unsigned phase_groups, unsigned tau_ps, unsigned lead, unsigned long long *pace)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t s_src[N_ACTIONS * 144];
 	__shared__ __attribute__((aligned(16))) uint16_t s_in[GROUP * 144];
@@ -1245,13 +1279,13 @@ void k_fanout686p(const uint16_t *__restrict__ states, u32x4 *__restrict__ out, 
 		const size_t p_count = n_in - p_first < (size_t)phase_groups * GROUP ? n_in - p_first : (size_t)phase_groups * GROUP;
 		pull_front_bytes(states + p_first * 144, p_count * S686_BYTES, (size_t)r * 4 + (tid >> 6), (size_t)pull_wgs * 4, tid & 63);
 		if (tid == 0 && ((r & 63) == 63 || r + 1 == pull_wgs))
-			__hip_atomic_fetch_max(&g_pace_base, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_fetch_max(pace, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		return;
 	}
 	const unsigned long long start = __builtin_amdgcn_s_memrealtime();
 	const size_t slot = r - pull_wgs, g = (size_t)phase * phase_groups + slot;
-	if (pull_wgs == 0 && slot == 0 && tid == 0) __hip_atomic_fetch_max(&g_pace_base, start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	const unsigned long long base = __hip_atomic_load(&g_pace_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if (pull_wgs == 0 && slot == 0 && tid == 0) __hip_atomic_fetch_max(pace, start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	const unsigned long long base = __hip_atomic_load(pace, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	const size_t first = g * GROUP;
 	const int ng = first >= n_in ? 0 : (int)((n_in - first < (size_t)GROUP) ? (n_in - first) : (size_t)GROUP);
 	// the group's states (ng x 18 16-byte words) and the tables travel together
@@ -1280,7 +1314,7 @@ void k_fanout686p(const uint16_t *__restrict__ states, u32x4 *__restrict__ out, 
 			}
 			s_col[i] = (uint8_t)col;
 		}
-	PaceHold{base, start, slot, tau_ps, lead, tid & 63}();
+	PaceHold{base, start, slot, tau_ps, lead, tid & 63, pace}();
 	u32x4 *dst = out + first * 12 * 18;
 	const int n_chunks = ng * 12 * 18;
 	for (int q = tid; q < n_chunks; q += 256) {
@@ -1385,6 +1419,14 @@ static const PaceConfig &pace_config()
 	return cfg;
 }
 
+// the cell of the next paced launch (see g_pace_cells): the ring's cells in turn, whatever the stream
+static unsigned long long *next_pace_cell()
+{
+	static unsigned long long *base = [] { void *p = nullptr; return hipGetSymbolAddress(&p, HIP_SYMBOL(g_pace_cells)) == hipSuccess ? (unsigned long long *)p : nullptr; }();
+	static std::atomic<unsigned> turn{0};
+	return base + (size_t)(turn.fetch_add(1, std::memory_order_relaxed) % PACE_CELLS) * PACE_CELL_STRIDE;
+}
+
 static void launch_expand12_paced(const int8_t *parents, int8_t *children, uint8_t *solved, long long *stats, size_t n, const PaceConfig &pc,
                                   unsigned tau_ps, hipStream_t st)
 {
@@ -1395,10 +1437,10 @@ static void launch_expand12_paced(const int8_t *parents, int8_t *children, uint8
 	const size_t grid = extra + (n_phases - 1) * (pc.pull_wgs + pc.phase_tiles / EXP_WAVES) + pc.pull_wgs + (last_tiles + EXP_WAVES - 1) / EXP_WAVES;
 	if (solved != nullptr)
 		hipLaunchKernelGGL((k_expand12p<true>), dim3((unsigned)grid), dim3(EXP_WAVES * WAVE), 0, st, (const uint32_t *)parents, (u32x4 *)children,
-			(uint32_t *)solved, stats, n, pc.pull_wgs, extra, pc.phase_tiles, tau_ps, pc.lead);
+			(uint32_t *)solved, stats, n, pc.pull_wgs, extra, pc.phase_tiles, tau_ps, pc.lead, next_pace_cell());
 	else
 		hipLaunchKernelGGL((k_expand12p<false>), dim3((unsigned)grid), dim3(EXP_WAVES * WAVE), 0, st, (const uint32_t *)parents, (u32x4 *)children,
-			(uint32_t *)nullptr, (long long *)nullptr, n, pc.pull_wgs, extra, pc.phase_tiles, tau_ps * 15360u / 16128u, pc.lead);
+			(uint32_t *)nullptr, (long long *)nullptr, n, pc.pull_wgs, extra, pc.phase_tiles, tau_ps * 15360u / 16128u, pc.lead, next_pace_cell());
 }
 
 #ifdef RK_TUNING   // tuning aids: compiled only into benchmarks/librubiks_hip_tune.so (python -m librubiks_amd.build --tune)
@@ -2086,7 +2128,8 @@ static unsigned row_grid_cap()
 // RK_PACE_SOLVED_TAU_PS for multi_is_solved override the constants (0 = unpaced).
 static unsigned env_u(const char *name, unsigned dflt) { const char *e = std::getenv(name); return e ? (unsigned)std::atol(e) : dflt; }
 
-void launch_multi_rotate(const int8_t *states, const uint8_t *actions, const uint8_t *dirs, int8_t *out, size_t n, hipStream_t st)
+void launch_multi_rotate(const int8_t *states, const uint8_t *actions, const uint8_t *dirs, int8_t *out, size_t n, hipStream_t st,
+                         uint8_t *flags, long long *stats, bool with_flags)
 {
 	static const unsigned tau_cfg = env_u("RK_PACE_ROT_TAU_PS", PACE_ROT_TAU_PS), nt_cfg = env_u("RK_PACE_ROT_NT", 1);
 	const size_t n_tiles = (n + ROW_TILE - 1) / ROW_TILE;
@@ -2094,21 +2137,33 @@ void launch_multi_rotate(const int8_t *states, const uint8_t *actions, const uin
 	const PaceConfig &pc = pace_config();
 	const bool paced = pc.on && tau_cfg > 0 && n_tiles >= 8192 && (size_t)grid * ROW_WAVES >= n_tiles;
 	const unsigned tau = paced ? tau_cfg : 0u, nt = paced ? nt_cfg : 0u;
-	if (dirs != nullptr)
-		hipLaunchKernelGGL(k_multi_rotate<true>, dim3(grid), dim3(ROW_WAVES * WAVE), 0, st, (const uint32_t *)states, actions, dirs,
-		                   (uint32_t *)out, n, n_tiles, tau, pc.lead, nt);
+	unsigned long long *const cell = paced ? next_pace_cell() : nullptr;
+	if (with_flags)
+		hipLaunchKernelGGL((k_multi_rotate<false, true>), dim3(grid), dim3(ROW_WAVES * WAVE), 0, st, (const uint32_t *)states, actions,
+		                   (const uint8_t *)nullptr, (uint32_t *)out, n, n_tiles, tau, pc.lead, nt, cell, flags, stats);
+	else if (dirs != nullptr)
+		hipLaunchKernelGGL((k_multi_rotate<true, false>), dim3(grid), dim3(ROW_WAVES * WAVE), 0, st, (const uint32_t *)states, actions, dirs,
+		                   (uint32_t *)out, n, n_tiles, tau, pc.lead, nt, cell, (uint8_t *)nullptr, (long long *)nullptr);
 	else
-		hipLaunchKernelGGL(k_multi_rotate<false>, dim3(grid), dim3(ROW_WAVES * WAVE), 0, st, (const uint32_t *)states, actions,
-		                   (const uint8_t *)nullptr, (uint32_t *)out, n, n_tiles, tau, pc.lead, nt);
+		hipLaunchKernelGGL((k_multi_rotate<false, false>), dim3(grid), dim3(ROW_WAVES * WAVE), 0, st, (const uint32_t *)states, actions,
+		                   (const uint8_t *)nullptr, (uint32_t *)out, n, n_tiles, tau, pc.lead, nt, cell, (uint8_t *)nullptr, (long long *)nullptr);
 }
 
-// reads and clears the mark bad action codes leave (synchronises `st`); negative on a HIP error
+// reads and clears the mark bad action codes leave (synchronises `st`); negative on a HIP error.  Read and clear are ONE
+// atomic exchange on the device: a kernel on another stream that sets the mark meanwhile is either seen now or stays for the next
+// call, never lost between a read and a separate clear.  The mark is per device, not per stream.
+__global__ void k_take_bad_actions(unsigned *out) { if (threadIdx.x == 0 && blockIdx.x == 0) *out = atomicExch(&g_bad_actions, 0u); }
+
 int read_bad_actions(hipStream_t st)
 {
-	unsigned h = 0, zero = 0;
-	if (hipMemcpyFromSymbolAsync(&h, HIP_SYMBOL(g_bad_actions), sizeof h, 0, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
-	if (hipMemcpyToSymbolAsync(HIP_SYMBOL(g_bad_actions), &zero, sizeof zero, 0, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
-	if (hipStreamSynchronize(st) != hipSuccess) return -1;
+	unsigned *cell = nullptr;
+	if (hipHostMalloc((void **)&cell, sizeof *cell, hipHostMallocDefault) != hipSuccess) return -1;
+	*cell = 0;
+	hipLaunchKernelGGL(k_take_bad_actions, dim3(1), dim3(64), 0, st, cell);
+	const bool ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+	const unsigned h = *cell;
+	(void)hipHostFree(cell);
+	if (!ok) return -1;
 	return h != 0 ? 1 : 0;
 }
 
@@ -2120,7 +2175,7 @@ void launch_multi_is_solved(const int8_t *states, uint8_t *flags, long long *sta
 	const PaceConfig &pc = pace_config();
 	const bool paced = pc.on && tau_cfg > 0 && n_tiles >= 8192 && (size_t)grid * ROW_WAVES >= n_tiles;
 	hipLaunchKernelGGL(k_multi_is_solved, dim3(grid), dim3(ROW_WAVES * WAVE), 0, st, (const uint32_t *)states, flags, stats, n, n_tiles,
-	                   paced ? tau_cfg : 0u, pc.lead);
+	                   paced ? tau_cfg : 0u, pc.lead, paced ? next_pace_cell() : (unsigned long long *)nullptr);
 }
 
 void launch_apply_sequences(const uint8_t *actions, int moves, int games, int with_solved, int only_last, int8_t *out, hipStream_t st)
@@ -2146,7 +2201,7 @@ void launch_as_oh_variant(int tile, int grid_cap, const int8_t *states, void *ou
 	const char *e5 = std::getenv("RK_OH_PULL"), *e6 = std::getenv("RK_OH_PHASE_STATES");
 	const unsigned pull = tau > 0 && e5 ? (unsigned)std::atoi(e5) : 0u;
 	const size_t phase_states = e6 ? (size_t)std::atol(e6) : ((size_t)1 << 20);
-	#define RK_OH2(T, EB, TL, NTS, TH) hipLaunchKernelGGL((k_as_oh<T, EB, TL, NTS, TH>), dim3(grid), dim3(TH), 0, st, (const uint32_t *)states, (u32x4 *)out, n, nt, tau, lead, pull, phase_tiles)
+	#define RK_OH2(T, EB, TL, NTS, TH) hipLaunchKernelGGL((k_as_oh<T, EB, TL, NTS, TH>), dim3(grid), dim3(TH), 0, st, (const uint32_t *)states, (u32x4 *)out, n, nt, tau, lead, pull, phase_tiles, next_pace_cell())
 	#define RK_OH(TL) do { const size_t nt = (n + (TL) - 1) / (TL); const unsigned phase_tiles = (unsigned)(phase_states / (TL)); \
 		const unsigned grid = tau > 0 ? oh_paced_grid(nt, pull, phase_tiles) : grid_for(nt, 1, grid_cap > 0 ? (unsigned)grid_cap : (1u << 22)); \
 		if (out_dtype == 0) { if (one_wave) { if (nts) RK_OH2(float, 4, TL, true, 64); else RK_OH2(float, 4, TL, false, 64); } \
@@ -2175,8 +2230,8 @@ void launch_as_oh(const int8_t *states, void *out, int out_dtype, size_t n, hipS
 	const unsigned phase_tiles = (unsigned)(((size_t)pc.phase_tiles * EXP_ROUND) / (out_dtype == 0 ? 8 : 16));    // the fan-out's phase in states: 1 Mi
 	const unsigned grid = paced ? oh_paced_grid(n_tiles, pc.pull_wgs, phase_tiles) : grid_for(n_tiles, 1, 1u << 22);
 	#define RK_OH(T, EB, TL) do { \
-		if (paced) hipLaunchKernelGGL((k_as_oh<T, EB, TL, true>), dim3(grid), dim3(256), 0, st, (const uint32_t *)states, (u32x4 *)out, n, n_tiles, tau, pc.lead, pc.pull_wgs, phase_tiles); \
-		else hipLaunchKernelGGL((k_as_oh<T, EB, TL, false>), dim3(grid), dim3(256), 0, st, (const uint32_t *)states, (u32x4 *)out, n, n_tiles, 0u, 0u, 0u, 0u); } while (0)
+		if (paced) hipLaunchKernelGGL((k_as_oh<T, EB, TL, true>), dim3(grid), dim3(256), 0, st, (const uint32_t *)states, (u32x4 *)out, n, n_tiles, tau, pc.lead, pc.pull_wgs, phase_tiles, next_pace_cell()); \
+		else hipLaunchKernelGGL((k_as_oh<T, EB, TL, false>), dim3(grid), dim3(256), 0, st, (const uint32_t *)states, (u32x4 *)out, n, n_tiles, 0u, 0u, 0u, 0u, (unsigned long long *)nullptr); } while (0)
 	if (out_dtype == 0) RK_OH(float, 4, 8);
 	else if (out_dtype == 1) RK_OH(_Float16, 2, 16);
 	else RK_OH(bf16_tag, 2, 16);
@@ -2202,10 +2257,10 @@ void launch_rotate686(const int8_t *states, const uint8_t *actions, int8_t *out,
 				const unsigned grid = (unsigned)((n_phases - 1) * (size_t)(pc.pull_wgs + phase_groups) + pc.pull_wgs + (n_groups - (n_phases - 1) * phase_groups));
 				if (flags != nullptr || stats != nullptr)
 					hipLaunchKernelGGL((k_fanout686p<true, G>), dim3(grid), dim3(256), 0, st, (const uint16_t *)states, (u32x4 *)out, n_in, flags, stats,
-					                   pc.pull_wgs, phase_groups, tau, pc.lead);
+					                   pc.pull_wgs, phase_groups, tau, pc.lead, next_pace_cell());
 				else
 					hipLaunchKernelGGL((k_fanout686p<false, G>), dim3(grid), dim3(256), 0, st, (const uint16_t *)states, (u32x4 *)out, n_in, (uint8_t *)nullptr,
-					                   (long long *)nullptr, pc.pull_wgs, phase_groups, tau, pc.lead);
+					                   (long long *)nullptr, pc.pull_wgs, phase_groups, tau, pc.lead, next_pace_cell());
 				return;
 			}
 		}

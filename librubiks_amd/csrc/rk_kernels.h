@@ -20,8 +20,9 @@ void tune_pace_debug(void *device_buffer_32_bytes_per_tile_or_null);
 #endif
 void launch_expand12_soa(const uint32_t *parents, uint32_t *children, uint8_t *solved, long long *stats, size_t n, hipStream_t st);
 void launch_states_soa(const int8_t *states, uint32_t *planes, size_t n, bool to_soa, hipStream_t st);
+// with_flags: the goal test of the moved states in the same launch (flags nullable, stats nullable); action indices only
 void launch_multi_rotate(const int8_t *states, const uint8_t *actions_or_faces, const uint8_t *dirs_or_null, int8_t *out,
-                         size_t n, hipStream_t st);
+                         size_t n, hipStream_t st, uint8_t *flags = nullptr, long long *stats = nullptr, bool with_flags = false);
 void launch_multi_is_solved(const int8_t *states, uint8_t *flags, long long *stats, size_t n, hipStream_t st);
 int read_bad_actions(hipStream_t st);
 void launch_apply_sequences(const uint8_t *actions, int moves, int games, int with_solved, int only_last, int8_t *out,

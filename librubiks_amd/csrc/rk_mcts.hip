@@ -18,6 +18,7 @@
 // Statistics are float64 and this file is compiled without fused multiply-add so that U = c*P*sqrt(sum N)/(1+N),
 // Q = W - L and the arg-max reproduce NumPy's results bit for bit.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <climits>
 #include <cmath>
 #include <cstdlib>
@@ -47,7 +48,15 @@ struct MctsDev {
 	uint32_t *children; int32_t *child_idx; uint8_t *child_new;
 };
 
-enum { TR_PLEN = 0, TR_NSTATES, TR_MAXSTATES, TR_SIMS, TR_SOLVE_ACTION, TR_SOLVE_LEAF, TR_ERROR, TR_FLAGS /* done | solved << 8 */, TR_INTS = 8 };
+// TR_READY: the 12 children of the pending simulation are in place (set by whoever expanded the path's leaf -- k_mcts_expand or
+// the previous backup + select launch expanding ahead --, cleared by the backup that consumes them).  The decision "has this
+// leaf been expanded already" therefore lives on the DEVICE: a k_mcts_expand that finds it set leaves at once, a backup that
+// finds it clear reports error 3 instead of backing up garbage -- so a captured step replays correctly from any state.
+enum { TR_PLEN = 0, TR_NSTATES, TR_MAXSTATES, TR_SIMS, TR_SOLVE_ACTION, TR_SOLVE_LEAF, TR_READY, TR_FLAGS /* done | solved << 8 | error << 16 */, TR_INTS = 8 };
+enum { MCTS_ERR_PATH = 1, MCTS_ERR_LINK = 2, MCTS_ERR_NOT_EXPANDED = 3 };
+__host__ __device__ inline int flags_done(int f) { return f & 0xFF; }
+__host__ __device__ inline int flags_solved(int f) { return (f >> 8) & 0xFF; }
+__host__ __device__ inline int flags_error(int f) { return (f >> 16) & 0xFF; }
 
 struct TreeRec { int32_t v[TR_INTS]; };
 
@@ -172,7 +181,7 @@ void k_mcts_root(MctsDev d, const uint32_t *starts, const int32_t *max_states)
 		d.path_nodes[(size_t)t * d.max_path] = 1;
 		tr[TR_PLEN] = 1;
 		tr[TR_SIMS] = 0;
-		tr[TR_ERROR] = 0;
+		tr[TR_READY] = 0;
 		tr[TR_SOLVE_ACTION] = -1;
 		tr[TR_SOLVE_LEAF] = -1;
 		const bool solved = is_solved5(s);            // agents.py:468: a solved start returns immediately
@@ -207,7 +216,7 @@ __device__ __forceinline__ void expand_leaf_body(const MctsDev &d, const u32x4 *
 	int32_t *trw = d.tree + (size_t)t * TR_INTS;
 	if (n + 12 > max_states) {                        // loop guard of agents.py:476
 		if (active) d.child_new[cbase] = 0;
-		if (lane == 0) trw[TR_FLAGS] = flags | 1;
+		if (lane == 0) { trw[TR_FLAGS] = flags | 1; trw[TR_READY] = 1; }
 		return;
 	}
 	const size_t node0 = (size_t)t * d.cap1;
@@ -255,11 +264,13 @@ __device__ __forceinline__ void expand_leaf_body(const MctsDev &d, const u32x4 *
 	if (lane == 0) {
 		node_of(d, node0, leaf).expanded() = 1u;                           // leaves[leaf] = False, agents.py:536
 		trw[TR_NSTATES] = n + __popcll(newmask);
+		trw[TR_READY] = 1;
 	}
 }
 
 // the first expansion of a search (the root's); later ones ride at the end of the previous simulation's backup + select
-// kernel when the engine expands ahead (rk_mcts_set_expand_ahead)
+// kernel when the engine expands ahead (rk_mcts_set_expand_ahead) -- this kernel then finds TR_READY set and leaves, so it
+// is correct to launch it in front of every simulation (what a step captured in a hipGraph does)
 __global__ __launch_bounds__(64)
 void k_mcts_expand(MctsDev d)
 {
@@ -272,13 +283,14 @@ void k_mcts_expand(MctsDev d)
 		if (lane < 12) d.child_new[(size_t)t * 12 + lane] = 0;
 		return;
 	}
+	if (tr.v[TR_READY]) return;                        // expanded ahead by the previous backup + select launch
 	const int leaf = d.path_nodes[(size_t)t * d.max_path + tr.v[TR_PLEN] - 1];
 	expand_leaf_body(d, s_act, t, lane, tr.v[TR_NSTATES], tr.v[TR_MAXSTATES], tr.v[TR_FLAGS], leaf);
 }
 
 // The net's outputs as the kernel takes them.  IN = 0: float32 probabilities (the caller ran softmax, agents.py:551) and
 // float32 values; IN = 1 / 2: the net's raw LOGITS and values in float32 / bfloat16 -- the softmax over a child's 12
-// logits (exp(x - max) / sum in float32, as torch computes it) happens here, which takes two conversion kernels, the
+// logits (exp(x - max) / sum in float32, summed in torch.softmax's own order, see child_policy) happens here, which takes two conversion kernels, the
 // softmax kernel and a copy out of every simulation.
 template <int IN>
 __device__ __forceinline__ float net_scalar(const void *p, size_t i)
@@ -296,9 +308,14 @@ __device__ __forceinline__ void child_policy(const void *probs, size_t row, int 
 	float m = out[0];
 	#pragma unroll
 	for (int k = 1; k < 12; k++) m = out[k] > m ? out[k] : m;
-	float sum = 0.0f;
 	#pragma unroll
-	for (int k = 0; k < 12; k++) { out[k] = expf(out[k] - m); sum += out[k]; }
+	for (int k = 0; k < 12; k++) out[k] = expf(out[k] - m);
+	// The sum in the order torch.softmax adds on this device: its kernel for rows of <= 1024 elements (softmax_warp_forward)
+	// pads the 12 logits to 16 lanes with -inf (exp -> +0) and reduces with an XOR butterfly over offsets 8, 4, 2, 1; float
+	// addition commutes exactly, so every lane of that butterfly ends with this tree's value.
+	const float a0 = (out[0] + out[8]) + out[4], a1 = (out[1] + out[9]) + out[5];
+	const float a2 = (out[2] + out[10]) + out[6], a3 = (out[3] + out[11]) + out[7];
+	const float sum = (a0 + a2) + (a1 + a3);
 	#pragma unroll
 	for (int k = 0; k < 12; k++) out[k] = out[k] / sum;
 }
@@ -325,7 +342,7 @@ void k_mcts_backup_select(MctsDev d, const void *probs, const void *values, int 
 	// round trip between each of these: six of them before any work)
 	const TreeRec tr = load_tree(d.tree, t);
 	int32_t *trw = d.tree + (size_t)t * TR_INTS;
-	const int is_done = tr.v[TR_FLAGS] & 0xFF, tree_solved = tr.v[TR_FLAGS] >> 8;
+	const int is_done = flags_done(tr.v[TR_FLAGS]), tree_solved = flags_solved(tr.v[TR_FLAGS]);
 	const int plen = tr.v[TR_PLEN], sims_before = tr.v[TR_SIMS];
 	const int idx = active ? d.child_idx[cbase] : 0;
 	const bool is_new = active && d.child_new[cbase] != 0;
@@ -334,6 +351,11 @@ void k_mcts_backup_select(MctsDev d, const void *probs, const void *values, int 
 		if (ahead_limit != 0 && active) d.child_new[cbase] = 0;            // (k_mcts_expand does this when it runs)
 		return;
 	}
+	if (!tr.v[TR_READY]) {                                                 // nobody expanded this path's leaf: refuse, loudly
+		if (lane == 0) trw[TR_FLAGS] = tr.v[TR_FLAGS] | 1 | (MCTS_ERR_NOT_EXPANDED << 16);
+		return;
+	}
+	if (lane == 0) trw[TR_READY] = 0;                                      // consumed here; set again below if this launch expands ahead
 	const int leaf = pnodes[plen - 1];
 	const double v = (double)vf;
 	if (is_new) {
@@ -429,7 +451,7 @@ void k_mcts_backup_select(MctsDev d, const void *probs, const void *values, int 
 		len++;
 		cur = next;
 		if (len >= (int)d.max_path || next <= 0) {
-			if (lane == 0) { trw[TR_ERROR] = next <= 0 ? 2 : 1; trw[TR_FLAGS] = tr.v[TR_FLAGS] | 1; }
+			if (lane == 0) trw[TR_FLAGS] = tr.v[TR_FLAGS] | 1 | ((next <= 0 ? MCTS_ERR_LINK : MCTS_ERR_PATH) << 16);
 			break;
 		}
 	}
@@ -441,6 +463,174 @@ void k_mcts_backup_select(MctsDev d, const void *probs, const void *values, int 
 		expand_leaf_body(d, s_act, t, lane, tr.v[TR_NSTATES], tr.v[TR_MAXSTATES], tr.v[TR_FLAGS], cur);
 	} else if (ahead_limit != 0 && active) {
 		d.child_new[cbase] = 0;                                            // nothing pending for this tree
+	}
+}
+
+
+// ---- growing the pools in place (agents.py:450-460 increase_stack_size; called from agents.py:503-504) -----------------------
+// After the arrays have been copied into pools of the new size: every stored state back into the (larger, cleared) hash table.
+__global__ __launch_bounds__(256)
+void k_mcts_rehash(MctsDev d)
+{
+	const int t = blockIdx.y;
+	const int n = d.tree[(size_t)t * TR_INTS + TR_NSTATES];
+	const size_t node0 = (size_t)t * d.cap1;
+	uint32_t *table = d.table + (size_t)t * (d.tmask + 1);
+	for (int idx = 1 + blockIdx.x * blockDim.x + threadIdx.x; idx <= n; idx += gridDim.x * blockDim.x) {
+		uint32_t s[5];
+		#pragma unroll
+		for (int j = 0; j < 5; j++) s[j] = d.states[(node0 + idx) * 5 + j];
+		uint32_t slot = mcts_hash(s) & d.tmask;
+		while (atomicCAS(&table[slot], 0u, (uint32_t)idx) != 0u) slot = (slot + 1) & d.tmask;
+	}
+}
+
+// New state budgets after a growth; a tree that had stopped at the loop guard only (agents.py:476: not solved, no error) and
+// has room again goes on: its descent is complete, its leaf not expanded, so the next expansion (k_mcts_expand) picks it up.
+__global__ void k_mcts_set_budgets(MctsDev d, const int32_t *max_states)
+{
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= d.T) return;
+	int32_t *tr = d.tree + (size_t)t * TR_INTS;
+	tr[TR_MAXSTATES] = max_states[t];
+	const int f = tr[TR_FLAGS];
+	if (flags_done(f) && !flags_solved(f) && !flags_error(f) && tr[TR_NSTATES] + 12 <= max_states[t]) {
+		tr[TR_FLAGS] = f & ~0xFF;
+		tr[TR_READY] = 0;
+	}
+}
+
+// ---- the explored graph of a solved tree (agents.py:597-633) ---------------------------------------------------------------
+// _complete_graph (agents.py:597-611): every leaf is linked to those of its 12 children that are already in the graph, both
+// ways.  One thread per (node, action) of 16 lanes per node; trees that have not solved are left alone (the reference
+// completes the graph only on a win, agents.py:483-486).  A child's reverse link neighbors[child, rev(a)] can only ever
+// name this leaf (moves are invertible), so the writes of different threads never disagree.
+__global__ __launch_bounds__(256)
+void k_mcts_complete(MctsDev d)
+{
+	__shared__ u32x4 s_act[36];
+	stage_action_tables(s_act, threadIdx.x);
+	__syncthreads();
+	const int t = blockIdx.y;
+	const int32_t *tr = d.tree + (size_t)t * TR_INTS;
+	if (flags_solved(tr[TR_FLAGS]) != 1) return;
+	const int n = tr[TR_NSTATES];
+	const size_t node0 = (size_t)t * d.cap1;
+	const uint32_t *table = d.table + (size_t)t * (d.tmask + 1);
+	const int a = threadIdx.x & 15;
+	for (int idx = 1 + (blockIdx.x * blockDim.x + threadIdx.x) / 16; idx <= n; idx += gridDim.x * blockDim.x / 16) {
+		const Node leaf = node_of(d, node0, idx);
+		if (a >= 12 || leaf.expanded()) continue;                          // np.where(self.leaves[:len(self)+1])[0][1:]
+		uint32_t s[5];
+		#pragma unroll
+		for (int j = 0; j < 5; j++) s[j] = d.states[(node0 + idx) * 5 + j];
+		uint32_t tab[12];
+		load_action_table(s_act, (uint32_t)a, tab);
+		move5(s, tab);
+		uint32_t slot = mcts_hash(s) & d.tmask;
+		int child = 0;
+		for (;;) {
+			const uint32_t e = table[slot];
+			if (e == 0u) break;
+			if (same5(s, d.states + (node0 + e) * 5)) { child = (int)e; break; }
+			slot = (slot + 1) & d.tmask;
+		}
+		leaf.nb()[a] = child;                                              // agents.py:607 (0 = not in the graph)
+		if (child) node_of(d, node0, child).nb()[a ^ 1] = idx;             // agents.py:608
+	}
+}
+
+// _shorten_action_queue (agents.py:613-633): breadth-first search from the root (index 1) through `neighbors` until the
+// solved state's index turns up; the path back through the BFS tree replaces the action queue.  The reference's queue is
+// sequential: a node's BFS parent is the FIRST (node, action) pair, in queue order, that reaches it, and nodes enter the
+// queue in that order.  One workgroup per tree reproduces it level by level: every edge (position p of the frontier, action a)
+// has the number e = 12 p + a; pass A lets every edge claim its unvisited target with atomicMin(e); pass B walks the edges in
+// order again and appends the winners -- in edge order, by an exclusive scan -- to the next frontier.  The first edge that
+// reaches the solved index is therefore exactly the one the reference's loop returns on.
+// Reads of words that other waves of the workgroup wrote go around the L1 (agent-scope atomic loads).
+struct BfsDev {
+	uint32_t *claim;          // [T][cap1]  smallest edge number that reached the node (0xFFFFFFFF: none yet)
+	int32_t *from;            // [T][cap1]  BFS parent (0: not visited; the root holds -1)
+	uint8_t *act;             // [T][cap1]  action from the BFS parent
+	int32_t *front[2];        // [T][cap1]  frontier, current and next
+	int32_t *len;             // [T]        length of the path found, -1: none (tree not solved, or the root itself is the goal)
+	uint8_t *actions;         // [T][max_path]
+};
+
+__device__ __forceinline__ int ld_i32(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t ld_u32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(1024)
+void k_mcts_bfs(MctsDev d, BfsDev b)
+{
+	__shared__ int s_wave[16];
+	__shared__ int s_count, s_found;
+	const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int32_t *tr = d.tree + (size_t)t * TR_INTS;
+	const int goal = tr[TR_SOLVE_LEAF];
+	if (flags_solved(tr[TR_FLAGS]) != 1 || goal <= 1) {                   // agents.py:614: the queue stays as it is
+		if (tid == 0) b.len[t] = -1;
+		return;
+	}
+	const size_t node0 = (size_t)t * d.cap1;
+	uint32_t *claim = b.claim + node0;
+	int32_t *from = b.from + node0;
+	uint8_t *act = b.act + node0;
+	int32_t *cur = b.front[0] + node0, *nxt = b.front[1] + node0;
+	if (tid == 0) { cur[0] = 1; from[1] = -1; s_found = 0; }
+	__syncthreads();
+	int fsize = 1, depth = 0;
+	while (fsize > 0) {
+		const long long total = 12ll * fsize;
+		for (long long e = tid; e < total; e += 1024) {                    // pass A: claims
+			const int v = ld_i32(cur + e / 12), a = (int)(e % 12);
+			const int w = node_of(d, node0, v).nb()[a];
+			if (w > 0 && ld_i32(from + w) == 0) atomicMin(claim + w, (uint32_t)e);
+		}
+		__syncthreads();
+		if (tid == 0) s_count = 0;
+		__syncthreads();
+		for (long long base = 0; base < total; base += 1024) {             // pass B: winners, in edge order
+			const long long e = base + tid;
+			int v = 0, a = 0, w = 0;
+			bool win = false;
+			if (e < total) {
+				v = ld_i32(cur + e / 12); a = (int)(e % 12);
+				w = node_of(d, node0, v).nb()[a];
+				win = w > 0 && ld_i32(from + w) == 0 && ld_u32(claim + w) == (uint32_t)e;
+			}
+			const unsigned long long m = __ballot(win);
+			if (lane == 0) s_wave[wv] = __popcll(m);
+			__syncthreads();
+			int before = 0, tot = 0;
+			#pragma unroll
+			for (int k = 0; k < 16; k++) { const int c = s_wave[k]; before += k < wv ? c : 0; tot += c; }
+			const int at = s_count + before + __popcll(m & ((1ull << lane) - 1ull));
+			if (win) {
+				nxt[at] = w;
+				__hip_atomic_store(from + w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				act[w] = (uint8_t)a;
+				if (w == goal) s_found = 1;
+			}
+			__syncthreads();
+			if (tid == 0) s_count += tot;
+			__syncthreads();
+		}
+		depth++;
+		fsize = s_count;
+		int32_t *sw = cur; cur = nxt; nxt = sw;
+		if (s_found) break;
+		__syncthreads();
+	}
+	if (tid == 0) {
+		if (!s_found || depth > (int)d.max_path) { b.len[t] = -1; return; }
+		uint8_t *out = b.actions + (size_t)t * d.max_path;
+		int v = goal;
+		for (int k = depth - 1; k >= 0; k--) {                             // agents.py:624-628
+			out[k] = __hip_atomic_load(act + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			v = ld_i32(from + v);
+		}
+		b.len[t] = depth;
 	}
 }
 
@@ -457,6 +647,9 @@ struct rk_mcts {
 	bool ready = false;
 	int ahead_limit = 0;          // rk_mcts_set_expand_ahead: 0 off, < 0 always, > 0 while the simulation number is below it
 	bool ahead = false;           // the last backup + select launch already expanded the leaves it found
+	BfsDev bfs{};                 // scratch of rk_mcts_search_graph, allocated at its first call (and again after a growth)
+	std::vector<void *> bfs_allocs;
+	bool bfs_valid = false;       // rk_mcts_search_graph has run since the last reset / growth
 };
 
 namespace {
@@ -472,6 +665,18 @@ int mcts_alloc(rk_mcts *h, T **p, size_t count)
 }
 
 inline unsigned nblocks(size_t n, unsigned per = 256) { return (unsigned)((n + per - 1) / per); }
+
+// `rows` blocks of `width` bytes, `spitch` / `dpitch` bytes apart, device to device: one plain copy per block (a tree's block can
+// be gigabytes wide, which is not what the 2-D copy engine path is made for), the 2-D call only for very many trees
+hipError_t strided_copy(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t rows, hipStream_t st)
+{
+	if (rows > 4096) return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyDeviceToDevice, st);
+	for (size_t r = 0; r < rows; r++) {
+		const hipError_t e = hipMemcpyAsync((char *)dst + r * dpitch, (const char *)src + r * spitch, width, hipMemcpyDeviceToDevice, st);
+		if (e != hipSuccess) return e;
+	}
+	return hipSuccess;
+}
 
 }  // namespace
 
@@ -512,6 +717,7 @@ int rk_mcts_destroy(rk_mcts_t *h)
 {
 	if (!h) return RK_OK;
 	for (void *p : h->allocs) (void)hipFree(p);
+	for (void *p : h->bfs_allocs) (void)hipFree(p);
 	delete h;
 	return RK_OK;
 }
@@ -544,6 +750,134 @@ int rk_mcts_reset(rk_mcts_t *h, const int8_t *h_start_states, const long long *h
 	h->ready = true;
 	h->ahead = false;
 	return RK_OK;
+}
+
+
+/* Grows every tree's pool to new_capacity states (>= the current one) and the path arrays to new_max_path entries, keeping
+ * everything the trees hold (agents.py:450-460): new arrays, device-to-device copies, the hash tables rebuilt by one kernel. */
+int rk_mcts_grow(rk_mcts_t *h, size_t new_capacity, size_t new_max_path, const long long *h_max_states, void *stream)
+{
+	if (!h || !h->ready) return fail(RK_ESTATE, "rk_mcts_grow: reset the engine first");
+	if (new_capacity < h->capacity || new_capacity > 0x3FFFFFF0ull) return fail(RK_EINVAL, "rk_mcts_grow: capacity %zu out of range (now %zu)", new_capacity, h->capacity);
+	if (new_max_path < h->d.max_path) new_max_path = h->d.max_path;
+	if (new_max_path > (1u << 30)) return fail(RK_EINVAL, "rk_mcts_grow: max_path %zu out of range", new_max_path);
+	hipStream_t st = (hipStream_t)stream;
+	const MctsDev old = h->d;
+	MctsDev d = old;
+	const size_t T = (size_t)d.T;
+	d.cap1 = (uint32_t)(new_capacity + 1);
+	uint64_t ts = 64;
+	while (ts < 2ull * d.cap1) ts <<= 1;
+	d.tmask = (uint32_t)(ts - 1);
+	d.max_path = (uint32_t)new_max_path;
+	const size_t rows = T * d.cap1;
+	std::vector<void *> fresh;
+	auto get = [&](size_t bytes) -> void * { void *q = nullptr; if (hipMalloc(&q, bytes + 16) != hipSuccess) return nullptr; fresh.push_back(q); return q; };
+	const bool pool = d.cap1 != old.cap1, paths = d.max_path != old.max_path;
+	if (pool) {
+		d.states = (uint32_t *)get(rows * 5 * sizeof(uint32_t));
+		d.nodes = (uint8_t *)get((rows + 1) * NODE_BYTES);
+		d.table = (uint32_t *)get(T * (size_t)ts * sizeof(uint32_t));
+	}
+	if (paths) {
+		d.path_nodes = (int32_t *)get(T * new_max_path * sizeof(int32_t));
+		d.path_actions = (uint8_t *)get(T * new_max_path);
+	}
+	if ((pool && (!d.states || !d.nodes || !d.table)) || (paths && (!d.path_nodes || !d.path_actions))) {
+		for (void *q : fresh) (void)hipFree(q);
+		(void)hipGetLastError();
+		return fail(RK_ECAPACITY, "rk_mcts_grow: no device memory for %d trees of %zu states", d.T, new_capacity);
+	}
+	if (pool) {
+		RK_HIP(hipMemsetAsync(d.nodes, 0, rows * NODE_BYTES, st));         // rows beyond the old pool: leaves, all statistics zero
+		RK_HIP(hipMemsetAsync(d.table, 0, T * (size_t)ts * sizeof(uint32_t), st));
+		RK_HIP(strided_copy(d.states, (size_t)d.cap1 * STATE_BYTES, old.states, (size_t)old.cap1 * STATE_BYTES, (size_t)old.cap1 * STATE_BYTES, T, st));
+		RK_HIP(strided_copy(d.nodes, (size_t)d.cap1 * NODE_BYTES, old.nodes, (size_t)old.cap1 * NODE_BYTES, (size_t)old.cap1 * NODE_BYTES, T, st));
+	}
+	if (paths) {
+		RK_HIP(strided_copy(d.path_nodes, new_max_path * 4, old.path_nodes, (size_t)old.max_path * 4, (size_t)old.max_path * 4, T, st));
+		RK_HIP(strided_copy(d.path_actions, new_max_path, old.path_actions, (size_t)old.max_path, (size_t)old.max_path, T, st));
+	}
+	if (pool) {
+		hipLaunchKernelGGL(k_mcts_rehash, dim3(std::min<unsigned>(nblocks(old.cap1), 4096u), d.T), dim3(256), 0, st, d);
+		RK_HIP(hipGetLastError());
+	}
+	std::vector<int32_t> ms(T);
+	for (size_t t = 0; t < T; t++) {
+		long long m = h_max_states ? h_max_states[t] : (long long)new_capacity;
+		if (m > (long long)new_capacity) m = (long long)new_capacity;
+		ms[t] = (int32_t)(m < 0 ? 0 : m);
+	}
+	RK_HIP(hipMemcpyAsync(h->max_states_dev, ms.data(), T * sizeof(int32_t), hipMemcpyHostToDevice, st));
+	hipLaunchKernelGGL(k_mcts_set_budgets, dim3(nblocks(T)), dim3(256), 0, st, d, h->max_states_dev);
+	RK_HIP(hipGetLastError());
+	RK_HIP(hipStreamSynchronize(st));                                      // `ms` and the old arrays go away now
+	auto drop = [&](void *q) {
+		for (size_t i = 0; i < h->allocs.size(); i++) if (h->allocs[i] == q) { h->allocs.erase(h->allocs.begin() + (long)i); break; }
+		(void)hipFree(q);
+	};
+	if (pool) { drop(old.states); drop(old.nodes); drop(old.table); }
+	if (paths) { drop(old.path_nodes); drop(old.path_actions); }
+	for (void *q : fresh) h->allocs.push_back(q);
+	h->d = d;
+	h->capacity = new_capacity;
+	h->ahead = false;                                                      // what is pending is decided on the device (TR_READY)
+	for (void *q : h->bfs_allocs) (void)hipFree(q);                        // sized by the pool: allocated again when next needed
+	h->bfs_allocs.clear();
+	h->bfs = BfsDev{};
+	h->bfs_valid = false;
+	return RK_OK;
+}
+
+/* agents.py:483-486 for every tree that has solved: _complete_graph (:597-611) and the breadth-first search of
+ * _shorten_action_queue (:613-633), both on the device; rk_mcts_graph_path then returns the shortened queue. */
+int rk_mcts_search_graph(rk_mcts_t *h, void *stream)
+{
+	if (!h || !h->ready) return fail(RK_ESTATE, "rk_mcts_search_graph: reset the engine first");
+	hipStream_t st = (hipStream_t)stream;
+	const MctsDev &d = h->d;
+	const size_t T = (size_t)d.T, rows = T * d.cap1;
+	if (h->bfs.claim == nullptr) {
+		BfsDev b{};
+		auto get = [&](size_t bytes) -> void * { void *q = nullptr; if (hipMalloc(&q, bytes + 16) != hipSuccess) return nullptr; h->bfs_allocs.push_back(q); return q; };
+		b.claim = (uint32_t *)get(rows * 4); b.from = (int32_t *)get(rows * 4); b.act = (uint8_t *)get(rows);
+		b.front[0] = (int32_t *)get(rows * 4); b.front[1] = (int32_t *)get(rows * 4);
+		b.len = (int32_t *)get(T * 4); b.actions = (uint8_t *)get(T * (size_t)d.max_path);
+		if (!b.claim || !b.from || !b.act || !b.front[0] || !b.front[1] || !b.len || !b.actions) {
+			for (void *q : h->bfs_allocs) (void)hipFree(q);
+			h->bfs_allocs.clear();
+			(void)hipGetLastError();
+			return fail(RK_ECAPACITY, "rk_mcts_search_graph: no device memory for the search scratch of %d trees", d.T);
+		}
+		h->bfs = b;
+	}
+	RK_HIP(hipMemsetAsync(h->bfs.claim, 0xFF, rows * 4, st));
+	RK_HIP(hipMemsetAsync(h->bfs.from, 0, rows * 4, st));
+	hipLaunchKernelGGL(k_mcts_complete, dim3(std::min<unsigned>(nblocks((size_t)d.cap1 * 16), 8192u), d.T), dim3(256), 0, st, d);
+	hipLaunchKernelGGL(k_mcts_bfs, dim3(d.T), dim3(1024), 0, st, d, h->bfs);
+	RK_HIP(hipGetLastError());
+	h->bfs_valid = true;
+	return RK_OK;
+}
+
+/* The action queue rk_mcts_search_graph found for `tree` (agents.py:624-628): returns its length, or -1 when the tree has none
+ * (not solved, or nothing to shorten: the queue of rk_mcts_path stands).  Synchronises. */
+long long rk_mcts_graph_path(rk_mcts_t *h, int tree, long long *h_actions, size_t max_len, void *stream)
+{
+	if (!h || !h->ready) return fail(RK_ESTATE, "rk_mcts_graph_path: reset the engine first");
+	if (!h->bfs_valid) return fail(RK_ESTATE, "rk_mcts_graph_path: call rk_mcts_search_graph first");
+	const MctsDev &d = h->d;
+	if (tree < 0 || tree >= d.T) return fail(RK_EINVAL, "rk_mcts_graph_path: tree %d out of range", tree);
+	hipStream_t st = (hipStream_t)stream;
+	int32_t len = -1;
+	RK_HIP(hipMemcpyAsync(&len, h->bfs.len + tree, sizeof len, hipMemcpyDeviceToHost, st));
+	RK_HIP(hipStreamSynchronize(st));
+	if (len <= 0) return len < 0 ? -1 : 0;
+	std::vector<uint8_t> acts((size_t)len);
+	RK_HIP(hipMemcpyAsync(acts.data(), h->bfs.actions + (size_t)tree * d.max_path, (size_t)len, hipMemcpyDeviceToHost, st));
+	RK_HIP(hipStreamSynchronize(st));
+	for (size_t i = 0; i < (size_t)len && i < max_len; i++) if (h_actions) h_actions[i] = acts[i];
+	return len;
 }
 
 int rk_mcts_set_expand_ahead(rk_mcts_t *h, long long sim_limit)
@@ -580,7 +914,14 @@ int rk_mcts_set_root_pv(rk_mcts_t *h, const float *d_probs, const float *d_value
 int rk_mcts_expand(rk_mcts_t *h, void *stream)
 {
 	if (!h || !h->ready) return fail(RK_ESTATE, "rk_mcts_expand: reset the engine first");
-	if (h->ahead) { h->ahead = false; return RK_OK; }    // the previous backup + select launch has done it already
+	// The previous backup + select launch may have expanded the leaves already (expand ahead).  Eagerly the host knows and skips
+	// the launch; a call that is being CAPTURED into a hipGraph always records the kernel, which takes the decision on the device
+	// (TR_READY) at every replay -- whatever state the graph was captured in and whatever state it is replayed from.
+	hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+	if (stream != nullptr && hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+	const bool skip = h->ahead && cap == hipStreamCaptureStatusNone;
+	h->ahead = false;
+	if (skip) return RK_OK;
 	hipLaunchKernelGGL(k_mcts_expand, dim3(h->d.T), dim3(64), 0, (hipStream_t)stream, h->d);
 	RK_HIP(hipGetLastError());
 	return RK_OK;
@@ -640,7 +981,8 @@ int rk_mcts_status(rk_mcts_t *h, long long *h_status, void *stream)
 	for (size_t t = 0; t < T; t++) {
 		const int32_t *tr = rec.data() + t * TR_INTS;
 		long long *r = h_status + 6 * t;
-		r[0] = tr[TR_FLAGS] & 0xFF; r[1] = tr[TR_FLAGS] >> 8; r[2] = tr[TR_NSTATES]; r[3] = tr[TR_SIMS]; r[4] = tr[TR_PLEN]; r[5] = tr[TR_ERROR];
+		r[0] = flags_done(tr[TR_FLAGS]); r[1] = flags_solved(tr[TR_FLAGS]); r[2] = tr[TR_NSTATES]; r[3] = tr[TR_SIMS]; r[4] = tr[TR_PLEN];
+		r[5] = flags_error(tr[TR_FLAGS]);
 	}
 	return RK_OK;
 }
@@ -691,7 +1033,7 @@ long long rk_mcts_path(rk_mcts_t *h, int tree, long long *h_actions, long long *
 	RK_HIP(hipMemcpyAsync(tr, d.tree + (size_t)tree * TR_INTS, sizeof tr, hipMemcpyDeviceToHost, st));
 	RK_HIP(hipStreamSynchronize(st));
 	const int32_t plen = tr[TR_PLEN];
-	const int solved = tr[TR_FLAGS] >> 8;
+	const int solved = flags_solved(tr[TR_FLAGS]);
 	if (plen < 1) return fail(RK_ESTATE, "rk_mcts_path: empty path");
 	std::vector<int32_t> nodes((size_t)plen);
 	std::vector<uint8_t> acts((size_t)plen);

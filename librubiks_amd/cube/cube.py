@@ -149,17 +149,30 @@ def _actions_from(faces, dirs, n: int) -> torch.Tensor:
 	return torch.from_numpy((2 * f + (1 - d)).astype(np.uint8)).to(gpu)
 
 
-_PINNED_FROM = 1 << 20      # device -> host results from 1 MiB on land in page-locked memory
+_PINNED_FROM = 1 << 20      # device -> host results from 1 MiB on are staged through page-locked memory
+#: Results up to this size are RETURNED as views of page-locked memory (torch's caching host allocator: a block goes back to its
+#: pool when the array dies, never to the OS); larger ones -- and everything once `pinned_result_budget` bytes of such results are
+#: alive -- are copied through one reusable page-locked staging buffer into an ordinary pageable array, so that a caller who
+#: keeps many results (a training loop keeping children arrays) does not pin its RAM.  Set either to 0 to switch the path off.
+pinned_result_max = 512 << 20
+pinned_result_budget = 2 << 30
+_pinned_alive = [0]
+_staging = [None]
+
+
+def _release_pinned(nbytes: int):
+	_pinned_alive[0] -= nbytes
 
 
 def _to_host(t: torch.Tensor) -> np.ndarray:
 	"""
-	Device tensor -> NumPy array.  Large results (the 240 MB of children of a 1 M-state fan-out) are copied into page-locked
-	memory from torch's caching host allocator: a fresh pageable array costs its first-touch page faults on top of a staged
-	copy -- 36-45 ms per 1 M parents against 8-9 ms this way (benchmarks/kernels.py, host_path).  The array keeps its tensor
-	alive; a refused page-locked allocation falls back to the pageable copy.
+	Device tensor -> NumPy array.  Large results (the 240 MB of children of a 1 M-state fan-out) land in page-locked memory:
+	a fresh pageable array costs its first-touch page faults on top of a staged copy -- 36-45 ms per 1 M parents against
+	8-9 ms this way (benchmarks/kernels.py, host_path).  The page-locked path is bounded (see `pinned_result_max`,
+	`pinned_result_budget`); a refused page-locked allocation falls back to the pageable copy.
 	"""
-	if t.numel() * t.element_size() >= _PINNED_FROM:
+	nbytes = t.numel() * t.element_size()
+	if nbytes >= _PINNED_FROM and nbytes <= pinned_result_max and _pinned_alive[0] + nbytes <= pinned_result_budget:
 		try:
 			host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
 		except RuntimeError:
@@ -167,8 +180,33 @@ def _to_host(t: torch.Tensor) -> np.ndarray:
 		if host is not None:
 			host.copy_(t, non_blocking=True)
 			torch.cuda.current_stream().synchronize()
-			return host.numpy()
+			out = host.numpy()
+			_pinned_alive[0] += nbytes
+			import weakref
+			weakref.finalize(host, _release_pinned, nbytes)              # the array keeps `host` alive; the budget follows its lifetime
+			return out
+	if nbytes >= _PINNED_FROM and pinned_result_max > 0:
+		# over the budget: one reusable page-locked staging buffer (64 MiB), copied piecewise into a pageable array
+		try:
+			if _staging[0] is None:
+				_staging[0] = torch.empty(64 << 20, dtype=torch.uint8, pin_memory=True)
+			stage = _staging[0]
+		except RuntimeError:
+			stage = None
+		if stage is not None:
+			flat = t.contiguous().view(torch.uint8).reshape(-1)
+			out = np.empty(nbytes, np.uint8)
+			for at in range(0, nbytes, len(stage)):
+				k = min(len(stage), nbytes - at)
+				stage[:k].copy_(flat[at:at + k], non_blocking=True)
+				torch.cuda.current_stream().synchronize()
+				out[at:at + k] = stage[:k].numpy()
+			return out.view(_NP_OF[t.dtype]).reshape(tuple(t.shape))
 	return t.cpu().numpy()
+
+
+_NP_OF = {torch.int8: np.int8, torch.uint8: np.uint8, torch.float32: np.float32, torch.float16: np.float16, torch.int64: np.int64,
+          torch.int32: np.int32, torch.float64: np.float64, torch.bool: np.bool_}
 
 
 def _new_stats() -> torch.Tensor:
@@ -224,6 +262,35 @@ class device:
 			_check_dev(out, torch.int8, "out")
 		_ffi.check(_ffi.lib().rk_multi_rotate(_repr_id(), states.data_ptr(), actions.data_ptr(), out.data_ptr(), n, _ffi.stream_ptr()))
 		return out
+
+	@staticmethod
+	def multi_rotate_solved(states: torch.Tensor, actions: torch.Tensor, out: torch.Tensor = None, flags: torch.Tensor = None,
+	                        stats: torch.Tensor = None):
+		"""
+		`multi_rotate` and `multi_is_solved` of the moved states in ONE launch (the pair of agents.py:157-159, :696-703 and
+		train.py:277-281): returns (moved states, uint8 flags).  `stats` (int64[2] = [count, first index], initialise to
+		[0, INT64_MAX]) is updated if given.  20-byte states: the moved states are not read back for the test.
+		"""
+		_ffi.require_gpu()
+		_check_dev(states, torch.int8, "states")
+		_check_dev(actions, torch.uint8, "actions")
+		device._validate(actions)
+		n = len(states)
+		if len(actions) != n:
+			raise ValueError(f"{n} states but {len(actions)} actions")
+		if out is None:
+			out = torch.empty_like(states)
+		else:
+			_check_dev(out, torch.int8, "out")
+		if flags is None:
+			flags = torch.empty(n, dtype=torch.uint8, device=states.device)
+		else:
+			_check_dev(flags, torch.uint8, "flags")
+		if stats is not None:
+			_check_dev(stats, torch.int64, "stats")
+		_ffi.check(_ffi.lib().rk_multi_rotate_solved(_repr_id(), states.data_ptr(), actions.data_ptr(), out.data_ptr(), flags.data_ptr(),
+		                                             stats.data_ptr() if stats is not None else None, n, _ffi.stream_ptr()))
+		return out, flags
 
 	@staticmethod
 	def expand12(parents: torch.Tensor, children: torch.Tensor = None, solved: torch.Tensor = None,

@@ -228,6 +228,9 @@ class EGVM(DeepAgent):
 		cur = torch.from_numpy(cube.repeat_state(np.asarray(state), self.workers)).to(gpu)
 		paths = np.empty((self.workers, self.depth), dtype=int)
 		visited = torch.empty((self.workers, self.depth, 20), dtype=torch.int8, device=gpu)
+		flags = torch.empty(self.workers, dtype=torch.uint8, device=gpu)
+		stats0 = torch.tensor([0, _ffi.INT64_MAX], dtype=torch.int64, device=gpu)
+		stats = torch.empty_like(stats0)
 		for d in range(self.depth):
 			use_random = np.random.choice(2, self.workers, p=[1 - self.epsilon, self.epsilon]).astype(bool)
 			actions = np.empty(self.workers, dtype=int)
@@ -236,11 +239,13 @@ class EGVM(DeepAgent):
 				p = self.net(cube.device.as_oh(cur[torch.from_numpy(~use_random).to(gpu)].contiguous()), value=False).float().cpu().numpy()
 				actions[~use_random] = p.argmax(axis=1)
 			paths[:, d] = actions
-			cur = cube.device.multi_rotate(cur, torch.from_numpy(actions.astype(np.uint8)).to(gpu))
-			flags = cube.device.multi_is_solved(cur).cpu().numpy().astype(bool)
-			if flags.any():
+			# move + goal test in one launch (agents.py:696-703); the host reads the two statistics words, not the flags
+			stats.copy_(stats0)
+			cur, _ = cube.device.multi_rotate_solved(cur, torch.from_numpy(actions.astype(np.uint8)).to(gpu), flags=flags, stats=stats)
+			hit = stats.cpu()
+			if int(hit[0]):
 				self._explored_states += (d + 1) * self.workers
-				return paths, None, None, (int(np.flatnonzero(flags)[0]), d + 1)
+				return paths, None, None, (int(hit[1]), d + 1)
 			visited[:, d] = cur
 		self._explored_states += self.workers * self.depth
 		flat = visited.reshape(self.workers * self.depth, 20)
@@ -356,9 +361,12 @@ class AStar(DeepAgent):
 	    padded batch (measured with fc_small at N = 700 ... 1000: 15 % faster in float32, but 20 % slower than running
 	    ahead of the GPU with the three times faster bf16 net).
 
-	`capacity` bounds the number of stored states when a search is limited only by time (the reference grows its
-	arrays without bound): the pool doubles (a new engine, the search restarts from the root) until `max_capacity`;
-	a search that still fills the pool warns with `CapacityExhausted` and sets `self.capacity_exhausted`.
+	`capacity` is the size the node pool starts with.  A search whose state budget is larger (or that is limited only by
+	time) GROWS the pool in place when it fills up, as the reference's increase_stack_size does (agents.py:396-402):
+	`rk_astar_grow` doubles it -- device-to-device copies and one rehash kernel, the open queue stays as it is -- and the
+	search continues where it stood, so it ends with the arrays of a search that had started in the large pool.  At
+	`max_capacity` a search that still fills the pool warns with `CapacityExhausted` and sets `self.capacity_exhausted`.
+	`self.grown` counts the growths of the last search.
 	"""
 	default_capacity = 4_000_000
 	max_capacity = 64_000_000
@@ -386,6 +394,7 @@ class AStar(DeepAgent):
 		self._cache = None
 		self.iterations = 0
 		self.capacity_exhausted = False
+		self.grown = 0                # times the pool grew in place during the last search
 		self.record_pops = False      # debugging aid: keep the popped indices of every iteration in self.pops
 		self.pops = []
 
@@ -447,13 +456,16 @@ class AStar(DeepAgent):
 			oh = torch.zeros((K, 480), dtype=oh_dtype, device=gpu)
 			code = _OH_CODES[oh_dtype]
 		status = (C.c_longlong * 8)()
-		while True:
-			h = self._engine(cap)
-			cap = self._h_cap
-			_ffi.check(lib.rk_astar_reset(h, state.ctypes.data, float(self.lambda_), _ffi.stream_ptr()))
-			_ffi.check(lib.rk_astar_set_budget(h, int(min(max_states, cap)), _ffi.stream_ptr()))
-			self._root, self._n, self._cache = state.copy(), 1, None
-			self.iterations, self.pops = 0, []
+		h = self._engine(cap)
+		cap = self._h_cap
+		_ffi.check(lib.rk_astar_reset(h, state.ctypes.data, float(self.lambda_), _ffi.stream_ptr()))
+		_ffi.check(lib.rk_astar_set_budget(h, int(min(max_states, cap)), _ffi.stream_ptr()))
+		self._root, self._n, self._cache = state.copy(), 1, None
+		self.iterations, self.pops, self.grown = 0, [], 0
+		exact = self.exact_batch if self.exact_batch is not None else (K >= 2048 and _has_f32_weights(self.net))
+		exact = exact and not self.use_hipgraph and not self.record_pops
+		info = (C.c_longlong * 5)()
+		while True:                                                  # one round per pool size: the pool grows in place below
 			graph = None
 			if self.use_hipgraph and not self.record_pops:
 				side = torch.cuda.Stream()
@@ -461,14 +473,11 @@ class AStar(DeepAgent):
 				with torch.cuda.stream(side):
 					self._iteration(h, oh, code)                   # a real iteration; also warms the allocator
 				torch.cuda.current_stream().wait_stream(side)
-				graph = torch.cuda.CUDAGraph()
+				graph = torch.cuda.CUDAGraph()                     # (captured again after a growth: it holds the pool's addresses)
 				with torch.cuda.graph(graph):
 					self._iteration(h, oh, code)
 			budget = int(min(max_states, cap))
 			done = won = err = solved_idx = 0
-			exact = self.exact_batch if self.exact_batch is not None else (K >= 2048 and _has_f32_weights(self.net))
-			exact = exact and graph is None and not self.record_pops
-			info = (C.c_longlong * 5)()
 			while exact:
 				# one synchronisation per iteration, the net sees exactly the new states (agents.py:315, :369-383)
 				_ffi.check(lib.rk_astar_expand(h, self.expansions, info, _ffi.stream_ptr()))
@@ -505,6 +514,7 @@ class AStar(DeepAgent):
 					raise _ffi.RubiksHipError(f"A* engine error code {err}")
 				if won or done or time.perf_counter() - t0 >= time_limit:
 					break
+			self._cache = None
 			if won:
 				path = (C.c_longlong * 4096)()
 				n = lib.rk_astar_path(h, solved_idx, path, 4096, _ffi.stream_ptr())
@@ -517,13 +527,17 @@ class AStar(DeepAgent):
 			if not (pool_full and max_states > cap and time.perf_counter() - t0 < time_limit):
 				return False
 			# the pool, not the caller's budget, ended the search: grow it like the reference's increase_stack_size
-			# (agents.py:396-402) -- here by restarting in an engine twice the size -- or say so
+			# (agents.py:396-402) -- in place, the search goes on where it stood -- or say so
 			if cap >= self.max_capacity:
 				self.capacity_exhausted = True
 				import warnings
 				warnings.warn(f"{self}: node pool of {cap} states is full with time left; raise max_capacity", CapacityExhausted)
 				return False
 			cap = min(2 * cap, self.max_capacity)
+			_ffi.check(lib.rk_astar_grow(h, cap, _ffi.stream_ptr()))
+			self._h_cap = cap
+			_ffi.check(lib.rk_astar_set_budget(h, int(min(max_states, cap)), _ffi.stream_ptr()))
+			self.grown += 1
 
 	# -- inspection (what the reference's tests look at: tests/test_agents.py:96-145) --------------------------
 	def _export(self):
@@ -605,6 +619,9 @@ def _policy_value_f32(out):
 	return p, v
 
 
+PRIORS = ("kernel", "torch", "reference")
+
+
 class MCTSBatch(DeepAgent):
 	"""
 	T independent Monte Carlo tree searches advanced in lock-step on the GPU (engine rk_mcts_*).  Each tree follows
@@ -614,25 +631,45 @@ class MCTSBatch(DeepAgent):
 	One simulation of all trees = expand kernel, one-hot kernel, net forward on the fixed (12 T, 480) batch,
 	backup+select kernel.  Nothing in a step synchronises, so `use_graph=True` captures the step in a hipGraph
 	(through torch.cuda.CUDAGraph) and replays it; the host only polls every `poll` simulations.
+
+	priors -- where softmax(logits) (agents.py:472, :551-552) is computed:
+	  "kernel"     inside the backup kernel from the net's raw float32 / bfloat16 logits: exp(x - max) / sum in float32, the sum
+	               taken in the order torch.softmax's own kernel adds on this device (rk_mcts.hip, child_policy) -- no softmax,
+	               conversion or copy kernels in the step; capturable.  The default of this class (the throughput form).
+	  "torch"      torch.softmax on the device, float32; capturable.
+	  "reference"  the reference's own two lines: the root's priors by `p.softmax(dim=1)` on the device (agents.py:472), every
+	               other node's by `p.cpu().softmax(dim=1)` (agents.py:551-552: on the HOST), bit for bit whatever torch's CPU
+	               kernel does.  One device-to-host wait per simulation, so not capturable.  The default of `MCTS`.
+	`search_graph`: after the search, every solved tree gets the reference's graph completion and breadth-first shortening
+	(agents.py:597-633) on the device (rk_mcts_search_graph); `action_queue_of` then returns the shortened queue.
+	`max_capacity`: pools that fill up while a tree's own budget is larger grow in place (rk_mcts_grow; agents.py:450-460),
+	doubling up to this many states per tree.
 	"""
 
 	def __init__(self, net, c: float, n_trees: int, capacity: int = 50_000, max_path: int = None, nu: float = 100.0,
-	             fused_first_layer=False, torch_softmax: bool = False):
+	             fused_first_layer=False, torch_softmax: bool = False, priors: str = None, search_graph: bool = False,
+	             max_capacity: int = None):
 		# fused_first_layer: the net's first Linear(480, H) reads the children's 20-byte states (librubiks_amd.oh_linear)
 		super().__init__(net, fused_first_layer)
-		# The priors are softmax(logits) (agents.py:551-552).  By default the backup kernel computes it itself from the net's
-		# raw float32 / bfloat16 logits (exp(x - max) / sum in float32: two kernels and a copy fewer per simulation); that
-		# agrees with torch.softmax to the last float32 bits but is not bit-identical to it on arbitrary logits
-		# (tests/test_mcts_gpu.py states the bound), and a one-ulp difference in P can flip an arg-max tie of U + Q.
-		# torch_softmax=True makes the priors torch's own softmax on this device, as the reference computes them.
-		self.torch_softmax = bool(torch_softmax)
+		priors = priors or ("torch" if torch_softmax else "kernel")
+		if priors not in PRIORS:
+			raise ValueError(f"priors is one of {PRIORS}")
+		self.priors = priors
+		self.search_graph = bool(search_graph)
 		self.c, self.nu, self.n_trees = float(c), float(nu), int(n_trees)
 		self.capacity = int(capacity)
+		self.max_capacity = int(max_capacity) if max_capacity else None
+		self._auto_path = max_path is None
 		self.max_path = int(max_path or max(4096, 2 * self.capacity))
 		self._h = None
 		self._shape = None
 		self.status = None
 		self.simulations = 0
+		self.grown = 0
+
+	@property
+	def torch_softmax(self) -> bool:
+		return self.priors == "torch"
 
 	def _engine(self):
 		shape = (self.n_trees, self.capacity, self.max_path)
@@ -654,17 +691,22 @@ class MCTSBatch(DeepAgent):
 		except Exception:
 			pass
 
+	_ERRORS = {1: "path longer than max_path", 2: "broken neighbour link", 3: "backup without a pending expansion (rk_mcts_expand missing from the step)"}
+
 	def _poll(self):
 		st = np.zeros((self.n_trees, 6), np.int64)
 		_ffi.check(_ffi.lib().rk_mcts_status(self._h, st.ctypes.data, _ffi.stream_ptr()))
 		if (st[:, 5] != 0).any():
-			raise _ffi.RubiksHipError(f"MCTS engine error codes {st[:, 5].tolist()}: path longer than max_path={self.max_path}")
+			codes = sorted(set(int(x) for x in st[:, 5] if x))
+			raise _ffi.RubiksHipError(f"MCTS engine error codes {codes}: " + "; ".join(self._ERRORS.get(k, "?") for k in codes)
+			                          + f" (max_path={self.max_path})")
 		self.status = st
 		return st
 
-	def _step(self, oh, h):
+	def _step(self, oh, h, expand: bool = True):
 		lib = _ffi.lib()
-		_ffi.check(lib.rk_mcts_expand(h, _ffi.stream_ptr()))
+		if expand:
+			_ffi.check(lib.rk_mcts_expand(h, _ffi.stream_ptr()))
 		if self._fs is not None:
 			# the first layer reads the children where the engine keeps them; no one-hot, no copy
 			x = self._fs.first.from_pointer(lib.rk_mcts_children(h), 12 * self.n_trees)
@@ -672,7 +714,7 @@ class MCTSBatch(DeepAgent):
 		else:
 			_ffi.check(lib.rk_mcts_children_oh(h, oh.data_ptr(), _OH_CODES[oh.dtype], _ffi.stream_ptr()))
 			p, v = self.net(oh)
-		if not self.torch_softmax and isinstance(p, torch.Tensor) and p.is_cuda and p.dtype == v.dtype and p.dtype in (torch.float32, torch.bfloat16) \
+		if self.priors == "kernel" and isinstance(p, torch.Tensor) and p.is_cuda and p.dtype == v.dtype and p.dtype in (torch.float32, torch.bfloat16) \
 		   and p.dim() == 2 and p.stride(1) == 1 and p.stride(0) >= 12 and v.numel() == len(p) and v.reshape(len(p), -1).stride(0) >= 1:
 			# raw logits and values in the net's dtype (rows may be views into one tensor of merged heads): the softmax
 			# (agents.py:551) runs inside the backup kernel
@@ -680,7 +722,12 @@ class MCTSBatch(DeepAgent):
 			_ffi.check(lib.rk_mcts_backup_select_logits(h, p.data_ptr(), p.stride(0), v.data_ptr(), v.reshape(len(p), -1).stride(0),
 			                                            _OH_CODES[p.dtype], _ffi.stream_ptr()))
 			return
-		p, v = _policy_value_f32((p, v))
+		if self.priors == "reference":
+			# agents.py:551-552 to the letter: `p.cpu().softmax(dim=1)` -- the HOST's softmax of the logits
+			v = v.detach().to(device=gpu, dtype=torch.float32).reshape(-1).contiguous()
+			p = p.detach().cpu().softmax(dim=1).to(torch.float32).contiguous().to(gpu)
+		else:
+			p, v = _policy_value_f32((p, v))
 		self._keep = (p, v)
 		_ffi.check(lib.rk_mcts_backup_select(h, p.data_ptr(), v.data_ptr(), _ffi.stream_ptr()))
 
@@ -694,7 +741,7 @@ class MCTSBatch(DeepAgent):
 		self._begin(states, max_states, max_sims, use_graph)
 		while time.perf_counter() - t0 < time_limit and (max_sims is None or self.simulations < max_sims):
 			self._advance(poll if max_sims is None else min(poll, max_sims - self.simulations))
-			if self._poll()[:, 0].all():
+			if self._poll()[:, 0].all() and not self._grow():
 				break
 		return self._finish()
 
@@ -709,7 +756,8 @@ class MCTSBatch(DeepAgent):
 		states = np.ascontiguousarray(states, dtype=np.int8).reshape(self.n_trees, 20)
 		if max_states is None:
 			max_states = self.capacity
-		ms = np.minimum(np.broadcast_to(np.asarray(max_states, dtype=np.int64), (self.n_trees,)), self.capacity).copy()
+		self._budget = np.broadcast_to(np.asarray(max_states, dtype=np.int64), (self.n_trees,)).copy()      # what the caller asked for
+		ms = np.minimum(self._budget, self.capacity)
 		h, lib = self._engine(), _ffi.lib()
 		_ffi.check(lib.rk_mcts_reset(h, states.ctypes.data, ms.ctypes.data, self.c, self.nu, _ffi.stream_ptr()))
 		self._fs = self._from_states           # re-copied here if the net changed since the last search
@@ -722,24 +770,32 @@ class MCTSBatch(DeepAgent):
 			oh_dtype = _oh_dtype(self.net)
 			root_oh = torch.empty((self.n_trees, 480), dtype=oh_dtype, device=gpu)
 			_ffi.check(lib.rk_mcts_roots_oh(h, root_oh.data_ptr(), _OH_CODES[oh_dtype], _ffi.stream_ptr()))
-			p, v = _policy_value_f32(self.net(root_oh))                  # agents.py:470-473
+			p, v = _policy_value_f32(self.net(root_oh))                  # agents.py:470-473: the root's softmax runs on the device
 			oh = torch.empty((12 * self.n_trees, 480), dtype=oh_dtype, device=gpu)
 		_ffi.check(lib.rk_mcts_set_root_pv(h, p.data_ptr(), v.data_ptr(), _ffi.stream_ptr()))
 		# every backup + select launch also expands the leaf it found, while another simulation is to follow
 		_ffi.check(lib.rk_mcts_set_expand_ahead(h, int(max_sims) if max_sims is not None else -1))
-		self.simulations = 0
+		self.simulations, self.grown = 0, 0
 		self._max_sims, self._oh, self._graph = max_sims, oh, None
-		if use_graph and (max_sims is None or max_sims > 2):
-			side = torch.cuda.Stream()
-			side.wait_stream(torch.cuda.current_stream())
-			with torch.cuda.stream(side):
-				for _ in range(2):                                     # real simulations; they also warm the allocator
-					self._step(oh, h)
-					self.simulations += 1
-			torch.cuda.current_stream().wait_stream(side)
-			self._graph = torch.cuda.CUDAGraph()
-			with torch.cuda.graph(self._graph):
+		self._use_graph = bool(use_graph) and self.priors != "reference"       # the host softmax waits for the device: nothing to capture
+		if self._use_graph and (max_sims is None or max_sims > 2):
+			self._capture(2)
+
+	def _capture(self, warm: int):
+		"""`warm` real simulations, then the step as a hipGraph.  After an eager step with expand-ahead on, every tree's next
+		expansion is always done by the backup launch before it, so the captured step leaves rk_mcts_expand out (one launch less
+		per replay); were that ever untrue, the backup kernel stops the tree with error 3 instead of using stale children."""
+		h, oh = self._h, self._oh
+		side = torch.cuda.Stream()
+		side.wait_stream(torch.cuda.current_stream())
+		with torch.cuda.stream(side):
+			for _ in range(warm):                                      # real simulations; they also warm the allocator
 				self._step(oh, h)
+				self.simulations += 1
+		torch.cuda.current_stream().wait_stream(side)
+		self._graph = torch.cuda.CUDAGraph()
+		with torch.cuda.graph(self._graph):
+			self._step(oh, h, expand=False)
 
 	@no_grad
 	def _advance(self, n: int):
@@ -750,6 +806,28 @@ class MCTSBatch(DeepAgent):
 				self._step(self._oh, self._h)
 		self.simulations += n
 
+	def _grow(self) -> bool:
+		"""All trees are done.  If some stopped only because the POOL was their budget (the caller's is larger), grow every
+		pool in place (agents.py:450-460, :503-504) and let those trees go on.  True if the search continues."""
+		st = self.status
+		if not self.max_capacity or self.capacity >= self.max_capacity:
+			return False
+		want = (st[:, 1] == 0) & (st[:, 2] + 12 > np.minimum(self._budget, self.capacity)) & (self._budget > self.capacity)
+		if not want.any():
+			return False
+		cap = min(2 * self.capacity, self.max_capacity)
+		path = max(self.max_path, 2 * cap) if self._auto_path else self.max_path
+		ms = np.minimum(self._budget, cap)
+		_ffi.check(_ffi.lib().rk_mcts_grow(self._h, cap, path, ms.ctypes.data, _ffi.stream_ptr()))
+		self.capacity, self.max_path = cap, path
+		self._shape = (self.n_trees, cap, path)
+		self.grown += 1
+		if self._graph is not None:                                   # the captured step holds the old pools' addresses
+			self._graph = None
+			if self._max_sims is None or self._max_sims - self.simulations > 1:
+				self._capture(1)
+		return True
+
 	@no_grad
 	def _finish(self) -> np.ndarray:
 		_ffi.check(_ffi.lib().rk_mcts_set_expand_ahead(self._h, 0))
@@ -759,11 +837,19 @@ class MCTSBatch(DeepAgent):
 			self._step(self._oh, self._h)
 			self.simulations += 1
 		st = self._poll()
+		self._graph_done = False
+		if self.search_graph and (st[:, 1] == 1).any():                 # agents.py:483-486, on the device
+			_ffi.check(_ffi.lib().rk_mcts_search_graph(self._h, _ffi.stream_ptr()))
+			self._graph_done = True
 		return st[:, 1] != 0
 
 	# -- results ------------------------------------------------------------------------------------------------
 	def action_queue_of(self, tree: int) -> deque:
 		buf = (C.c_longlong * self.max_path)()
+		if getattr(self, "_graph_done", False) and self.status[tree, 1] == 1:
+			n = _ffi.lib().rk_mcts_graph_path(self._h, tree, buf, self.max_path, _ffi.stream_ptr())
+			if n >= 0:
+				return deque(int(a) for a in buf[:n])
 		n = _ffi.lib().rk_mcts_path(self._h, tree, buf, None, self.max_path, _ffi.stream_ptr())
 		if n < 0:
 			_ffi.check(int(n))
@@ -801,13 +887,24 @@ class MCTS(DeepAgent):
 	The reference's single-tree agent (agents.py:415-645) on the device engine: `MCTS(net, c, search_graph)`,
 	`search(state, time_limit, max_states)`, `action_queue`, `len(agent)`, and the arrays `states, neighbors, leaves,
 	P, V, N, W, L, indices` for inspection (tests/test_agents.py:49-94).
+
+	With default arguments the priors are computed exactly where and how the reference computes them (`priors="reference"`,
+	see MCTSBatch: the root's softmax on the device, every other node's on the host, agents.py:472 and :551-552), so P equals
+	the reference's bit for bit whenever the logits do; that costs one device-to-host wait per simulation.  `priors="kernel"`
+	(softmax inside the backup kernel, no wait, hipGraph-capturable) is the fast form; `use_hipgraph=True` implies it unless
+	`priors` is given.  The pool starts at `capacity` (default 200 000 nodes) and grows in place while the state budget allows
+	(rk_mcts_grow, agents.py:450-460) up to `max_capacity`; graph completion and path shortening of a solved search
+	(`search_graph`, agents.py:597-633) run on the device.
 	"""
 	default_capacity = 200_000
 	max_capacity = 25_000_000           # 461 B per node: 11.5 GB
 
-	def __init__(self, net, c: float, search_graph: bool, capacity: int = None, use_hipgraph: bool = False, torch_softmax: bool = False):
+	def __init__(self, net, c: float, search_graph: bool, capacity: int = None, use_hipgraph: bool = False, torch_softmax: bool = False,
+	             priors: str = None):
 		super().__init__(net)
-		self.torch_softmax = torch_softmax        # priors by torch.softmax instead of the backup kernel's own (see MCTSBatch)
+		self.priors = priors or ("torch" if torch_softmax else ("kernel" if use_hipgraph else "reference"))
+		if self.priors not in PRIORS:
+			raise ValueError(f"priors is one of {PRIORS}")
 		self.c = c
 		self.search_graph = search_graph
 		self.nu = 100
@@ -816,6 +913,11 @@ class MCTS(DeepAgent):
 		self._batch = None
 		self._arrays = None
 		self._n = 0
+		self.capacity_exhausted = False
+
+	@property
+	def grown(self) -> int:
+		return self._batch.grown if self._batch is not None else 0
 
 	def reset(self, time_limit: float, max_states: int):
 		time_limit, max_states = super().reset(time_limit, max_states)
@@ -824,77 +926,25 @@ class MCTS(DeepAgent):
 
 	@no_grad
 	def search(self, state: np.ndarray, time_limit: float = None, max_states: int = None) -> bool:
-		t0 = time.perf_counter()
 		time_limit, max_states = self.reset(time_limit, max_states)
 		self.capacity_exhausted = False
 		cap = int(min(max_states, self.capacity or self.default_capacity))
-		while True:
-			if self._batch is None or self._batch.capacity != cap or self._batch.c != float(self.c):
-				self._batch = MCTSBatch(self.net, self.c, 1, capacity=cap, nu=self.nu, torch_softmax=self.torch_softmax)
-			self._batch.net = self.net
-			left = time_limit - (time.perf_counter() - t0)
-			solved = bool(self._batch.search(np.asarray(state)[None], time_limit=max(left, 1e-3), max_states=cap, poll=8,
-			                                 use_graph=self.use_hipgraph)[0])
-			self._n = int(self._batch.status[0, 2])
-			# a search limited only by time that filled its pool: the reference grows its arrays (agents.py:496-503);
-			# here the tree restarts in a pool twice the size, or the caller is told
-			pool_full = not solved and self._n + 12 > cap and max_states > cap and time.perf_counter() - t0 < time_limit
-			if not pool_full:
-				break
-			if cap >= self.max_capacity:
-				self.capacity_exhausted = True
-				import warnings
-				warnings.warn(f"{self}: node pool of {cap} states is full with time left; raise max_capacity", CapacityExhausted)
-				break
-			cap = min(2 * cap, self.max_capacity)
-		self.action_queue = self._batch.action_queue_of(0)
-		if solved and self.search_graph and len(self.action_queue):
-			solve_leaf = self.index_of_solved()
-			self._complete_graph()
-			self._shorten_action_queue(solve_leaf)
+		b = self._batch
+		if b is None or b.capacity < cap or b.c != float(self.c) or b.priors != self.priors or b.search_graph != bool(self.search_graph) \
+		   or b.max_capacity != self.max_capacity:
+			b = self._batch = MCTSBatch(self.net, self.c, 1, capacity=cap, nu=self.nu, priors=self.priors, search_graph=self.search_graph,
+			                            max_capacity=self.max_capacity)
+		b.net = self.net
+		# the pool grows in place inside the batch engine while the budget is larger (agents.py:496-503)
+		solved = bool(b.search(np.asarray(state)[None], time_limit=time_limit, max_states=int(min(max_states, 2 ** 62)), poll=8,
+		                       use_graph=self.use_hipgraph)[0])
+		self._n = int(b.status[0, 2])
+		if not solved and self._n + 12 > b.capacity and max_states > b.capacity and b.capacity >= self.max_capacity:
+			self.capacity_exhausted = True
+			import warnings
+			warnings.warn(f"{self}: node pool of {b.capacity} states is full with time left; raise max_capacity", CapacityExhausted)
+		self.action_queue = b.action_queue_of(0)       # with search_graph: completed and shortened on the device (agents.py:483-486)
 		return solved
-
-	# -- graph post-processing of a solved search (agents.py:597-633); runs once, on the exported arrays ---------
-	def index_of_solved(self) -> int:
-		return self.indices[cube.get_solved().tobytes()]
-
-	def _complete_graph(self):
-		"""Link every leaf to those of its 12 children that are already in the graph (agents.py:597-611)."""
-		a = self._export()
-		n, idx = self._n, self.indices
-		leaf_idx = np.flatnonzero(a["leaves"][:n + 1])[1:]
-		if not len(leaf_idx):
-			return
-		children = cube.expand(a["states"][leaf_idx])
-		child_idx = np.array([idx.get(c.tobytes(), 0) for c in children], dtype=np.int64)
-		rep = np.repeat(leaf_idx, 12)
-		acts = np.tile(np.arange(12), len(leaf_idx))
-		a["neighbors"][rep, acts] = child_idx
-		a["neighbors"][child_idx, acts ^ 1] = rep
-		a["neighbors"][0] = 0
-
-	def _shorten_action_queue(self, solved_index: int):
-		"""Breadth-first search for the shortest known path root -> solved state (agents.py:613-633)."""
-		if solved_index == 1:
-			return
-		nb = self._export()["neighbors"]
-		back = {1: (0, 0)}
-		frontier = deque([1])
-		while frontier:
-			v = frontier.popleft()
-			for a in range(12):
-				w = int(nb[v, a])
-				if w == 0 or w in back:
-					continue
-				back[w] = (v, a)
-				if w == solved_index:
-					queue = deque()
-					while w != 1:
-						w, act = back[w]
-						queue.appendleft(act)
-					self.action_queue = queue
-					return
-				frontier.append(w)
 
 	# -- inspection -------------------------------------------------------------------------------------------
 	def _export(self) -> dict:
@@ -915,6 +965,7 @@ class MCTS(DeepAgent):
 
 	@property
 	def indices(self) -> dict:
+		"""state bytes -> index (the reference's dict, agents.py:419), rebuilt on the host from the exported states: inspection only"""
 		st = self.states
 		return {st[i].tobytes(): i for i in range(1, self._n + 1)}
 
