@@ -666,6 +666,15 @@ int mcts_alloc(rk_mcts *h, T **p, size_t count)
 
 inline unsigned nblocks(size_t n, unsigned per = 256) { return (unsigned)((n + per - 1) / per); }
 
+// is `st` recording into a hipGraph? (the legacy default stream cannot be)
+inline bool capturing(hipStream_t st)
+{
+	if (st == nullptr) return false;
+	hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+	if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); return false; }
+	return cap != hipStreamCaptureStatusNone;
+}
+
 // `rows` blocks of `width` bytes, `spitch` / `dpitch` bytes apart, device to device: one plain copy per block (a tree's block can
 // be gigabytes wide, which is not what the 2-D copy engine path is made for), the 2-D call only for very many trees
 hipError_t strided_copy(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t rows, hipStream_t st)
@@ -916,12 +925,13 @@ int rk_mcts_expand(rk_mcts_t *h, void *stream)
 	if (!h || !h->ready) return fail(RK_ESTATE, "rk_mcts_expand: reset the engine first");
 	// The previous backup + select launch may have expanded the leaves already (expand ahead).  Eagerly the host knows and skips
 	// the launch; a call that is being CAPTURED into a hipGraph always records the kernel, which takes the decision on the device
-	// (TR_READY) at every replay -- whatever state the graph was captured in and whatever state it is replayed from.
-	hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-	if (stream != nullptr && hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
-	const bool skip = h->ahead && cap == hipStreamCaptureStatusNone;
-	h->ahead = false;
-	if (skip) return RK_OK;
+	// (TR_READY) at every replay -- whatever state the graph was captured in and whatever state it is replayed from.  The host's
+	// flag is only ever an optimisation of eager sequences: captured calls execute nothing and leave it alone.
+	if (!capturing((hipStream_t)stream)) {
+		const bool skip = h->ahead;
+		h->ahead = false;
+		if (skip) return RK_OK;
+	}
 	hipLaunchKernelGGL(k_mcts_expand, dim3(h->d.T), dim3(64), 0, (hipStream_t)stream, h->d);
 	RK_HIP(hipGetLastError());
 	return RK_OK;
@@ -944,7 +954,7 @@ int rk_mcts_backup_select(rk_mcts_t *h, const float *d_probs, const float *d_val
 	if (!d_probs || !d_values) return fail(RK_EINVAL, "rk_mcts_backup_select: null pointer");
 	hipLaunchKernelGGL(k_mcts_backup_select<0>, dim3(h->d.T), dim3(64), 0, (hipStream_t)stream, h->d, (const void *)d_probs, (const void *)d_values, 12, 1, h->ahead_limit);
 	RK_HIP(hipGetLastError());
-	h->ahead = h->ahead_limit != 0;
+	if (!capturing((hipStream_t)stream)) h->ahead = h->ahead_limit != 0;
 	return RK_OK;
 }
 
@@ -960,7 +970,7 @@ int rk_mcts_backup_select_logits(rk_mcts_t *h, const void *d_logits, int logits_
 	else
 		return fail(RK_EINVAL, "rk_mcts_backup_select_logits: logits and values must be float32 or bfloat16");
 	RK_HIP(hipGetLastError());
-	h->ahead = h->ahead_limit != 0;
+	if (!capturing((hipStream_t)stream)) h->ahead = h->ahead_limit != 0;
 	return RK_OK;
 }
 

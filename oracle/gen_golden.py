@@ -230,6 +230,10 @@ def mcts_traces():
 		"d": dict(seed=23, depth=12, c=2.5, search_graph=False, max_states=2_500),
 		"e": dict(seed=2, depth=2, c=1.0, search_graph=True, max_states=10_000),    # solves at 1 568 states
 		"f": dict(seed=31, depth=9, c=3.0, search_graph=False, max_states=3_000, net="policy"),   # non-uniform priors
+		# search_graph cases in which the breadth-first search really SHORTENS the queue (the descents run in circles under a
+		# strongly non-uniform policy and a large c): 9 moves found, 3 after agents.py:613-633; 9 -> 5
+		"g": dict(seed=1032, depth=3, c=50.0, search_graph=True, max_states=4_000, net="policy"),
+		"h": dict(seed=1010, depth=5, c=50.0, search_graph=True, max_states=4_000, net="policy"),
 	}
 	for tag, c in cases.items():
 		np.random.seed(c["seed"])

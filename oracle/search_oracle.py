@@ -78,6 +78,35 @@ class PolicyStubNet(StubNet):
 		return out if len(out) > 1 else out[0]
 
 
+class NoisyStubNet(StubNet):
+	"""
+	StubNet plus exact integer "noise": value = -(cubies off their solved code) + ((one-hot . w) mod 7) - 3 with a fixed vector
+	of small integers w, so every number is a small integer in float32 on any hardware.  The noise misleads the search, which
+	then reaches the goal over roundabout paths -- what the graph completion and the breadth-first shortening of MCTS
+	(agents.py:597-633) need to have something to shorten.  Test infrastructure only.
+	"""
+	def __init__(self, seed: int = 0):
+		super().__init__()
+		self.w = np.random.RandomState(seed).randint(0, 50, 480).astype(np.float32)
+		self._w_dev = {}
+
+	def __call__(self, x, policy=True, value=True):
+		import torch
+		out = []
+		if policy:
+			out.append(torch.zeros(len(x), 12, device=x.device) if isinstance(x, torch.Tensor) else np.zeros((len(x), 12), np.float32))
+		if value:
+			base = super().__call__(x, policy=False, value=True)
+			if isinstance(x, torch.Tensor):
+				if x.device not in self._w_dev:
+					self._w_dev[x.device] = torch.from_numpy(self.w).to(x.device)
+				noise = torch.remainder((x.float() * self._w_dev[x.device]).sum(dim=1, keepdim=True), 7.0) - 3.0
+			else:
+				noise = (np.mod((x * self.w).sum(axis=1, keepdims=True), 7.0) - 3.0).astype(np.float32)
+			out.append(base + noise)
+		return out if len(out) > 1 else out[0]
+
+
 def adi_traindata_oracle(net, games: int, depth: int, alpha: float, method: str):
 	"""
 	`Train.ADI_traindata` (train.py:256-339) on the CPU oracle: scramble (:277), 12-child fan-out (:285), rewards

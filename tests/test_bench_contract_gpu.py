@@ -36,3 +36,19 @@ def test_smoke_entry_point():
 	sys.path.insert(0, ROOT)
 	import __graft_entry__
 	__graft_entry__.smoke()
+
+
+def test_bench_two_ranks_without_a_launcher():
+	"""VERDICT r3 #1a: `python bench.py --gpus 2` with no launcher starts its own two ranks (benchmarks/spawn.py) -- here sharing
+	the one GPU of the box, rendezvous over gloo -- and prints ONE line whose value is both ranks' work over the slower one's time."""
+	env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+	env["RK_BENCH_BACKEND"] = "gloo"
+	out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2"],
+	                     capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+	assert out.returncode == 0, out.stderr[-3000:]
+	lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+	assert len(lines) == 1
+	r = json.loads(lines[0])
+	assert r["n_gpus"] == 2 and r["steps"] == 10 and r["scaling"] == "weak" and "cpu_baseline" not in r
+	assert abs(r["value"] - 2 * 1e6 / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-6
+	assert r["config"]["parallelism"] == "independent batches x2"

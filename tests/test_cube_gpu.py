@@ -637,3 +637,110 @@ def test_paced_as_oh_every_dtype(dtype):
 		for lo in (0, n // 2, n - 5000):
 			assert torch.equal(cube.device.as_oh(states[lo:lo + 5000], dtype=dtype), oh[lo:lo + 5000])      # unpaced launches
 		del oh
+
+
+@pytest.mark.parametrize("n", [1, 3, 63, 256, 257, 1000, 70_001, 2_100_003])
+def test_multi_rotate_solved_is_the_two_calls_in_one(n):
+	"""rk_multi_rotate_solved: `multi_rotate` and `multi_is_solved` of the moved states in one launch -- the pair of
+	agents.py:157-159, :696-703, train.py:277-281.  Moved states, flags, count and first index against the two separate kernels and
+	(a sample) the C oracle; planted rows one move from solved; in place; ragged tiles; the paced size (2 Mi states on)."""
+	g = torch.Generator(device="cuda")
+	g.manual_seed(1000 + n % 997)
+	states = cube.device.apply_sequences(torch.randint(0, 12, (11, n), device="cuda", dtype=torch.uint8, generator=g), False, True)
+	acts = torch.randint(0, 12, (n,), device="cuda", dtype=torch.uint8, generator=g)
+	plant = sorted({0, n // 3, n - 1})
+	for k, i in enumerate(plant):                                              # state = rev(a) of solved, action = a: the move solves it
+		a = (5 * k + 2) % 12
+		states[i] = dev(orc.rotate(orc.SOLVED, (a ^ 1) // 2, 1 - (a ^ 1) % 2))
+		acts[i] = a
+	want = cube.device.multi_rotate(states, acts)
+	want_fl = cube.device.multi_is_solved(want)
+	stats = torch.tensor([0, _ffi.INT64_MAX], dtype=torch.int64, device="cuda")
+	out, fl = cube.device.multi_rotate_solved(states, acts, stats=stats)
+	assert torch.equal(out, want) and torch.equal(fl, want_fl)
+	assert int(fl.sum()) == stats[0].item() >= len(plant) and stats[1].item() == int(torch.nonzero(fl)[0]) == 0
+	assert all(bool(fl[i]) for i in plant)
+	pick = torch.unique(torch.cat([torch.arange(0, min(n, 512)), torch.randint(0, n, (min(n, 2048),)), torch.arange(max(0, n - 512), n)])).cuda()
+	ref = c_oracle.multi_rotate(states[pick].cpu().numpy(), acts[pick].cpu().numpy())
+	assert (out[pick].cpu().numpy() == ref).all() and (fl[pick].cpu().numpy().astype(bool) == orc.multi_is_solved(ref)).all()
+	# in place, flags only / stats only, misaligned flag buffer (byte path)
+	inplace = states.clone()
+	store = torch.zeros(n + 3, dtype=torch.uint8, device="cuda")
+	o2, f2 = cube.device.multi_rotate_solved(inplace, acts, out=inplace, flags=store[3:])
+	assert o2 is inplace and torch.equal(inplace, want) and torch.equal(f2, want_fl)
+	lib = _ffi.lib()
+	st2 = torch.tensor([0, _ffi.INT64_MAX], dtype=torch.int64, device="cuda")
+	tmp = torch.empty_like(states)
+	_ffi.check(lib.rk_multi_rotate_solved(_ffi.REPR_2024, states.data_ptr(), acts.data_ptr(), tmp.data_ptr(), None, st2.data_ptr(), n, None))
+	assert torch.equal(tmp, want) and st2.tolist() == stats.tolist()
+	assert lib.rk_multi_rotate_solved(_ffi.REPR_2024, states.data_ptr(), acts.data_ptr(), tmp.data_ptr(), None, None, n, None) == -1
+
+
+def test_multi_rotate_solved_686():
+	cube.set_is2024(False)
+	try:
+		n = 3001
+		g = torch.Generator(device="cuda")
+		g.manual_seed(9)
+		p = dev(np.broadcast_to(orc.SOLVED686, (n, 6, 8, 6)).copy())
+		for _ in range(4):
+			p = cube.device.multi_rotate(p, torch.randint(0, 12, (n,), device="cuda", dtype=torch.uint8, generator=g))
+		acts = torch.randint(0, 12, (n,), device="cuda", dtype=torch.uint8, generator=g)
+		p[17] = dev(orc.rotate686(orc.SOLVED686, 2, 1))
+		acts[17] = 2 * 2 + 1                                                # (face 2, dir 0) undoes (face 2, dir 1)
+		want = cube.device.multi_rotate(p, acts)
+		stats = torch.tensor([0, _ffi.INT64_MAX], dtype=torch.int64, device="cuda")
+		out, fl = cube.device.multi_rotate_solved(p, acts, stats=stats)
+		assert torch.equal(out, want) and torch.equal(fl, cube.device.multi_is_solved(want)) and bool(fl[17]) and stats[0].item() == int(fl.sum())
+	finally:
+		cube.set_is2024(True)
+
+
+def test_paced_kernels_of_different_kinds_on_two_streams():
+	"""VERDICT r3 #7 / ADVICE r3: every paced launch has its own time base now (a cell of g_pace_cells handed out per launch), so
+	two paced kernels of DIFFERENT kinds in flight on two streams -- what the sharded search and ADI run -- cannot move each
+	other's schedule.  Results never depended on the base; they are checked here for the pairs fan-out / as_oh and fan-out /
+	6x8x6 fan-out, several rounds each (benchmarks/pace_streams.py records what the concurrency costs in time)."""
+	n = 600_000
+	g = torch.Generator(device="cuda")
+	g.manual_seed(77)
+	a = cube.device.apply_sequences(torch.randint(0, 12, (9, n), device="cuda", dtype=torch.uint8, generator=g), False, True)
+	b = cube.device.apply_sequences(torch.randint(0, 12, (9, n), device="cuda", dtype=torch.uint8, generator=g), False, True)
+	ref_ch, ref_fl = cube.device.expand12(a)
+	ref_oh = cube.device.as_oh(b, dtype=torch.bfloat16)
+	s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+	ch, fl, oh = torch.empty_like(ref_ch), torch.empty_like(ref_fl), torch.empty_like(ref_oh)
+	torch.cuda.synchronize()
+	for _ in range(4):
+		ch.zero_(); fl.fill_(9); oh.zero_()
+		torch.cuda.synchronize()
+		with torch.cuda.stream(s1):
+			cube.device.expand12(a, ch, fl)
+			cube.device.expand12(a, ch, fl)
+		with torch.cuda.stream(s2):
+			cube.device.as_oh(b, oh, torch.bfloat16)
+			cube.device.as_oh(b, oh, torch.bfloat16)
+		torch.cuda.synchronize()
+		assert torch.equal(ch, ref_ch) and torch.equal(fl, ref_fl) and torch.equal(oh, ref_oh)
+	del oh, ref_oh
+	cube.set_is2024(False)
+	try:
+		m = 80_000
+		p = dev(np.broadcast_to(orc.SOLVED686, (m, 6, 8, 6)).copy())
+		for _ in range(5):
+			p = cube.device.multi_rotate(p, torch.randint(0, 12, (m,), device="cuda", dtype=torch.uint8, generator=g))
+		ref6, ref6_fl = cube.device.expand12(p)
+		ch6, fl6 = torch.empty_like(ref6), torch.empty_like(ref6_fl)
+		for _ in range(3):
+			ch.zero_(); ch6.zero_()
+			torch.cuda.synchronize()
+			with torch.cuda.stream(s1):
+				cube.set_is2024(True)
+				cube.device.expand12(a, ch, fl)
+			with torch.cuda.stream(s2):
+				cube.set_is2024(False)
+				cube.device.expand12(p, ch6, fl6)
+			torch.cuda.synchronize()
+			assert torch.equal(ch, ref_ch) and torch.equal(ch6, ref6) and torch.equal(fl6, ref6_fl)
+	finally:
+		cube.set_is2024(True)

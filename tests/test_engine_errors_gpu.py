@@ -101,7 +101,8 @@ def test_astar_batch_argument_and_state_errors():
 
 def test_time_limited_search_grows_its_pool_or_says_so():
 	"""A search limited only by time must not stop silently on its default pool (the reference grows its arrays): the pool
-	doubles while time is left; at max_capacity the agent warns and flags it."""
+	doubles IN PLACE while time is left (rk_astar_grow / rk_mcts_grow; tests/test_growth_gpu.py holds the grown search to the
+	arrays of one that started large); at max_capacity the agent warns and flags it."""
 	from librubiks_amd.solving.agents import CapacityExhausted, MCTS
 	np.random.seed(6)
 	start, _, _ = orc.scramble(30, True)
@@ -109,7 +110,7 @@ def test_time_limited_search_grows_its_pool_or_says_so():
 	agent.max_capacity = 12_000
 	with pytest.warns(CapacityExhausted):
 		assert agent.search(start, time_limit=20) is False
-	assert agent.capacity_exhausted and 6_000 < len(agent) <= 12_000          # grew 3000 -> 6000 -> 12000, then gave up
+	assert agent.capacity_exhausted and 6_000 < len(agent) <= 12_000 and agent.grown == 2      # grew 3000 -> 6000 -> 12000, then gave up
 	agent.max_capacity = 10_000_000
 	assert agent.search(start, time_limit=None, max_states=5_000) is False and not agent.capacity_exhausted   # a budget is not a full pool
 	assert len(agent) <= 5_000
@@ -117,4 +118,4 @@ def test_time_limited_search_grows_its_pool_or_says_so():
 	tree.max_capacity = 4000
 	with pytest.warns(CapacityExhausted):
 		assert tree.search(start, time_limit=20) is False
-	assert tree.capacity_exhausted and 2000 < len(tree) <= 4000
+	assert tree.capacity_exhausted and 2000 < len(tree) <= 4000 and tree.grown == 2

@@ -30,13 +30,13 @@ def _same_tree(arrs: dict, ref: MCTSOracle):
 	assert (arrs["P"][1:n + 1] == ref.P[1:n + 1]).all()
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f", "g", "h"])
 def test_reference_traces(golden, tag):
 	t = golden["mcts_trace"]
 	_, _, search_graph, max_states = (int(x) for x in t[f"{tag}_params"])
 	start = t[f"{tag}_start"]
 	net = PolicyStubNet() if f"{tag}_P" in t else StubNet()          # trace f: non-uniform priors (exactly 0, 1/8, 1/4)
-	agent = MCTS(net, float(t[f"{tag}_c"]), bool(search_graph), use_hipgraph=tag in ("b", "d"))
+	agent = MCTS(net, float(t[f"{tag}_c"]), bool(search_graph), use_hipgraph=tag in ("b", "d", "h"))
 	solved = agent.search(start, time_limit=None, max_states=max_states)
 	n = int(t[f"{tag}_n"])
 	assert solved == bool(t[f"{tag}_solved"]) and len(agent) == n
@@ -151,34 +151,223 @@ class ExactLogitNet:
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_priors_against_torch_softmax(dtype):
-	"""the backup kernel's own softmax (exp(x - max) / sum in float32 on the raw logits) replaces torch.softmax
-	(agents.py:551-552); the reference traces only pin it on logits whose softmax is exact.  On real logits:
-	  * torch_softmax=True  -> the stored priors ARE torch's softmax of the same logits, bit for bit;
-	  * default             -> within 4 float32 ulps of it (measured: the bound below), rows summing to 1 within 1e-6.
-	A last-bit difference in P can in principle flip an arg-max tie of U + Q between otherwise equal children; that is the
-	documented deviation of the default path ("parity unpinned" on non-dyadic logits)."""
+	"""The priors are softmax(logits) (agents.py:472, :551-552).  On real (non-dyadic) logits, three ways to get them:
+	  * priors="torch"   -> the stored priors ARE torch.softmax of the same logits on the device, bit for bit;
+	  * priors="kernel"  -> the backup kernel's own softmax (exp(x - max) / sum in float32 on the raw logits, the sum taken in
+	                        the order torch's kernel adds): the SAME bits as torch.softmax on this device (VERDICT r3 #6) --
+	                        asserted here on every stored row, and on a million random rows in the next test;
+	  * priors="reference" -> the reference's own computation: root by the device's softmax, every other node by the HOST's
+	                        (`p.cpu().softmax(dim=1)`, agents.py:551-552), bit for bit."""
 	net = ExactLogitNet(dtype)
 	starts = []
 	for i in range(3):
 		np.random.seed(500 + i)
 		starts.append(orc.scramble(6 + i, True)[0])
 	starts = np.array(starts)
-	worst = 0.0
-	for own in (True, False):
-		agent = MCTSBatch(net, 1.0, 3, capacity=1500, torch_softmax=own)
+	for priors in ("torch", "kernel", "reference"):
+		agent = MCTSBatch(net, 1.0, 3, capacity=1500, priors=priors)
 		agent.search(starts, max_states=1500, max_sims=100)
 		for tree in range(3):
 			t = agent.tree_arrays(tree)
 			n = t["n"]
 			assert n > 300
 			logits, v = net(cube.as_oh(t["states"][1:n + 1]))
-			want = logits.float().softmax(dim=1).double().cpu().numpy()
 			got = t["P"][1:n + 1]
 			assert (t["V"][1:n + 1] == v.float().double().reshape(-1).cpu().numpy()).all()
-			if own:
-				assert (got == want).all()
+			on_device = logits.float().softmax(dim=1).double().cpu().numpy()
+			if priors in ("torch", "kernel"):
+				assert (got == on_device).all(), (priors, np.abs(got - on_device).max())
 			else:
-				rel = np.abs(got - want) / want
-				worst = max(worst, float(rel.max()))
-				assert rel.max() <= 4 * 2.0 ** -23 and np.abs(got.sum(axis=1) - 1).max() < 1e-6
-	print(f"in-kernel softmax vs torch.softmax ({dtype}): max relative difference {worst:.3e} = {worst / 2.0 ** -23:.2f} ulp")
+				on_host = logits.cpu().softmax(dim=1).double().numpy()
+				assert (got[0] == on_device[0]).all()                            # the root: agents.py:472
+				assert (got[1:] == on_host[1:]).all()                            # everybody else: agents.py:551-552
+			assert np.abs(got.sum(axis=1) - 1).max() < 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_kernel_softmax_equals_torch_bitwise_on_random_logits(dtype):
+	"""The in-kernel softmax against torch.softmax on this device, bit for bit, on 12 x 87 000 random rows -- wide and narrow
+	ranges, ties, a few -inf -- driven through the engine's own entry (rk_mcts_backup_select_logits) on one-simulation trees."""
+	import ctypes as C
+	from librubiks_amd import _ffi
+	lib, st = _ffi.lib(), _ffi.stream_ptr
+	T = 87_000
+	h = C.c_void_p()
+	_ffi.check(lib.rk_mcts_create(C.byref(h), T, 13, 4))
+	np.random.seed(1)
+	start = orc.scramble(9, True)[0]
+	starts = np.ascontiguousarray(np.broadcast_to(start, (T, 20)))
+	_ffi.check(lib.rk_mcts_reset(h, starts.ctypes.data, None, 1.0, 100.0, st()))
+	g = torch.Generator(device="cuda").manual_seed(5)
+	scale = torch.tensor([0.01, 0.5, 3.0, 20.0], device="cuda")[torch.randint(0, 4, (12 * T, 1), device="cuda", generator=g)]
+	logits = (torch.randn((12 * T, 12), device="cuda", generator=g) * scale)
+	logits[::97, 3] = logits[::97, 7]                                         # ties
+	logits[::1013, 5] = -float("inf")
+	logits = logits.to(dtype)
+	values = torch.randn(12 * T, device="cuda", generator=g).to(dtype)
+	root_p = torch.full((T, 12), 1 / 12, device="cuda")
+	root_v = torch.zeros(T, device="cuda")
+	_ffi.check(lib.rk_mcts_set_root_pv(h, root_p.data_ptr(), root_v.data_ptr(), st()))
+	_ffi.check(lib.rk_mcts_expand(h, st()))
+	_ffi.check(lib.rk_mcts_backup_select_logits(h, logits.data_ptr(), 12, values.data_ptr(), 1, _ffi.OH_F32 if dtype == torch.float32 else _ffi.OH_BF16, st()))
+	want = logits.float().softmax(dim=1).double().cpu().numpy().reshape(T, 12, 12)
+	P = np.zeros((12, 12))
+	nb = np.zeros((1, 12), np.int64)
+	bad = 0
+	for t in range(0, T, 613):                                               # a sample of trees: all 12 new children each
+		_ffi.check(lib.rk_mcts_export(h, t, 1, 1, None, nb.ctypes.data, None, None, None, None, None, None, st()))
+		assert (nb[0] == np.arange(2, 14)).all()
+		_ffi.check(lib.rk_mcts_export(h, t, 2, 12, None, None, None, P.ctypes.data, None, None, None, None, st()))
+		bad += int((P != want[t]).sum())
+	assert bad == 0
+	_ffi.check(lib.rk_mcts_destroy(h))
+
+
+def test_default_priors():
+	"""VERDICT r3 #6: `MCTS(net, c, search_graph)` with default arguments computes P as agents.py:472 / :551-552 do."""
+	assert MCTS(StubNet(), 1.0, False).priors == "reference" and MCTS(StubNet(), 1.0, False, use_hipgraph=True).priors == "kernel"
+	assert MCTSBatch(StubNet(), 1.0, 2).priors == "kernel" and MCTSBatch(StubNet(), 1.0, 2, torch_softmax=True).priors == "torch"
+	net = ExactLogitNet()
+	np.random.seed(77)
+	start = orc.scramble(8, True)[0]
+	agent = MCTS(net, 1.0, False)
+	agent.search(start, None, 2000)
+	n = len(agent)
+	logits, v = net(cube.as_oh(agent.states[1:n + 1]))
+	assert (agent.P[1] == logits[:1].softmax(dim=1).double().cpu().numpy()[0]).all()
+	assert (agent.P[2:n + 1] == logits[1:].cpu().softmax(dim=1).double().numpy()).all()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_search_graph_on_the_device(use_graph):
+	"""agents.py:483-486 + :597-633 for a BATCH of trees (VERDICT r3 #4): graph completion and the breadth-first shortening run as
+	kernels (rk_mcts_search_graph); every solved tree's `neighbors` and action queue equal the oracle's MCTS(search_graph=True)
+	run alone -- the same path, not merely one of the same length --, unsolved trees are left as they are."""
+	# a strongly non-uniform (exact) policy and a large c drive the descents round in circles: the solution is then found at the
+	# end of a path that the graph shortcuts (seeds picked with the oracle: 1002 5 -> 3 moves, 1010 9 -> 5, 1032 9 -> 3, ...)
+	seeds, c = [1002, 1010, 1004, 1014, 1000, 1032, 1023, 1001, 1003, 1005], 50.0
+	T = len(seeds)
+	starts, budgets = [], []
+	for seed in seeds:
+		np.random.seed(seed)
+		starts.append(orc.scramble(3 + seed % 4, True)[0])
+		budgets.append(4000)
+	starts = np.array(starts)
+	budgets[4] = 40                                                         # one tree that cannot solve
+	batch = MCTSBatch(PolicyStubNet(), c, T, capacity=4000, search_graph=True)
+	solved = batch.search(starts, max_states=np.array(budgets), use_graph=use_graph, poll=16)
+	shorter = 0
+	for i in range(T):
+		ref = MCTSOracle(PolicyStubNet(), c, True)
+		assert ref.search(starts[i], budgets[i]) == bool(solved[i]), i
+		plain = MCTSOracle(PolicyStubNet(), c, False)
+		plain.search(starts[i], budgets[i])
+		a = batch.tree_arrays(i)
+		n = len(ref)
+		assert a["n"] == n and (a["neighbors"][1:n + 1] == ref.neighbors[1:n + 1]).all(), i
+		assert list(batch.action_queue_of(i)) == list(ref.action_queue), i
+		shorter += len(ref.action_queue) < len(plain.action_queue)
+		if solved[i]:
+			s = starts[i]
+			for act in batch.action_queue_of(i):
+				s = orc.rotate(s, act // 2, 1 - act % 2)
+			assert orc.is_solved(s)
+	assert solved.sum() >= 6 and not solved[4] and shorter >= 5             # the shortening did shorten something
+	# the single-tree agent goes through the same kernels
+	one = MCTS(PolicyStubNet(), c, True)
+	for i in (1, 5, 8):
+		ref = MCTSOracle(PolicyStubNet(), c, True)
+		assert one.search(starts[i], None, budgets[i]) == ref.search(starts[i], budgets[i])
+		assert list(one.action_queue) == list(ref.action_queue) and (one.neighbors[1:len(ref) + 1] == ref.neighbors[1:len(ref) + 1]).all()
+
+
+class _CaptureNet:
+	"""StubNet's numbers without host-side allocations inside a capture."""
+	def __init__(self):
+		self.sol = torch.from_numpy(orc.as_oh(orc.SOLVED)[0]).cuda()
+
+	def __call__(self, x):
+		return torch.zeros(len(x), 12, device="cuda"), -(20 - (x * self.sol).sum(dim=1))
+
+
+@pytest.mark.parametrize("captured_at", [0, 3])
+def test_a_step_captured_at_any_point_replays_correctly(captured_at):
+	"""ADVICE r3 (medium): a C-ABI caller captures ONE step -- expand, children one-hot, net, backup + select with expand-ahead
+	on -- into a hipGraph, straight after the reset or in the middle of a search, and replays it.  Whether the path's leaf still
+	needs expanding is decided on the device at every replay, so both graphs give the oracle's trees; round 3 took the
+	decision on the host at capture time and a graph captured at step 0 re-expanded leaves that were expanded ahead."""
+	import ctypes as C
+	from librubiks_amd import _ffi
+	lib, st = _ffi.lib(), _ffi.stream_ptr
+	T, sims, cap = 5, 60, 2000
+	starts = []
+	for i in range(T):
+		np.random.seed(900 + i)
+		starts.append(orc.scramble(7 + i, True)[0])
+	starts = np.array(starts)
+	h = C.c_void_p()
+	_ffi.check(lib.rk_mcts_create(C.byref(h), T, cap, 512))
+	_ffi.check(lib.rk_mcts_reset(h, starts.ctypes.data, None, 2.0, 100.0, st()))
+	net = _CaptureNet()
+	root_oh = torch.empty((T, 480), device="cuda")
+	_ffi.check(lib.rk_mcts_roots_oh(h, root_oh.data_ptr(), _ffi.OH_F32, st()))
+	p, v = net(root_oh)
+	p = p.softmax(dim=1).contiguous()
+	_ffi.check(lib.rk_mcts_set_root_pv(h, p.data_ptr(), v.contiguous().data_ptr(), st()))
+	_ffi.check(lib.rk_mcts_set_expand_ahead(h, -1))
+	oh = torch.empty((12 * T, 480), device="cuda")
+	keep = []
+
+	def step():
+		_ffi.check(lib.rk_mcts_expand(h, st()))
+		_ffi.check(lib.rk_mcts_children_oh(h, oh.data_ptr(), _ffi.OH_F32, st()))
+		logits, values = net(oh)
+		keep.append((logits, values))
+		_ffi.check(lib.rk_mcts_backup_select_logits(h, logits.data_ptr(), 12, values.data_ptr(), 1, _ffi.OH_F32, st()))
+
+	side = torch.cuda.Stream()
+	with torch.cuda.stream(side):
+		step() if captured_at else net(oh)                                  # (the allocator is warm either way)
+		for _ in range(max(0, captured_at - 1)):
+			step()
+		torch.cuda.synchronize()
+		graph = torch.cuda.CUDAGraph()
+		with torch.cuda.graph(graph, stream=side):
+			step()
+	for _ in range(sims - captured_at):
+		graph.replay()
+	_ffi.check(lib.rk_mcts_set_expand_ahead(h, 0))
+	step()                                                                  # completes the leaves expanded ahead
+	status = np.zeros((T, 6), np.int64)
+	_ffi.check(lib.rk_mcts_status(h, status.ctypes.data, st()))
+	assert not status[:, 5].any(), status
+	for t in range(T):
+		ref = MCTSOracle(StubNet(), 2.0, False)
+		ref_solved = ref.search(starts[t], cap, max_sims=sims + 1)
+		n = len(ref)
+		assert status[t, 2] == n and bool(status[t, 1]) == ref_solved and status[t, 3] == ref.sims, (t, status[t], n, ref.sims)
+		nb, N = np.zeros((n, 12), np.int64), np.zeros((n, 12), np.int64)
+		W = np.zeros((n, 12))
+		_ffi.check(lib.rk_mcts_export(h, t, 1, n, None, nb.ctypes.data, None, None, None, N.ctypes.data, W.ctypes.data, None, st()))
+		assert (nb == ref.neighbors[1:n + 1]).all() and (N == ref.N[1:n + 1]).all() and (W == ref.W[1:n + 1]).all(), t
+	_ffi.check(lib.rk_mcts_destroy(h))
+
+
+def test_a_backup_without_an_expansion_is_refused():
+	"""A step that leaves rk_mcts_expand out is only right while every backup expands ahead; used on a fresh engine it must stop
+	the trees with error 3 instead of backing up stale children."""
+	import ctypes as C
+	from librubiks_amd import _ffi
+	lib, st = _ffi.lib(), _ffi.stream_ptr
+	h = C.c_void_p()
+	_ffi.check(lib.rk_mcts_create(C.byref(h), 2, 500, 64))
+	np.random.seed(5)
+	starts = np.array([orc.scramble(6, True)[0] for _ in range(2)])
+	_ffi.check(lib.rk_mcts_reset(h, starts.ctypes.data, None, 1.0, 100.0, st()))
+	probs = torch.full((24, 12), 1 / 12, device="cuda")
+	values = torch.zeros(24, device="cuda")
+	_ffi.check(lib.rk_mcts_backup_select(h, probs.data_ptr(), values.data_ptr(), st()))
+	status = np.zeros((2, 6), np.int64)
+	_ffi.check(lib.rk_mcts_status(h, status.ctypes.data, st()))
+	assert (status[:, 5] == 3).all() and (status[:, 0] == 1).all() and (status[:, 2] == 1).all()
+	_ffi.check(lib.rk_mcts_destroy(h))

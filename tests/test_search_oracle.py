@@ -47,7 +47,7 @@ def test_astar_trace_a_matches_survey_hashes(golden):
 	assert hashlib.sha256(t["a_parents"].tobytes()).hexdigest() == "a6b721d892115c0198cc62e4e1d1ed58ede395ee6c7806a0eb20eed338c989a3"
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f", "g", "h"])
 def test_mcts_oracle_reproduces_reference_trace(golden, tag):
 	t = golden["mcts_trace"]
 	seed, depth, search_graph, max_states = (int(x) for x in t[f"{tag}_params"])
@@ -57,7 +57,7 @@ def test_mcts_oracle_reproduces_reference_trace(golden, tag):
 	agent = MCTSOracle(PolicyStubNet() if f"{tag}_P" in t else StubNet(), float(t[f"{tag}_c"]), bool(search_graph))
 	solved = agent.search(start, max_states)
 	n = len(agent)
-	if f"{tag}_P" in t:                      # trace f: non-uniform priors, exactly 0, 1/8 or 1/4
+	if f"{tag}_P" in t:                      # traces f, g, h: non-uniform priors, exactly 0, 1/8 or 1/4
 		assert (agent.P[1:n + 1] == t[f"{tag}_P"]).all() and len(np.unique(t[f"{tag}_P"])) == 3
 	assert solved == bool(t[f"{tag}_solved"]) and n == int(t[f"{tag}_n"]) and agent.sims == int(t[f"{tag}_sims"])
 	assert (agent.states[1:n + 1] == t[f"{tag}_states"]).all()
