@@ -210,7 +210,8 @@ int rk_astar_step_commit(rk_astar_t *h, const float *d_values, void *stream);
 int rk_astar_set_values_dtype(rk_astar_t *h, int dtype);
 int rk_astar_status(rk_astar_t *h, long long *h_status /* [8] */, void *stream);
 /* The same iteration as three calls for hosts that want to feed the net exactly the new states: rk_astar_expand
- * synchronises, h_info = {popped, new, won, solved_index, n_states}; rk_astar_new_states_oh writes the one-hot of the
+ * synchronises, h_info = {popped, new, won, solved_index, n_states} (popped == 0: the engine is done -- budget, nothing open --
+ * and nothing is pending: there is no iteration to commit); rk_astar_new_states_oh writes the one-hot of the
  * `new` states in index order; rk_astar_commit takes their values. */
 int rk_astar_expand(rk_astar_t *h, int n_expand, long long *h_info /* [5] */, void *stream);
 int rk_astar_new_states_oh(rk_astar_t *h, void *d_out, int out_dtype, void *stream);
@@ -306,6 +307,9 @@ int rk_astar_shard_flush(rk_astar_t *h, const void *d_recv, void *stream);
 int rk_astar_shard_clear_send(rk_astar_t *h, void *d_send, int records, int offers, void *stream);
 /* h_out = {parent rank, parent index, action} of node `index` on this rank (for the cross-rank path walk). */
 int rk_astar_shard_parent(rk_astar_t *h, long long index, long long *h_out, void *stream);
+/* Rows [first, first+count) of the parents' owner ranks (int64, HOST): with rk_astar_export's states / G / parents / actions
+ * the whole shard of this rank. */
+int rk_astar_shard_export_ranks(rk_astar_t *h, size_t first, size_t count, long long *h_parent_ranks, void *stream);
 
 /* ---- transport of the hash-sharded search over RCCL / xGMI, for callers without torch.distributed ----------------
  * No counterpart in the reference (single process); SURVEY.md 8(b) `rk_comm_*`.  One communicator per process (= per GPU,

@@ -96,6 +96,7 @@ SIGNATURES = {
 	"rk_astar_shard_flush": (_i, [_vp, _vp, _vp]),
 	"rk_astar_shard_clear_send": (_i, [_vp, _vp, _i, _i, _vp]),
 	"rk_astar_shard_parent": (_i, [_vp, C.c_longlong, _vp, _vp]),
+	"rk_astar_shard_export_ranks": (_i, [_vp, _sz, _sz, _vp, _vp]),
 	"rk_comm_unique_id": (_i, [_vp]),
 	"rk_comm_create": (_i, [C.POINTER(_vp), _vp, _i, _i]),
 	"rk_comm_destroy": (_i, [_vp]),

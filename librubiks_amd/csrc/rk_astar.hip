@@ -1506,6 +1506,12 @@ int rk_astar_expand(rk_astar_t *h, int n_expand, long long *h_info, void *stream
 	if (int e = read_ctr(h, c, st)) return e;            // the one synchronisation of the iteration (the kernels above leave NPOP alone)
 	h->last_n_new = c[C_NNEW];
 	h->last_n_before = c[C_NBEFORE];
+	if (c[C_NPOP] == 0) {
+		// the engine is done (budget, nothing open): the launches above were no-ops, but they drew their tickets.  Close the empty
+		// iteration here so that the caller has nothing to commit and the engine can go on later (rk_astar_set_budget after a
+		// growth, rk_astar_grow itself): no cost records, no push, no iteration counted, the counters of the launch sequence reset.
+		if (int e = rk_astar_step_commit(h, reinterpret_cast<const float *>(h->d.val1), stream)) return e;
+	}
 	h_info[0] = c[C_NPOP]; h_info[1] = c[C_NNEW]; h_info[2] = c[C_WON]; h_info[3] = c[C_SOLVED]; h_info[4] = c[C_NSTATES];
 	return RK_OK;
 }
@@ -1789,6 +1795,20 @@ int rk_astar_shard_parent(rk_astar_t *h, long long index, long long *h_out /* [3
 	RK_HIP(hipMemcpyAsync(&r, h->d.prank + index, 1, hipMemcpyDeviceToHost, st));
 	RK_HIP(hipStreamSynchronize(st));
 	h_out[0] = r; h_out[1] = p; h_out[2] = a;
+	return RK_OK;
+}
+
+/* Rows [first, first + count) of the parents' OWNER RANKS (the fourth node array of a sharded engine, beside rk_astar_export's
+ * states / G / parents / actions): what a cross-rank walk of the parent links, or a comparison of whole shards, needs. */
+int rk_astar_shard_export_ranks(rk_astar_t *h, size_t first, size_t count, long long *h_parent_ranks, void *stream)
+{
+	if (!h || !h_parent_ranks) return fail(RK_EINVAL, "rk_astar_shard_export_ranks: null argument");
+	if (first + count > h->cap + 1) return fail(RK_EINVAL, "rk_astar_shard_export_ranks: rows %zu..%zu outside the pool", first, first + count);
+	if (count == 0) return RK_OK;
+	std::vector<uint8_t> r(count);
+	RK_HIP(hipMemcpyAsync(r.data(), h->d.prank + first, count, hipMemcpyDeviceToHost, (hipStream_t)stream));
+	RK_HIP(hipStreamSynchronize((hipStream_t)stream));
+	for (size_t i = 0; i < count; i++) h_parent_ranks[i] = r[i];
 	return RK_OK;
 }
 
