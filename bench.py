@@ -148,7 +148,97 @@ def cpu_baseline(sample: int = 1_000_000, numpy_reps: int = 5, native_reps: int 
 	}
 
 
-PMC_FILE = os.path.join("profiles", "r03_expand12_pmc.json")
+
+def search_legs():
+	"""
+	BASELINE.json configs[2] and configs[3] on the driver's clock, run once behind the timed region on rank 0 of a
+	1-GPU run.  Random-init fc_small in bfloat16, first layer fused with its epilogue, BatchNorm folded (benchmarks/nets.py,
+	librubiks_amd/oh_linear.py); one-time costs (pools, GEMM selection, graph capture) stay outside the clocks.
+	  A*:   depth-14 scrambles, lambda 0.16, N = 1000, 150 000 states per game, 5 games after one warm-up game.
+	        astar_states_per_s / astar_ms_per_iteration: wall clock around the games (synchronised);
+	        astar_engine_us_per_iteration / astar_net_share: a second pass over the same games with HIP events between the
+	        three parts of every iteration (engine: expand + lookup + append + rows | net | engine: sort + push + bookkeeping) --
+	        engine = the two engine parts, net share = net part / whole iteration on the GPU's timeline.
+	  MCTS: 256 trees x 4096 simulations, depth-14 scrambles, c = 0.6, step replayed as a hipGraph.
+	        mcts_tree_sims_per_s / mcts_ms_per_step: wall clock around the search;
+	        mcts_select_us: mean HIP-event time of the backup + select (+ expand ahead) launch over a second, eager run of
+	        the same search (events cannot be recorded inside a replayed graph).
+	Returns a FLAT dict: the driver's parser keeps flat extra keys and drops nested ones.
+	"""
+	from benchmarks.nets import FcSmall
+	from librubiks_amd import cube
+	from librubiks_amd.solving.agents import AStar, MCTSBatch
+	net = FcSmall().cuda().eval().to(torch.bfloat16)
+	out = {}
+	# ---- configs[2]: A* ------------------------------------------------------------------------------------------
+	lam, N, depth, budget, games = 0.16, 1000, 14, 150_000, 5
+	agent = AStar(net, lam, N, fused_first_layer="folded")
+	np.random.seed(12345)
+	agent.search(cube.scramble(depth, True)[0], time_limit=None, max_states=40 * N)           # warm-up
+	starts = []
+	for g in range(games):
+		np.random.seed(g)
+		starts.append(cube.scramble(depth, True)[0])
+	tot_t = tot_states = tot_iter = solved = 0
+	for st in starts:
+		torch.cuda.synchronize()
+		t0 = time.perf_counter()
+		solved += bool(agent.search(st, time_limit=None, max_states=budget))
+		torch.cuda.synchronize()
+		tot_t += time.perf_counter() - t0
+		tot_states += len(agent)
+		tot_iter += agent.iterations
+	eng = netp = whole = 0.0
+	n_it = 0
+	for st in starts:
+		agent.profile_events = []
+		agent.search(st, time_limit=None, max_states=budget)
+		torch.cuda.synchronize()
+		for a, b, c, d in agent.profile_events:
+			eng += a.elapsed_time(b) + c.elapsed_time(d)
+			netp += b.elapsed_time(c)
+			whole += a.elapsed_time(d)
+		n_it += len(agent.profile_events)
+	agent.profile_events = None
+	out.update({
+		"astar_states_per_s": tot_states / tot_t, "astar_ms_per_iteration": tot_t / max(tot_iter, 1) * 1e3,
+		"astar_engine_us_per_iteration": eng / max(n_it, 1) * 1e3, "astar_net_share": netp / max(whole, 1e-12),
+		"astar_iterations": tot_iter, "astar_states": tot_states, "astar_games": games, "astar_solved": solved,
+		"astar_config": f"configs[2]: depth-{depth} scrambles, lambda={lam}, N={N}, {budget} states per game, fc_small bf16 random init, first layer fused + folded",
+	})
+	del agent
+	# ---- configs[3]: MCTS -----------------------------------------------------------------------------------------
+	T, sims, c = 256, 4096, 0.6
+	starts = []
+	for g in range(T):
+		np.random.seed(g)
+		starts.append(cube.scramble(depth, True)[0])
+	starts = np.array(starts)
+	cap = 12 * sims + 64
+	trees = MCTSBatch(net, c, T, capacity=cap, max_path=16384, fused_first_layer="folded")
+	trees.search(starts, max_states=cap, max_sims=16, use_graph=True, poll=8)                     # pools, GEMM selection, first capture
+	torch.cuda.synchronize()
+	t0 = time.perf_counter()
+	ok = trees.search(starts, max_states=cap, max_sims=sims, use_graph=True, poll=64)
+	torch.cuda.synchronize()
+	dt = time.perf_counter() - t0
+	status = trees.status
+	steps = trees.simulations
+	trees.profile_events = []
+	trees.search(starts, max_states=cap, max_sims=sims, use_graph=False, poll=64)
+	torch.cuda.synchronize()
+	sel = [a.elapsed_time(b) for a, b in trees.profile_events]
+	trees.profile_events = None
+	out.update({
+		"mcts_tree_sims_per_s": float(status[:, 3].sum()) / dt, "mcts_ms_per_step": dt / max(steps, 1) * 1e3,
+		"mcts_select_us": sum(sel) / max(len(sel), 1) * 1e3, "mcts_steps": steps, "mcts_tree_sims": int(status[:, 3].sum()),
+		"mcts_solved": int(ok.sum()),
+		"mcts_config": f"configs[3]: {T} trees x {sims} simulations, depth-{depth} scrambles, c={c}, fc_small bf16 random init, first layer fused + folded, step replayed as a hipGraph",
+	})
+	return out
+
+
+PMC_FILE = os.path.join("profiles", "r04_expand12_pmc.json")
 
 
 def pmc_traffic():
@@ -276,6 +366,15 @@ def main():
 	kernel_ms_4in = back_to_back(max(40, min(args.steps, 300)))
 	in_sets[0] = N_IN_SETS
 
+	# for the record (outside the timed region): the UNPACED ring form on this very box, same rotation -- a box on which the
+	# paced form's 2.10 ns/tile schedule does not hold shows up as a ratio near 1 instead of as an unexplained lower fraction
+	kernel_ms_ring = None
+	if PACED:
+		_ffi.check(_ffi.lib().rk_set_pacing(0))
+		back_to_back(8)
+		kernel_ms_ring = back_to_back(max(40, min(args.steps, 300)))
+		_ffi.check(_ffi.lib().rk_set_pacing(-1))
+
 	# per-launch distribution (outside the timed region): one event pair per launch, same rotation
 	per = []
 	evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(args.steps, 200))]
@@ -324,10 +423,20 @@ def main():
 			             "kernel_ms_back_to_back": kernel_ms,
 			             "per_launch_event_pairs_ms": {"min": per[0], "median": per[len(per) // 2], "mean": sum(per) / len(per)},
 			             "kernel_ms_4_input_sets": kernel_ms_4in, "frac_4_input_sets": BYTES_PER_PARENT * N_PARENTS / (kernel_ms_4in * 1e-3) / 1e9 / HBM_PEAK_GBS,
+			             "kernel_ms_ring_same_box": kernel_ms_ring,
+			             "frac_ring_same_box": (BYTES_PER_PARENT * N_PARENTS / (kernel_ms_ring * 1e-3) / 1e9 / HBM_PEAK_GBS) if kernel_ms_ring else None,
 			             "algorithmic_bytes_per_launch": BYTES_PER_PARENT * N_PARENTS,
 			             "algorithmic_read_bytes_per_launch": READ_BYTES_PER_PARENT * N_PARENTS,
 			             "cache_neutral": True},
 		}
+		if kernel_ms_ring:
+			# flat copies: the driver's parser keeps flat extra keys
+			line["frac_ring_same_box"] = line["roofline"]["frac_ring_same_box"]
+			line["paced_over_ring_same_box"] = kernel_ms_ring / kernel_ms
+		if world == 1 and not args.no_search_legs:
+			del ins, outs                                     # 1.6 GB back to the allocator before the pools of the search legs
+			torch.cuda.empty_cache()
+			line.update(search_legs())
 		if world == 1 and not args.no_cpu_baseline:
 			line["cpu_baseline"] = cpu_baseline()
 		print(json.dumps(line), flush=True)

@@ -22,7 +22,7 @@ bench)
 	step 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -- python3 bench.py --steps 64 --warmup 8 --no-cpu-baseline --no-search-legs > $O/pmc_w.log 2>&1
 	python benchmarks/pmc_summary.py --stats $O/prof_stats --fetch $O/pmc_f --write $O/pmc_w --kernel k_expand12p --commit "${RK_COMMIT:-unknown}" \
 		--command "python3 bench.py --steps 64 --warmup 8 --no-cpu-baseline --no-search-legs" --out-pmc $O/expand12_pmc.json --out-stats $O/expand12_kernel_stats.csv > $O/pmc_summary.log 2>&1; cut -c1-400 $O/pmc_summary.log
-	python benchmarks/search_legs_summary.py --stats $O/prof_stats --bench-log $O/bench_prof.log --out $O/search_legs.json > $O/search_legs.log 2>&1; cut -c1-600 $O/search_legs.log
+	python benchmarks/search_legs_summary.py --stats $O/prof_stats --bench-log $O/bench_prof.log --out $O/search_legs.json --out-stats $O/search_legs_kernel_stats.csv > $O/search_legs.log 2>&1; cut -c1-600 $O/search_legs.log
 	RK_BENCH_BACKEND=gloo step 300 python bench.py --gpus 2 --steps 50 --warmup 5 > $O/bench_2ranks_gloo.log 2>&1; tail -1 $O/bench_2ranks_gloo.log | cut -c1-200
 	;;
 kernels)

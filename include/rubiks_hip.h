@@ -62,6 +62,12 @@ const char *rk_last_error(void);
 /* Select `device` for the calling thread and check that it is a gfx950 part. */
 int         rk_init(int device);
 
+/* The large launches of the write-heavy kernels (fan-out, one-hot, 6x8x6 fan-out, multi_rotate) run in a PACED form: inputs read
+ * first, every tile's stores released on a fixed-rate schedule.  Results never depend on it.  mode 0 switches
+ * the form off for this process (the unpaced kernels run at every size), 1 on, -1 back to the environment's choice (RK_PACE,
+ * default on).  bench.py uses it to time both forms on the same box in one run (`frac_ring_same_box`). */
+int rk_set_pacing(int mode);
+
 /* Move tables, written to HOST memory.
  * RK_REPR_2024: uint8 (12,2,24) absolute table T[a][kind][v] = v + maps[dir][face][kind][v]
  *               (maps.py:107-145).   RK_REPR_686: uint8 (12,48) sticker-slot permutation,

@@ -28,6 +28,7 @@ SIGNATURES = {
 	"rk_version": (_i, []),
 	"rk_last_error": (C.c_char_p, []),
 	"rk_init": (_i, [_i]),
+	"rk_set_pacing": (_i, [_i]),
 	"rk_tables": (_i, [_i, _vp]),
 	"rk_solved": (_i, [_i, _vp]),
 	"rk_malloc": (_i, [C.POINTER(_vp), _sz]),

@@ -51,9 +51,17 @@ def build_tune(verbose: bool = False) -> str:
 	return os.path.abspath(TUNE_OUT)
 
 
+#: what the last build() did: "compiled" = sources that went through hipcc, "reused" = objects that were newer than their sources
+#: and every header, "linked" = whether the shared object was linked again (RK_BUILD_FORCE=1 or force=True compiles everything)
+LAST = {"compiled": [], "reused": [], "linked": False}
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+	force = force or os.environ.get("RK_BUILD_FORCE", "") not in ("", "0")
+	LAST.update(compiled=[], reused=[os.path.basename(s) for s in sources()], linked=False)
 	if not force and not stale():
 		return OUT
+	LAST["reused"] = []
 	objs = []
 	for src in sources():
 		obj = os.path.join(CSRC, os.path.basename(src)[:-4] + ".o")
@@ -64,11 +72,15 @@ def build(force: bool = False, verbose: bool = False) -> str:
 			if verbose:
 				print(" ".join(cmd))
 			subprocess.run(cmd, check=True)
+			LAST["compiled"].append(os.path.basename(src))
+		else:
+			LAST["reused"].append(os.path.basename(src))
 		objs.append(obj)
 	cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-rpath,/opt/rocm/lib", "-o", OUT] + objs
 	if verbose:
 		print(" ".join(cmd))
 	subprocess.run(cmd, check=True)
+	LAST["linked"] = True
 	return OUT
 
 

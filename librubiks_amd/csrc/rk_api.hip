@@ -166,6 +166,12 @@ int rk_multi_rotate(int repr, const int8_t *d_states, const uint8_t *d_actions, 
 	return RK_OK;
 }
 
+int rk_set_pacing(int mode)
+{
+	set_pace_override(mode);
+	return RK_OK;
+}
+
 int rk_multi_rotate_solved(int repr, const int8_t *d_states, const uint8_t *d_actions, int8_t *d_out, uint8_t *d_flags, long long *d_stats,
                            size_t n, void *stream)
 {

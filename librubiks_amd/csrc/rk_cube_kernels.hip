@@ -1427,6 +1427,15 @@ static unsigned long long *next_pace_cell()
 	return base + (size_t)(turn.fetch_add(1, std::memory_order_relaxed) % PACE_CELLS) * PACE_CELL_STRIDE;
 }
 
+// rk_set_pacing: -1 = what the environment says (RK_PACE, default on), 0 = the unpaced forms, 1 = the paced forms
+static std::atomic<int> g_pace_override{-1};
+void set_pace_override(int mode) { g_pace_override.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed); }
+static inline bool pace_on(const PaceConfig &pc)
+{
+	const int o = g_pace_override.load(std::memory_order_relaxed);
+	return o < 0 ? pc.on : o != 0;
+}
+
 static void launch_expand12_paced(const int8_t *parents, int8_t *children, uint8_t *solved, long long *stats, size_t n, const PaceConfig &pc,
                                   unsigned tau_ps, hipStream_t st)
 {
@@ -2088,7 +2097,7 @@ void launch_expand12(const int8_t *parents, int8_t *children, uint8_t *solved, l
 {
 	const size_t n_tiles = (n + EXP_ROUND - 1) / EXP_ROUND;
 	const PaceConfig &pc = pace_config();
-	if (pc.on && n_tiles >= pc.min_tiles) { launch_expand12_paced(parents, children, solved, stats, n, pc, pc.tau_ps, st); return; }
+	if (pace_on(pc) && n_tiles >= pc.min_tiles) { launch_expand12_paced(parents, children, solved, stats, n, pc, pc.tau_ps, st); return; }
 	const bool ring = n_tiles >= 3000 && n_tiles < 24000;
 	unsigned grid;
 	if (!ring) grid = grid_for(n_tiles, EXP_WAVES, 1u << 22);
@@ -2135,7 +2144,7 @@ void launch_multi_rotate(const int8_t *states, const uint8_t *actions, const uin
 	const size_t n_tiles = (n + ROW_TILE - 1) / ROW_TILE;
 	const unsigned grid = grid_for(n_tiles, ROW_WAVES, row_grid_cap());
 	const PaceConfig &pc = pace_config();
-	const bool paced = pc.on && tau_cfg > 0 && n_tiles >= 8192 && (size_t)grid * ROW_WAVES >= n_tiles;
+	const bool paced = pace_on(pc) && tau_cfg > 0 && n_tiles >= 8192 && (size_t)grid * ROW_WAVES >= n_tiles;
 	const unsigned tau = paced ? tau_cfg : 0u, nt = paced ? nt_cfg : 0u;
 	unsigned long long *const cell = paced ? next_pace_cell() : nullptr;
 	if (with_flags)
@@ -2173,7 +2182,7 @@ void launch_multi_is_solved(const int8_t *states, uint8_t *flags, long long *sta
 	const size_t n_tiles = (n + ROW_TILE - 1) / ROW_TILE;
 	const unsigned grid = grid_for(n_tiles, ROW_WAVES, row_grid_cap());
 	const PaceConfig &pc = pace_config();
-	const bool paced = pc.on && tau_cfg > 0 && n_tiles >= 8192 && (size_t)grid * ROW_WAVES >= n_tiles;
+	const bool paced = pace_on(pc) && tau_cfg > 0 && n_tiles >= 8192 && (size_t)grid * ROW_WAVES >= n_tiles;
 	hipLaunchKernelGGL(k_multi_is_solved, dim3(grid), dim3(ROW_WAVES * WAVE), 0, st, (const uint32_t *)states, flags, stats, n, n_tiles,
 	                   paced ? tau_cfg : 0u, pc.lead, paced ? next_pace_cell() : (unsigned long long *)nullptr);
 }
@@ -2225,7 +2234,7 @@ void launch_as_oh(const int8_t *states, void *out, int out_dtype, size_t n, hipS
 	// profiles/r03_oh_pace.json.  Unpaced, non-temporal stores lose to plain ones (0.72 / 0.70), and plain ones gain nothing from pacing.
 	const PaceConfig &pc = pace_config();
 	const size_t n_tiles = out_dtype == 0 ? (n + 7) / 8 : (n + 15) / 16;
-	const bool paced = pc.on && n_tiles >= 8192;
+	const bool paced = pace_on(pc) && n_tiles >= 8192;
 	const unsigned tau = paced ? pc.tau_ps * 15360u / 16128u : 0u;
 	const unsigned phase_tiles = (unsigned)(((size_t)pc.phase_tiles * EXP_ROUND) / (out_dtype == 0 ? 8 : 16));    // the fan-out's phase in states: 1 Mi
 	const unsigned grid = paced ? oh_paced_grid(n_tiles, pc.pull_wgs, phase_tiles) : grid_for(n_tiles, 1, 1u << 22);
@@ -2248,7 +2257,7 @@ void launch_rotate686(const int8_t *states, const uint8_t *actions, int8_t *out,
 		{
 			static const unsigned min_parents = env_u("RK_PACE686_MIN", PACE686_MIN_PARENTS);
 			const PaceConfig &pc = pace_config();
-			if (pc.on && n_in >= min_parents) {
+			if (pace_on(pc) && n_in >= min_parents) {
 				constexpr unsigned G = 8;
 				const size_t n_groups = (n_in + G - 1) / G;
 				const unsigned phase_groups = (unsigned)(((size_t)pc.phase_tiles * 4) / G);

@@ -395,6 +395,7 @@ class AStar(DeepAgent):
 		self.iterations = 0
 		self.capacity_exhausted = False
 		self.grown = 0                # times the pool grew in place during the last search
+		self.profile_events = None    # a list: every run-ahead iteration appends four HIP events (before expand, before the net, after it, after commit)
 		self.record_pops = False      # debugging aid: keep the popped indices of every iteration in self.pops
 		self.pops = []
 
@@ -432,10 +433,21 @@ class AStar(DeepAgent):
 
 	def _iteration(self, h, oh, code):
 		lib = _ffi.lib()
+		ev = self.profile_events           # measurement aid (bench.py): HIP events between the three parts of an iteration
+		if ev is not None:
+			marks = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+			marks[0].record()
 		_ffi.check(lib.rk_astar_step_expand(h, oh.data_ptr(), code, _ffi.stream_ptr()))
+		if ev is not None:
+			marks[1].record()
 		values = _values_for_engine(h, _sliced_value_forward(self._fs or self.net, oh))
 		self._keep = values                # the commit kernels read it after this call returns
+		if ev is not None:
+			marks[2].record()
 		_ffi.check(lib.rk_astar_step_commit(h, values.data_ptr(), _ffi.stream_ptr()))
+		if ev is not None:
+			marks[3].record()
+			ev.append(marks)
 
 	@no_grad
 	def search(self, state: np.ndarray, time_limit: float = None, max_states: int = None) -> bool:
@@ -666,6 +678,7 @@ class MCTSBatch(DeepAgent):
 		self.status = None
 		self.simulations = 0
 		self.grown = 0
+		self.profile_events = None        # a list: every eager simulation step appends a HIP event pair around its backup + select launch
 
 	@property
 	def torch_softmax(self) -> bool:
@@ -714,13 +727,20 @@ class MCTSBatch(DeepAgent):
 		else:
 			_ffi.check(lib.rk_mcts_children_oh(h, oh.data_ptr(), _OH_CODES[oh.dtype], _ffi.stream_ptr()))
 			p, v = self.net(oh)
+		ev = self.profile_events           # measurement aid (bench.py): a HIP event pair around the backup + select launch
 		if self.priors == "kernel" and isinstance(p, torch.Tensor) and p.is_cuda and p.dtype == v.dtype and p.dtype in (torch.float32, torch.bfloat16) \
 		   and p.dim() == 2 and p.stride(1) == 1 and p.stride(0) >= 12 and v.numel() == len(p) and v.reshape(len(p), -1).stride(0) >= 1:
 			# raw logits and values in the net's dtype (rows may be views into one tensor of merged heads): the softmax
 			# (agents.py:551) runs inside the backup kernel
 			self._keep = (p, v)        # the kernels read these after this call returns
+			if ev is not None:
+				pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+				pair[0].record()
 			_ffi.check(lib.rk_mcts_backup_select_logits(h, p.data_ptr(), p.stride(0), v.data_ptr(), v.reshape(len(p), -1).stride(0),
 			                                            _OH_CODES[p.dtype], _ffi.stream_ptr()))
+			if ev is not None:
+				pair[1].record()
+				ev.append(pair)
 			return
 		if self.priors == "reference":
 			# agents.py:551-552 to the letter: `p.cpu().softmax(dim=1)` -- the HOST's softmax of the logits

@@ -181,7 +181,8 @@ def test_priors_against_torch_softmax(dtype):
 				on_host = logits.cpu().softmax(dim=1).double().numpy()
 				assert (got[0] == on_device[0]).all()                            # the root: agents.py:472
 				assert (got[1:] == on_host[1:]).all()                            # everybody else: agents.py:551-552
-			assert np.abs(got.sum(axis=1) - 1).max() < 1e-6
+			# (a bfloat16 net's logits softmaxed on the host stay bfloat16 there, as `p.cpu().softmax(dim=1)` leaves them: rows sum to 1 within bf16)
+			assert np.abs(got.sum(axis=1) - 1).max() < (1e-6 if priors != "reference" or dtype == torch.float32 else 2e-2)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
