@@ -170,6 +170,16 @@ def search_legs():
 	from librubiks_amd.solving.agents import AStar, MCTSBatch
 	net = FcSmall().cuda().eval().to(torch.bfloat16)
 	out = {}
+	# what an event pair with NOTHING between its two records reads on this box: the part of every event-based figure below
+	# that is not kernel time (rocprofv3's kernel averages of the same legs do not contain it)
+	pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
+	torch.cuda.synchronize()
+	for a, b in pairs:
+		a.record()
+		b.record()
+	torch.cuda.synchronize()
+	empty_us = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2] * 1e3
+	out["event_pair_overhead_us"] = empty_us
 	# ---- configs[2]: A* ------------------------------------------------------------------------------------------
 	lam, N, depth, budget, games = 0.16, 1000, 14, 150_000, 5
 	agent = AStar(net, lam, N, fused_first_layer="folded")
@@ -203,6 +213,7 @@ def search_legs():
 	out.update({
 		"astar_states_per_s": tot_states / tot_t, "astar_ms_per_iteration": tot_t / max(tot_iter, 1) * 1e3,
 		"astar_engine_us_per_iteration": eng / max(n_it, 1) * 1e3, "astar_net_share": netp / max(whole, 1e-12),
+		"astar_engine_us_per_iteration_less_event_overhead": eng / max(n_it, 1) * 1e3 - 2 * empty_us,       # two event pairs per iteration
 		"astar_iterations": tot_iter, "astar_states": tot_states, "astar_games": games, "astar_solved": solved,
 		"astar_config": f"configs[2]: depth-{depth} scrambles, lambda={lam}, N={N}, {budget} states per game, fc_small bf16 random init, first layer fused + folded",
 	})
@@ -231,7 +242,8 @@ def search_legs():
 	trees.profile_events = None
 	out.update({
 		"mcts_tree_sims_per_s": float(status[:, 3].sum()) / dt, "mcts_ms_per_step": dt / max(steps, 1) * 1e3,
-		"mcts_select_us": sum(sel) / max(len(sel), 1) * 1e3, "mcts_steps": steps, "mcts_tree_sims": int(status[:, 3].sum()),
+		"mcts_select_us": sum(sel) / max(len(sel), 1) * 1e3, "mcts_select_us_less_event_overhead": sum(sel) / max(len(sel), 1) * 1e3 - empty_us,
+		"mcts_steps": steps, "mcts_tree_sims": int(status[:, 3].sum()),
 		"mcts_solved": int(ok.sum()),
 		"mcts_config": f"configs[3]: {T} trees x {sims} simulations, depth-{depth} scrambles, c={c}, fc_small bf16 random init, first layer fused + folded, step replayed as a hipGraph",
 	})

@@ -35,6 +35,12 @@ kernels)
 	done
 	python benchmarks/paced_pmc.py --summarise $O --out $O/paced_pmc.json > $O/paced_pmc_summary.log 2>&1; cut -c1-600 $O/paced_pmc_summary.log
 	;;
+rows)
+	step 300 python benchmarks/rows_fit.py > $O/rows_fit_events.json 2> $O/rows_fit.err; tail -3 $O/rows_fit_events.json | cut -c1-300
+	step 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_rows -- python3 benchmarks/rows_fit.py > $O/rows_fit_prof.log 2>&1
+	python benchmarks/kernel_trace_by_grid.py $O/prof_rows --segments --min-calls 100 --skip 10 > $O/rows_trace_runs.csv
+	python benchmarks/rows_fit.py --fit $O/rows_trace_runs.csv > $O/rows_fit_rocprof.json; cut -c1-400 $O/rows_fit_rocprof.json
+	;;
 streams)
 	step 400 python benchmarks/pace_streams.py > $O/pace_streams.json 2> $O/pace_streams.err; cut -c1-400 $O/pace_streams.json
 	;;

@@ -54,12 +54,16 @@ def main():
 		"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline",
 		"astar_iterations_in_process": iters, "astar_engine_us_per_iteration_rocprof": engine_us, "astar_kernels": astar,
 		"mcts_backup_select_launches": sel_calls, "mcts_select_us_rocprof": sel_us,
-		"bench_line": {k: line.get(k) for k in ("astar_engine_us_per_iteration", "astar_net_share", "astar_ms_per_iteration", "astar_states_per_s",
-		                                         "mcts_select_us", "mcts_ms_per_step", "mcts_tree_sims_per_s")} if line else None,
+		"bench_line": {k: line.get(k) for k in ("event_pair_overhead_us", "astar_engine_us_per_iteration", "astar_engine_us_per_iteration_less_event_overhead",
+		                                         "astar_net_share", "astar_ms_per_iteration", "astar_states_per_s", "mcts_select_us",
+		                                         "mcts_select_us_less_event_overhead", "mcts_ms_per_step", "mcts_tree_sims_per_s")} if line else None,
 	}
 	if line and line.get("astar_engine_us_per_iteration"):
 		rec["astar_engine_events_over_rocprof"] = line["astar_engine_us_per_iteration"] / max(engine_us, 1e-9)
 		rec["mcts_select_events_over_rocprof"] = line["mcts_select_us"] / max(sel_us, 1e-9)
+		if line.get("event_pair_overhead_us") is not None:
+			rec["astar_engine_events_less_overhead_over_rocprof"] = line["astar_engine_us_per_iteration_less_event_overhead"] / max(engine_us, 1e-9)
+			rec["mcts_select_events_less_overhead_over_rocprof"] = line["mcts_select_us_less_event_overhead"] / max(sel_us, 1e-9)
 		rec["reading"] = ("the event figures bracket whole calls (several kernels and the gaps between them, under rocprofv3's own per-launch overhead in this run); "
 		                  "the rocprof figures are kernel time only")
 	with open(a.out, "w") as f:

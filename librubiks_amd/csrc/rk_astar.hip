@@ -759,14 +759,21 @@ __device__ __forceinline__ void end_body(const AstarDev &d, int new_in_rec1, int
 	const int n_pop = s_ctr[C_NPOP];
 	if (!SHARDED && !s_ctr[C_WON]) {
 		for (int i = tid; i < n_pop; i += blockDim.x) {
+			// the parent's twelve shortcut flags arrive as three dwords in ONE round trip (as twelve byte loads, each behind a
+			// conditional store the compiler must not move it across, they were twelve dependent round trips of this kernel);
+			// only the LAST set flag matters: a later assignment to the same parent overwrites an earlier one
+			const uint32_t *f = reinterpret_cast<const uint32_t *>(d.shortcut + 12 * (size_t)i);
+			const uint32_t w0 = f[0], w1 = f[1], w2 = f[2];
 			const int32_t p = d.exp_idx[i];
-			for (int a = 0; a < 12; a++) {
+			int a = -1;
+			if (w2) a = 8 + ((31 - __clz((int)w2)) >> 3);
+			else if (w1) a = 4 + ((31 - __clz((int)w1)) >> 3);
+			else if (w0) a = (31 - __clz((int)w0)) >> 3;
+			if (a >= 0) {
 				const int c = 12 * i + a;
-				if (d.shortcut[c]) {
-					d.G[p] = d.val2[c];
-					d.pact[p] = (uint8_t)(a ^ 1);          // rev_action                                 cube.py:197-200
-					d.parents[p] = d.seen[c];
-				}
+				d.G[p] = d.val2[c];
+				d.pact[p] = (uint8_t)(a ^ 1);              // rev_action                                 cube.py:197-200
+				d.parents[p] = d.seen[c];
 			}
 		}
 	}
