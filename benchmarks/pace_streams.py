@@ -8,6 +8,8 @@ Cache), HIP events on each stream:
   pair        A on stream 1 and B on stream 2 at once, launch counts chosen so that both streams are busy about equally long;
               `makespan_over_sum` = time until both are done / (n_A x alone_A + n_B x alone_B): 1.0 = the pair costs exactly what
               the two cost one after the other (HBM-bound kernels cannot do better), above 1 = they disturb each other
+  RK_PACE_SERIAL=0    the same with the library's cross-stream turn-taking of paced launches switched off (what two paced launches
+              cost each other when they really overlap; the default makes a paced launch wait for the previous one on another stream)
   beside an exchange   the fan-out while another stream runs rk_comm_all_to_all (RCCL, world 1: the block is copied device to
               device) of configs[4]'s block size back to back
 
@@ -93,7 +95,8 @@ def main():
 			best = span if best is None else min(best, span)
 		return {"launches": [na, nb], "makespan_ms": best, "sum_alone_ms": na * ta + nb * tb, "makespan_over_sum": best / (na * ta + nb * tb)}
 
-	out = {"bench": "pace_streams", "commit": os.environ.get("RK_COMMIT", "")}
+	out = {"bench": "pace_streams", "commit": os.environ.get("RK_COMMIT", ""),
+	       "paced_launches_take_turns_across_streams": os.environ.get("RK_PACE_SERIAL", "1") != "0"}
 	t_fan, t_oh, t_686 = alone(fan), alone(onehot), alone(fan686)
 	out["alone_ms"] = {"fanout_1M": t_fan, "as_oh_bf16_1M": t_oh, "fanout686_200k": t_686}
 	out["alone_frac_of_8TBps"] = {"fanout_1M": 272e6 / (t_fan * 1e-3) / 8e12, "as_oh_bf16_1M": 980e6 / (t_oh * 1e-3) / 8e12,

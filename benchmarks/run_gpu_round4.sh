@@ -42,10 +42,18 @@ rows)
 	python benchmarks/rows_fit.py --fit $O/rows_trace_runs.csv > $O/rows_fit_rocprof.json; cut -c1-400 $O/rows_fit_rocprof.json
 	;;
 streams)
-	step 400 python benchmarks/pace_streams.py > $O/pace_streams.json 2> $O/pace_streams.err; cut -c1-400 $O/pace_streams.json
+	step 400 python benchmarks/pace_streams.py 2> $O/pace_streams.err | grep '^{' > $O/pace_streams.json; cut -c1-600 $O/pace_streams.json
+	RK_PACE_SERIAL=0 step 400 python benchmarks/pace_streams.py 2> $O/pace_streams_overlapping.err | grep '^{' > $O/pace_streams_overlapping.json; cut -c1-600 $O/pace_streams_overlapping.json
 	;;
 search)
 	step 500 python benchmarks/astar_small.py > $O/astar_small.json 2> $O/astar_small.err; cut -c1-300 $O/astar_small.json
+	;;
+astar)
+	for n in 1 10 100 700; do
+		step 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/n$n -- python3 benchmarks/astar_floor.py --n $n > $O/n$n.log 2>&1
+	done
+	python benchmarks/astar_floor.py --table $O --out $O/astar_floor.json | cut -c1-1500
+	for n in 10 100 700; do python benchmarks/astar_floor.py --n $n; done > $O/astar_floor_unprofiled.json 2>/dev/null; cat $O/astar_floor_unprofiled.json
 	;;
 esac
 find $O -name "*kernel_trace.csv" -size +3M -delete; find $O -name "*counter_collection.csv" -size +8M -delete

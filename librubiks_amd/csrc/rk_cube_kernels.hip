@@ -14,6 +14,7 @@
 // and reads mixed into it cost 2.5 x their share.  Only WHEN a finished tile is stored depends on any of that (RK_PACE=0: never).
 #include <atomic>
 #include <cstdlib>
+#include <mutex>
 
 #include "rk_device.h"
 #include "rk_kernels.h"
@@ -1436,9 +1437,57 @@ static inline bool pace_on(const PaceConfig &pc)
 	return o < 0 ? pc.on : o != 0;
 }
 
+// Paced launches take turns.  A paced kernel schedules its stores for the WHOLE memory system (7.7 TB/s of 8); two of them in
+// flight on two streams oversubscribe it and both fall off their schedules -- measured (profiles/r04_pace_streams.json, makespan
+// of the pair over the two run one after the other): fan-out beside as_oh 1.05, beside the 6x8x6 fan-out 1.08, two fan-outs
+// 1.23 -- worse than the unpaced kernels.  HBM-bound launches gain nothing from overlapping each other, so the library makes
+// them wait for each other across streams: a paced launch on another stream than the previous paced launch first waits (on the
+// device: hipStreamWaitEvent) for that one's end.  Everything else on the streams overlaps as before.  Not while a stream is being
+// captured into a hipGraph (an event from outside the capture cannot be waited for inside it); RK_PACE_SERIAL=0 switches it off.
+struct PacedTurn {
+	struct Gate { std::mutex mu; hipEvent_t ev = nullptr; hipStream_t last = nullptr; bool valid = false; };
+	static Gate &gate()
+	{
+		static Gate gates[32];
+		int dev = 0;
+		(void)hipGetDevice(&dev);
+		return gates[dev & 31];
+	}
+	static bool enabled()
+	{
+		static const bool on = [] { const char *e = std::getenv("RK_PACE_SERIAL"); return e == nullptr || std::atoi(e) != 0; }();
+		return on;
+	}
+	static bool capturing(hipStream_t st)
+	{
+		if (st == nullptr) return false;
+		hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+		if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); return false; }
+		return cap != hipStreamCaptureStatusNone;
+	}
+	hipStream_t st;
+	bool on;
+	PacedTurn(hipStream_t s, bool paced) : st(s), on(paced && enabled() && !capturing(s))
+	{
+		if (!on) return;
+		Gate &g = gate();
+		std::lock_guard<std::mutex> lk(g.mu);
+		if (g.ev == nullptr && hipEventCreateWithFlags(&g.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); g.ev = nullptr; on = false; return; }
+		if (g.valid && g.last != st) (void)hipStreamWaitEvent(st, g.ev, 0);
+	}
+	~PacedTurn()
+	{
+		if (!on) return;
+		Gate &g = gate();
+		std::lock_guard<std::mutex> lk(g.mu);
+		if (hipEventRecord(g.ev, st) == hipSuccess) { g.last = st; g.valid = true; } else (void)hipGetLastError();
+	}
+};
+
 static void launch_expand12_paced(const int8_t *parents, int8_t *children, uint8_t *solved, long long *stats, size_t n, const PaceConfig &pc,
                                   unsigned tau_ps, hipStream_t st)
 {
+	PacedTurn turn(st, true);
 	const size_t n_tiles = (n + EXP_ROUND - 1) / EXP_ROUND;
 	const size_t n_phases = (n_tiles + pc.phase_tiles - 1) / pc.phase_tiles;
 	const size_t last_tiles = n_tiles - (n_phases - 1) * pc.phase_tiles;
@@ -2147,6 +2196,7 @@ void launch_multi_rotate(const int8_t *states, const uint8_t *actions, const uin
 	const bool paced = pace_on(pc) && tau_cfg > 0 && n_tiles >= 8192 && (size_t)grid * ROW_WAVES >= n_tiles;
 	const unsigned tau = paced ? tau_cfg : 0u, nt = paced ? nt_cfg : 0u;
 	unsigned long long *const cell = paced ? next_pace_cell() : nullptr;
+	PacedTurn turn(st, paced);
 	if (with_flags)
 		hipLaunchKernelGGL((k_multi_rotate<false, true>), dim3(grid), dim3(ROW_WAVES * WAVE), 0, st, (const uint32_t *)states, actions,
 		                   (const uint8_t *)nullptr, (uint32_t *)out, n, n_tiles, tau, pc.lead, nt, cell, flags, stats);
@@ -2183,6 +2233,7 @@ void launch_multi_is_solved(const int8_t *states, uint8_t *flags, long long *sta
 	const unsigned grid = grid_for(n_tiles, ROW_WAVES, row_grid_cap());
 	const PaceConfig &pc = pace_config();
 	const bool paced = pace_on(pc) && tau_cfg > 0 && n_tiles >= 8192 && (size_t)grid * ROW_WAVES >= n_tiles;
+	PacedTurn turn(st, paced);
 	hipLaunchKernelGGL(k_multi_is_solved, dim3(grid), dim3(ROW_WAVES * WAVE), 0, st, (const uint32_t *)states, flags, stats, n, n_tiles,
 	                   paced ? tau_cfg : 0u, pc.lead, paced ? next_pace_cell() : (unsigned long long *)nullptr);
 }
@@ -2238,6 +2289,7 @@ void launch_as_oh(const int8_t *states, void *out, int out_dtype, size_t n, hipS
 	const unsigned tau = paced ? pc.tau_ps * 15360u / 16128u : 0u;
 	const unsigned phase_tiles = (unsigned)(((size_t)pc.phase_tiles * EXP_ROUND) / (out_dtype == 0 ? 8 : 16));    // the fan-out's phase in states: 1 Mi
 	const unsigned grid = paced ? oh_paced_grid(n_tiles, pc.pull_wgs, phase_tiles) : grid_for(n_tiles, 1, 1u << 22);
+	PacedTurn turn(st, paced);
 	#define RK_OH(T, EB, TL) do { \
 		if (paced) hipLaunchKernelGGL((k_as_oh<T, EB, TL, true>), dim3(grid), dim3(256), 0, st, (const uint32_t *)states, (u32x4 *)out, n, n_tiles, tau, pc.lead, pc.pull_wgs, phase_tiles, next_pace_cell()); \
 		else hipLaunchKernelGGL((k_as_oh<T, EB, TL, false>), dim3(grid), dim3(256), 0, st, (const uint32_t *)states, (u32x4 *)out, n, n_tiles, 0u, 0u, 0u, 0u, (unsigned long long *)nullptr); } while (0)
@@ -2264,6 +2316,7 @@ void launch_rotate686(const int8_t *states, const uint8_t *actions, int8_t *out,
 				const unsigned tau = (unsigned)((unsigned long long)pc.tau_ps * (G * 12 * S686_BYTES + G * 12) / 16128u);
 				const size_t n_phases = (n_groups + phase_groups - 1) / phase_groups;
 				const unsigned grid = (unsigned)((n_phases - 1) * (size_t)(pc.pull_wgs + phase_groups) + pc.pull_wgs + (n_groups - (n_phases - 1) * phase_groups));
+				PacedTurn turn(st, true);
 				if (flags != nullptr || stats != nullptr)
 					hipLaunchKernelGGL((k_fanout686p<true, G>), dim3(grid), dim3(256), 0, st, (const uint16_t *)states, (u32x4 *)out, n_in, flags, stats,
 					                   pc.pull_wgs, phase_groups, tau, pc.lead, next_pace_cell());
