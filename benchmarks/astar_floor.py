@@ -44,7 +44,7 @@ def run(n):
 
 def table(root, out):
 	rec = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 benchmarks/astar_floor.py --n N  (one process per N)", "N": {}}
-	for d in sorted(glob.glob(os.path.join(root, "n*")), key=lambda p: int(os.path.basename(p)[1:])):
+	for d in sorted((p for p in glob.glob(os.path.join(root, "n*")) if os.path.isdir(p)), key=lambda p: int(os.path.basename(p)[1:])):
 		n = int(os.path.basename(d)[1:])
 		hits = sorted(glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True))
 		if not hits:
