@@ -62,13 +62,22 @@ class Agent:
 
 def _net_signature(net):
 	"""Changes whenever the net is swapped or its parameters / buffers are modified in place (optimizer steps,
-	load_state_dict, BatchNorm statistics): module identity + training flag + the tensors' storage and version counters."""
+	load_state_dict, BatchNorm statistics): module identity + training flag + the tensors' storage and version counters.
+	Writes through `.data` (`p.data.add_(...)`, the idiom of hand-written update loops) do not bump a tensor's version counter, so
+	the signature also carries a checksum of the first floating-point parameter -- the layer the fused form copies -- read at the
+	start of a search (one small reduction and one device-to-host wait per search); an update that leaves that one tensor's
+	sum unchanged bit for bit and bypasses the version counters of all others is the remaining blind spot."""
 	sig = [id(net), bool(getattr(net, "training", False))]
+	first = None
 	for get in ("parameters", "buffers"):
 		it = getattr(net, get, None)
 		if callable(it):
 			for t in it():
 				sig.append((t.data_ptr(), t._version))
+				if first is None and t.is_floating_point():
+					first = t
+	if first is not None:
+		sig.append(float(first.detach().double().sum()))
 	return tuple(sig)
 
 

@@ -272,6 +272,15 @@ def test_fused_copy_follows_the_net(mode):
 	fresh.search(start, None, 8_000)
 	assert same_search(a, fresh)
 	assert len(a) != len(before[0]) - 1 or not (a.states == before[0]).all() or not (a.G == before[1]).all()      # the new weights do search differently
+	# an update through `.data` does not bump the tensors' version counters; the checksum of the first layer catches it
+	again = a._fs
+	first_layer = next(net.parameters())
+	first_layer.data.mul_(1.5)
+	a.search(start, None, 8_000)
+	assert a._fs is not again
+	fresh = AStar(net, 0.2, 50, fused_first_layer=mode)
+	fresh.search(start, None, 8_000)
+	assert same_search(a, fresh)
 	net2 = FcSmall(seed=9).cuda().eval()                           # the net is swapped (train.py:214: agent.net = net)
 	a.net = net2
 	a.search(start, None, 8_000)
