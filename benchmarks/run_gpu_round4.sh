@@ -47,6 +47,7 @@ streams)
 	;;
 search)
 	step 500 python benchmarks/astar_small.py > $O/astar_small.json 2> $O/astar_small.err; cut -c1-300 $O/astar_small.json
+	step 300 python benchmarks/grow_cost.py 2> $O/grow_cost.err | grep '^{' > $O/grow_cost.json; cut -c1-300 $O/grow_cost.json
 	;;
 astar)
 	for n in 1 10 100 700; do
