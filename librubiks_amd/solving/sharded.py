@@ -350,6 +350,14 @@ class ShardedAStar(DeepAgent):
 			                                      pact[1:].ctypes.data, _ffi.stream_ptr()))
 		return states, G, parents, pact
 
+	def local_parent_ranks(self) -> np.ndarray:
+		"""Owner rank of every local node's parent, rows 1..n (row 0 unused): with `local_arrays` the whole shard."""
+		n = self._n
+		out = np.zeros(n + 1, np.int64)
+		if n:
+			_ffi.check(_ffi.lib().rk_astar_shard_export_ranks(self._h, 1, n, out[1:].ctypes.data, _ffi.stream_ptr()))
+		return out
+
 	def __len__(self):
 		return self._n
 
