@@ -752,9 +752,29 @@ class MCTSBatch(DeepAgent):
 				ev.append(pair)
 			return
 		if self.priors == "reference":
-			# agents.py:551-552 to the letter: `p.cpu().softmax(dim=1)` -- the HOST's softmax of the logits
+			# agents.py:551-552 to the letter: `p.cpu().softmax(dim=1)` -- the HOST's softmax of the logits, the same CPU kernel on
+			# the same numbers; only the plumbing differs: the logits travel through page-locked buffers, and the 144 numbers are
+			# softmaxed by ONE thread.  torch forks its whole intra-op pool even for twelve rows, and a pool of 128 threads spinning
+			# after every simulation on a host whose CPU share is a fraction of that starves the launching thread: 3.3 ms per
+			# simulation instead of 0.25 (profiles/r04_mcts_priors_cost.json).  Rows are independent: the bits do not depend on it.
 			v = v.detach().to(device=gpu, dtype=torch.float32).reshape(-1).contiguous()
-			p = p.detach().cpu().softmax(dim=1).to(torch.float32).contiguous().to(gpu)
+			buf = getattr(self, "_ref_buf", None)
+			if buf is None or buf[0].shape != p.shape or buf[0].dtype != p.dtype:
+				buf = self._ref_buf = (torch.empty(p.shape, dtype=p.dtype).pin_memory(), torch.empty(p.shape, dtype=torch.float32).pin_memory(),
+				                       torch.empty(p.shape, dtype=torch.float32, device=gpu))
+			h_in, h_out, d_out = buf
+			h_in.copy_(p.detach(), non_blocking=True)
+			torch.cuda.current_stream().synchronize()                    # the one device-to-host wait of this mode
+			threads = torch.get_num_threads()
+			if threads != 1:
+				torch.set_num_threads(1)
+			try:
+				h_out.copy_(h_in.softmax(dim=1))
+			finally:
+				if threads != 1:
+					torch.set_num_threads(threads)
+			d_out.copy_(h_out, non_blocking=True)
+			p = d_out
 		else:
 			p, v = _policy_value_f32((p, v))
 		self._keep = (p, v)
