@@ -125,6 +125,20 @@ class DeepAgent(Agent):
 		return cls(_load_net(loc, use_best, loader))
 
 
+def _host_softmax(logits_cpu: torch.Tensor) -> torch.Tensor:
+	"""`logits.softmax(dim=1)` of a small CPU tensor on ONE intra-op thread (same kernel, same bits: rows are independent).  torch
+	forks its whole thread pool even for twelve rows; on a host whose CPU share is a fraction of its thread count the pool's threads
+	spin after every call and starve the thread that launches GPU work (measured: 3.3 ms per MCTS simulation instead of 0.29)."""
+	threads = torch.get_num_threads()
+	if threads != 1:
+		torch.set_num_threads(1)
+	try:
+		return logits_cpu.softmax(dim=1)
+	finally:
+		if threads != 1:
+			torch.set_num_threads(threads)
+
+
 class RandomSearch(Agent):
 	"""Random walk (agents.py:82-89)."""
 	def _step(self, state):
@@ -181,7 +195,7 @@ class PolicySearch(DeepAgent):
 
 	def _step(self, state):
 		logits = self.net(cube.as_oh(state), value=False)
-		policy = torch.nn.functional.softmax(logits.float().cpu(), dim=1).numpy().squeeze()
+		policy = _host_softmax(logits.float().cpu()).numpy().squeeze()
 		action = int(np.random.choice(cube.action_dim, p=policy)) if self.sample_policy else int(policy.argmax())
 		state = cube.rotate(state, *cube.action_space[action])
 		return action, state, cube.is_solved(state)
@@ -765,14 +779,7 @@ class MCTSBatch(DeepAgent):
 			h_in, h_out, d_out = buf
 			h_in.copy_(p.detach(), non_blocking=True)
 			torch.cuda.current_stream().synchronize()                    # the one device-to-host wait of this mode
-			threads = torch.get_num_threads()
-			if threads != 1:
-				torch.set_num_threads(1)
-			try:
-				h_out.copy_(h_in.softmax(dim=1))
-			finally:
-				if threads != 1:
-					torch.set_num_threads(threads)
+			h_out.copy_(_host_softmax(h_in))
 			d_out.copy_(h_out, non_blocking=True)
 			p = d_out
 		else:
