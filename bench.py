@@ -448,9 +448,15 @@ def main():
 		if world == 1 and not args.no_search_legs:
 			del ins, outs                                     # 1.6 GB back to the allocator before the pools of the search legs
 			torch.cuda.empty_cache()
-			line.update(search_legs())
+			try:
+				line.update(search_legs())
+			except Exception as e:                            # the headline line must not be lost to a leg: say what failed and go on
+				line["search_legs_error"] = f"{type(e).__name__}: {e}"[:400]
 		if world == 1 and not args.no_cpu_baseline:
-			line["cpu_baseline"] = cpu_baseline()
+			try:
+				line["cpu_baseline"] = cpu_baseline()
+			except Exception as e:
+				line["cpu_baseline"] = {"value": None, "unit": "expansions/s", "cores": 0, "kind": "port", "sample": "failed", "error": f"{type(e).__name__}: {e}"[:400]}
 		print(json.dumps(line), flush=True)
 	if dist is not None:
 		dist.barrier()

@@ -984,7 +984,7 @@ class MCTS(DeepAgent):
 	def search(self, state: np.ndarray, time_limit: float = None, max_states: int = None) -> bool:
 		time_limit, max_states = self.reset(time_limit, max_states)
 		self.capacity_exhausted = False
-		cap = int(min(max_states, self.capacity or self.default_capacity))
+		cap = max(int(min(max_states, self.capacity or self.default_capacity)), 13)      # a pool holds at least the root and its 12 children
 		b = self._batch
 		if b is None or b.capacity < cap or b.c != float(self.c) or b.priors != self.priors or b.search_graph != bool(self.search_graph) \
 		   or b.max_capacity != self.max_capacity:
