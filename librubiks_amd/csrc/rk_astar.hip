@@ -1168,6 +1168,7 @@ struct rk_astar {
 	bool ready = false, pending = false;
 	bool budget_explicit = false; // rk_astar_set_budget was called since the last reset
 	int last_n_new = 0, last_n_before = 0;    // sizes reported by the last rk_astar_expand
+	int32_t *ctr_host = nullptr;  // page-locked landing place of the counter block: a status poll is one direct copy, no staging
 	std::vector<void *> allocs;
 };
 
@@ -1190,8 +1191,10 @@ constexpr int WALK_MAX = 1 << 16;
 
 int read_ctr(rk_astar *h, int32_t *out, hipStream_t st)
 {
-	RK_HIP(hipMemcpyAsync(out, h->d.ctr, C_COUNT * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+	int32_t *dst = h->ctr_host != nullptr ? h->ctr_host : out;      // (pageable memory costs a staged copy per poll)
+	RK_HIP(hipMemcpyAsync(dst, h->d.ctr, C_COUNT * sizeof(int32_t), hipMemcpyDeviceToHost, st));
 	RK_HIP(hipStreamSynchronize(st));
+	if (dst != out) memcpy(out, dst, C_COUNT * sizeof(int32_t));
 	return RK_OK;
 }
 
@@ -1295,6 +1298,7 @@ static int astar_create_impl(rk_astar_t **out, size_t capacity, int max_expansio
 	if (!e) e = dev_alloc(h, &h->root_dev, 8);
 	if (!e) e = dev_alloc(h, &h->walk, WALK_MAX + 8);
 	if (!e) e = dev_alloc(h, &h->decision, D_COUNT);
+	if (!e && hipHostMalloc((void **)&h->ctr_host, C_COUNT * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h->ctr_host = nullptr; }
 	if (!e) {
 		hipError_t he = hipMemset(d.chain0, 0, n_scan_blocks * sizeof(unsigned long long));
 		if (he == hipSuccess) he = hipMemset(d.chain1, 0, n_scan_blocks * world * sizeof(unsigned long long));
@@ -1320,6 +1324,7 @@ int rk_astar_destroy(rk_astar_t *h)
 {
 	if (!h) return RK_OK;
 	for (void *p : h->allocs) (void)hipFree(p);
+	if (h->ctr_host != nullptr) (void)hipHostFree(h->ctr_host);
 	delete h;
 	return RK_OK;
 }

@@ -647,6 +647,7 @@ struct rk_mcts {
 	bool ready = false;
 	int ahead_limit = 0;          // rk_mcts_set_expand_ahead: 0 off, < 0 always, > 0 while the simulation number is below it
 	bool ahead = false;           // the last backup + select launch already expanded the leaves it found
+	int32_t *tree_host = nullptr; // page-locked landing place of the per-tree records: a status poll is one direct copy, no staging
 	BfsDev bfs{};                 // scratch of rk_mcts_search_graph, allocated at its first call (and again after a growth)
 	std::vector<void *> bfs_allocs;
 	bool bfs_valid = false;       // rk_mcts_search_graph has run since the last reset / growth
@@ -717,6 +718,7 @@ int rk_mcts_create(rk_mcts_t **out, int n_trees, size_t capacity_per_tree, size_
 	#undef A
 	if (!e) e = mcts_alloc(h, &h->starts_dev, T * 5);
 	if (!e) e = mcts_alloc(h, &h->max_states_dev, T);
+	if (!e && hipHostMalloc((void **)&h->tree_host, T * TR_INTS * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h->tree_host = nullptr; }
 	if (e) { rk_mcts_destroy(h); return e; }
 	*out = h;
 	return RK_OK;
@@ -727,6 +729,7 @@ int rk_mcts_destroy(rk_mcts_t *h)
 	if (!h) return RK_OK;
 	for (void *p : h->allocs) (void)hipFree(p);
 	for (void *p : h->bfs_allocs) (void)hipFree(p);
+	if (h->tree_host != nullptr) (void)hipHostFree(h->tree_host);
 	delete h;
 	return RK_OK;
 }
@@ -985,11 +988,13 @@ int rk_mcts_status(rk_mcts_t *h, long long *h_status, void *stream)
 	hipStream_t st = (hipStream_t)stream;
 	const MctsDev &d = h->d;
 	const size_t T = (size_t)d.T;
-	std::vector<int32_t> rec(T * TR_INTS);
-	RK_HIP(hipMemcpyAsync(rec.data(), d.tree, T * TR_INTS * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+	std::vector<int32_t> pageable;
+	int32_t *rec = h->tree_host;
+	if (rec == nullptr) { pageable.resize(T * TR_INTS); rec = pageable.data(); }
+	RK_HIP(hipMemcpyAsync(rec, d.tree, T * TR_INTS * sizeof(int32_t), hipMemcpyDeviceToHost, st));
 	RK_HIP(hipStreamSynchronize(st));
 	for (size_t t = 0; t < T; t++) {
-		const int32_t *tr = rec.data() + t * TR_INTS;
+		const int32_t *tr = rec + t * TR_INTS;
 		long long *r = h_status + 6 * t;
 		r[0] = flags_done(tr[TR_FLAGS]); r[1] = flags_solved(tr[TR_FLAGS]); r[2] = tr[TR_NSTATES]; r[3] = tr[TR_SIMS]; r[4] = tr[TR_PLEN];
 		r[5] = flags_error(tr[TR_FLAGS]);
