@@ -79,6 +79,24 @@ class StubNet:
 		return out if len(out) > 1 else out[0]
 
 
+class NoisyStubNet(StubNet):
+	"""The twin of oracle.search_oracle.NoisyStubNet for the reference's torch tensors: the stub's value plus exact integer noise
+	((one-hot . w) mod 7) - 3 with w = RandomState(seed).randint(0, 50, 480).  It misleads the search, so that states are rediscovered
+	over shorter ways: BOTH relaxation cases of agents.py:333-367 really happen (with the plain stub they almost never do)."""
+	def __init__(self, seed: int = 0):
+		super().__init__()
+		self.w = torch.from_numpy(np.random.RandomState(seed).randint(0, 50, 480).astype(np.float32))
+
+	def __call__(self, x, policy=True, value=True):
+		out = []
+		if policy:
+			out.append(torch.zeros(len(x), 12))
+		if value:
+			base = -(20 - (x * self.solved_oh).sum(dim=1, keepdim=True))
+			out.append(base + torch.remainder((x * self.w).sum(dim=1, keepdim=True), 7.0) - 3.0)
+		return out if len(out) > 1 else out[0]
+
+
 def tables():
 	with open(os.path.join(REF, "frontend", "src", "assets", "maps.json")) as f:
 		front = json.load(f)
@@ -195,11 +213,24 @@ def astar_traces():
 		"b": dict(seed=11, depth=8, lambda_=0.2, expansions=64, max_states=3_000),   # runs out of budget
 		"c": dict(seed=3, depth=5, lambda_=1.0, expansions=1, max_states=50_000),
 		"d": dict(seed=19, depth=7, lambda_=0.1, expansions=300, max_states=60_000),
+		# a misleading heuristic (NoisyStubNet): states are rediscovered over shorter ways, both relaxation cases happen, several
+		# shortcuts hit one parent in one batch (the last assignment must stay).  The counts are recorded with the trace.
+		"e": dict(seed=11, depth=14, lambda_=0.05, expansions=50, max_states=60_000, net="noisy"),
+		"f": dict(seed=12, depth=16, lambda_=0.02, expansions=200, max_states=40_000, net="noisy"),
 	}
 	for tag, c in cases.items():
 		np.random.seed(c["seed"])
 		state, faces, dirs = cube.scramble(c["depth"], True)
-		agent = agents.AStar(StubNet(), lambda_=c["lambda_"], expansions=c["expansions"])
+		agent = agents.AStar(NoisyStubNet() if c.get("net") == "noisy" else StubNet(), lambda_=c["lambda_"], expansions=c["expansions"])
+		relax = [0, 0]
+		inner_relax = agent.relax_seen_states
+		def counted_relax(*a, inner_relax=inner_relax, relax=relax, agent=agent, **k):
+			before = agent.G.copy()
+			r = inner_relax(*a, **k)
+			relax[0] += int((agent.G[:len(before)] != before).sum())
+			relax[1] += 1
+			return r
+		agent.relax_seen_states = counted_relax
 		pops = []
 		inner = agent.expand_batch
 		agent.expand_batch = lambda idcs, inner=inner, pops=pops: (pops.append(np.array(idcs)), inner(idcs))[1]
@@ -217,7 +248,8 @@ def astar_traces():
 		out[f"{tag}_action_queue"] = np.array(list(agent.action_queue), dtype=np.int64)
 		out[f"{tag}_pop_lens"] = np.array([len(p) for p in pops])
 		out[f"{tag}_pops"] = np.concatenate(pops) if pops else np.zeros(0, dtype=np.int64)
-		print(f"astar {tag}: solved={solved} n={n} iters={len(pops)} queue_len={len(agent.action_queue)}")
+		out[f"{tag}_relaxed"] = np.array(relax[0])                           # G entries lowered by relax_seen_states over the whole search
+		print(f"astar {tag}: solved={solved} n={n} iters={len(pops)} queue_len={len(agent.action_queue)} G entries relaxed={relax[0]}")
 	np.savez_compressed(os.path.join(OUT, "astar_trace.npz"), **out)
 
 

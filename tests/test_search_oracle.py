@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from oracle import cube_oracle as orc
-from oracle.search_oracle import AStarOracle, MCTSOracle, PolicyStubNet, StubNet, adi_traindata_oracle
+from oracle.search_oracle import AStarOracle, MCTSOracle, NoisyStubNet, PolicyStubNet, StubNet, adi_traindata_oracle
 
 
 def _apply(state, queue):
@@ -15,16 +15,19 @@ def _apply(state, queue):
 	return state
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "d", "c"])
+@pytest.mark.parametrize("tag", ["a", "b", "d", "c", "e", "f"])
 def test_astar_oracle_reproduces_reference_trace(golden, tag):
+	"""Traces e and f were driven by the misleading NoisyStubNet: the unmodified reference lowered 39 / 2 G entries in
+	relax_seen_states (both cases, several shortcuts on one parent in one batch) -- with the plain stub it almost never does."""
 	t = golden["astar_trace"]
 	seed, depth, expansions, max_states = (int(x) for x in t[f"{tag}_params"])
 	np.random.seed(seed)
 	start, _, _ = orc.scramble(depth, True)
 	assert (start == t[f"{tag}_start"]).all()
-	agent = AStarOracle(StubNet(), float(t[f"{tag}_lambda"]), expansions)
+	agent = AStarOracle(NoisyStubNet() if tag in ("e", "f") else StubNet(), float(t[f"{tag}_lambda"]), expansions)
 	solved = agent.search(start, max_states)
 	assert solved == bool(t[f"{tag}_solved"]) and len(agent) == int(t[f"{tag}_n"])
+	assert int(t["e_relaxed"]) >= 30                                       # the relaxation code really ran in the reference
 	states, G, parents, pact = agent.arrays()
 	assert (states == t[f"{tag}_states"]).all()
 	assert (G == t[f"{tag}_G"]).all()

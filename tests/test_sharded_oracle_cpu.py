@@ -12,17 +12,20 @@ import pytest
 
 from librubiks_amd import _ffi
 from oracle import cube_oracle as orc
-from oracle.search_oracle import AStarOracle, StubNet
+from oracle.search_oracle import AStarOracle, NoisyStubNet, StubNet
 from oracle.sharded_oracle import STOP_BUDGET, STOP_CAPACITY, STOP_WON, ShardedAStarOracle, owner_of
 
+NOISY_CASES = [(11, 14, 0.05, 50, 60_000), (12, 16, 0.02, 200, 40_000)]
 CASES = [(7, 6, 0.5, 10, 30_000), (19, 7, 0.1, 300, 60_000), (402, 6, 1.0, 50, 30_000), (405, 8, 0.5, 30, 40_000), (104, 6, 0.05, 1000, 40_000)]
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "d"])
+@pytest.mark.parametrize("tag", ["a", "b", "d", "e", "f"])
 def test_world1_is_the_reference(golden, tag):
+	"""e, f: traces of the unmodified reference with the misleading NoisyStubNet, in which relaxation cases 1 and 2 really happen:
+	the protocol's offers (case 2 deferred to the next exchange, last hit per parent wins) must give the reference's arrays."""
 	t = golden["astar_trace"]
 	_, _, expansions, max_states = (int(x) for x in t[f"{tag}_params"])
-	o = ShardedAStarOracle(StubNet(), float(t[f"{tag}_lambda"]), expansions, 1)
+	o = ShardedAStarOracle(NoisyStubNet() if tag in ("e", "f") else StubNet(), float(t[f"{tag}_lambda"]), expansions, 1)
 	stop = o.search(t[f"{tag}_start"], max_states)
 	assert (stop == STOP_WON) == bool(t[f"{tag}_solved"])
 	states, G, parents, prank, pact = o.arrays(0)
@@ -48,6 +51,17 @@ def test_world1_equals_the_single_queue_oracle(seed, depth, lam, n, budget):
 	assert len(o.pops) == len(ref.pops) and all((np.array(a[0]) == b).all() for a, b in zip(o.pops, ref.pops))
 	assert list(o.action_queue) == list(ref.action_queue)
 	assert sorted(ref.open) == o.open_queue(0)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_protocol_with_a_misleading_heuristic(world):
+	"""NoisyStubNet: dozens of cross-rank shortcut offers, several on one parent in one exchange.  The shards stay consistent."""
+	for seed, depth, lam, n, budget in NOISY_CASES:
+		np.random.seed(seed)
+		start, _, _ = orc.scramble(depth, True)
+		o = ShardedAStarOracle(NoisyStubNet(), lam, n, world)
+		o.search(start, budget)
+		assert len(check_shards(o, start)) == o.total_states
 
 
 def test_owner_function_is_the_librarys():
