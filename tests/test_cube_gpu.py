@@ -744,3 +744,24 @@ def test_paced_kernels_of_different_kinds_on_two_streams():
 			assert torch.equal(ch, ref_ch) and torch.equal(ch6, ref6) and torch.equal(fl6, ref6_fl)
 	finally:
 		cube.set_is2024(True)
+
+
+def test_set_pacing_switches_the_form_not_the_results():
+	"""rk_set_pacing(0 / 1 / -1): the unpaced kernels at every size, the paced forms, back to the environment's choice -- at run time,
+	which is how bench.py times both forms in one process.  Same children, flags and one-hot either way."""
+	lib = _ffi.lib()
+	n = 400_000
+	g = torch.Generator(device="cuda")
+	g.manual_seed(33)
+	p = cube.device.apply_sequences(torch.randint(0, 12, (8, n), device="cuda", dtype=torch.uint8, generator=g), False, True)
+	try:
+		outs = []
+		for mode in (1, 0, -1, 0, 1):
+			_ffi.check(lib.rk_set_pacing(mode))
+			ch, fl = cube.device.expand12(p)
+			oh = cube.device.as_oh(p, dtype=torch.bfloat16)
+			outs.append((ch, fl, oh))
+		for ch, fl, oh in outs[1:]:
+			assert torch.equal(ch, outs[0][0]) and torch.equal(fl, outs[0][1]) and torch.equal(oh, outs[0][2])
+	finally:
+		_ffi.check(lib.rk_set_pacing(-1))
