@@ -215,8 +215,8 @@ def astar_traces():
 		"d": dict(seed=19, depth=7, lambda_=0.1, expansions=300, max_states=60_000),
 		# a misleading heuristic (NoisyStubNet): states are rediscovered over shorter ways, both relaxation cases happen, several
 		# shortcuts hit one parent in one batch (the last assignment must stay).  The counts are recorded with the trace.
-		"e": dict(seed=11, depth=14, lambda_=0.05, expansions=50, max_states=60_000, net="noisy"),
-		"f": dict(seed=12, depth=16, lambda_=0.02, expansions=200, max_states=40_000, net="noisy"),
+		"e": dict(seed=11, depth=14, lambda_=0.05, expansions=50, max_states=20_000, net="noisy"),
+		"f": dict(seed=12, depth=16, lambda_=0.02, expansions=200, max_states=20_000, net="noisy"),
 	}
 	for tag, c in cases.items():
 		np.random.seed(c["seed"])

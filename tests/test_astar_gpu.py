@@ -29,7 +29,7 @@ def _check_against(agent: AStar, states, G, parents, pact, queue):
 
 @pytest.mark.parametrize("tag", ["a", "b", "d", "c", "e", "f"])
 def test_reference_traces(golden, tag):
-	"""e, f: the reference driven by a misleading heuristic (NoisyStubNet), 39 / 2 G entries lowered by relax_seen_states."""
+	"""e, f: the reference driven by a misleading heuristic (NoisyStubNet), 26 / 2 G entries lowered by relax_seen_states."""
 	t = golden["astar_trace"]
 	_, _, expansions, max_states = (int(x) for x in t[f"{tag}_params"])
 	start = t[f"{tag}_start"]
