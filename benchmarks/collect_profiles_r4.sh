@@ -33,4 +33,7 @@ if [ -f $O/search/astar_small.json ]; then
 	cp $O/search/astar_small.json $P/r04_astar_small.json
 	[ -s $O/search/grow_cost.json ] && cp $O/search/grow_cost.json $P/r04_grow_cost.json
 fi
+[ -s $O/sharded/rehearsal.json ] && cp $O/sharded/rehearsal.json $P/r04_sharded_rehearsal.json
+[ -s $O/mcts_priors_cost.json ] && cp $O/mcts_priors_cost.json $P/r04_mcts_priors_cost.json
+[ -s $O/phase/sweep.json ] && cp $O/phase/sweep.json $P/r04_phase_sweep.json
 git status --short $P | head -40
