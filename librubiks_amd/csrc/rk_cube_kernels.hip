@@ -821,11 +821,21 @@ void k_multi_rotate(const uint32_t *__restrict__ states, const uint8_t *__restri
 			#pragma unroll
 			for (int k = 0; k < 5; k++) buf[k * 64 + lane] = src4[k * 64 + lane];
 		} else {
+			// ragged or misaligned tile: dword loads from CLAMPED addresses -- always valid, so all twenty are issued back to back and
+			// waited for once.  As predicated loads (`idx < ndw ? src[idx] : 0`) they compiled to one exec branch and one
+			// `s_waitcnt vmcnt(0)` each: twenty dependent round trips, 3.5 us on top of every launch whose row count is not a
+			// multiple of 256 (multi_is_solved on 250 000 rows: 6.8 us against 3.4 us on 261 120, profiles/r04_rows_ragged.json)
 			const int ndw = np * STATE_DWORDS;
+			uint32_t got[20];
 			#pragma unroll
 			for (int k = 0; k < 20; k++) {
 				const int idx = k * 64 + lane;
-				buf_dw[idx] = idx < ndw ? src[idx] : 0u;
+				got[k] = src[idx < ndw ? idx : ndw - 1];
+			}
+			#pragma unroll
+			for (int k = 0; k < 20; k++) {
+				const int idx = k * 64 + lane;
+				buf_dw[idx] = idx < ndw ? got[k] : 0u;
 			}
 		}
 		// the four actions of this lane's states: one dword per lane when the tile is whole and the codes are aligned
@@ -840,11 +850,16 @@ void k_multi_rotate(const uint32_t *__restrict__ states, const uint8_t *__restri
 			note_bad_action(((w & (w << 1)) & 0x08080808u) != 0u || (w & 0xF0F0F0F0u) != 0u);                // any byte >= 12: bits 3 and 2, or a high nibble
 		} else {
 			bool bad_any = false;
+			uint32_t raw[4];
+			#pragma unroll
+			for (int q = 0; q < 4; q++) {                 // clamped addresses: four loads in flight, not four round trips (see above)
+				const int r = 4 * lane + q;
+				const size_t i = p0 + (size_t)(r < np ? r : np - 1);
+				raw[q] = SPLIT_FD ? (2u * act_or_faces[i] + (1u - dirs[i])) : act_or_faces[i];
+			}
 			#pragma unroll
 			for (int q = 0; q < 4; q++) {
-				const size_t i = p0 + 4 * lane + q;
-				uint32_t a = 0;
-				if (4 * lane + q < np) a = SPLIT_FD ? (2u * act_or_faces[i] + (1u - dirs[i])) : act_or_faces[i];
+				const uint32_t a = 4 * lane + q < np ? raw[q] : 0u;
 				bad_any |= a >= 12u;
 				act[q] = a < 12u ? a : 0u;            // out-of-range actions are rejected on the host; never index past the table
 			}
@@ -950,11 +965,17 @@ void k_multi_is_solved(const uint32_t *__restrict__ states, uint8_t *__restrict_
 			#pragma unroll
 			for (int k = 0; k < 5; k++) buf[k * 64 + lane] = src4[k * 64 + lane];
 		} else {
-			const int ndw = np * STATE_DWORDS;
+			const int ndw = np * STATE_DWORDS;                               // clamped addresses, as in k_multi_rotate's ragged path
+			uint32_t got[20];
 			#pragma unroll
 			for (int k = 0; k < 20; k++) {
 				const int idx = k * 64 + lane;
-				buf_dw[idx] = idx < ndw ? src[idx] : 0xFFFFFFFFu;
+				got[k] = src[idx < ndw ? idx : ndw - 1];
+			}
+			#pragma unroll
+			for (int k = 0; k < 20; k++) {
+				const int idx = k * 64 + lane;
+				buf_dw[idx] = idx < ndw ? got[k] : 0xFFFFFFFFu;
 			}
 		}
 		wave_lds_fence();
