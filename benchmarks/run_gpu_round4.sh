@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-4 GPU work on one MI355X box, in stages (one gpurun call each, a call is limited to 20 minutes):
 #   gpurun --timeout 1200 -- 'RK_COMMIT=<sha> bash benchmarks/run_gpu_round4.sh <stage>'
-# stages: tests | bench | search | kernels | streams   (profiles/README.md maps the records to these commands)
+# stages: tests | bench | search | kernels | rows | streams | astar | evaluator   (profiles/README.md maps the records to these commands)
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 STAGE=${1:-tests}
@@ -48,6 +48,9 @@ streams)
 search)
 	step 500 python benchmarks/astar_small.py > $O/astar_small.json 2> $O/astar_small.err; cut -c1-300 $O/astar_small.json
 	step 300 python benchmarks/grow_cost.py 2> $O/grow_cost.err | grep '^{' > $O/grow_cost.json; cut -c1-300 $O/grow_cost.json
+	;;
+evaluator)
+	step 900 python benchmarks/evaluator.py 2> $O/evaluator.err | grep '^{' > $O/evaluator.json; cut -c1-700 $O/evaluator.json
 	;;
 astar)
 	for n in 1 10 100 700; do

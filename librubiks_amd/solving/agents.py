@@ -702,6 +702,7 @@ class MCTSBatch(DeepAgent):
 		self.simulations = 0
 		self.grown = 0
 		self.profile_events = None        # a list: every eager simulation step appends a HIP event pair around its backup + select launch
+		self.on_poll = None               # callable(status): called with every status the search reads (solving/evaluation.py times games with it)
 
 	@property
 	def torch_softmax(self) -> bool:
@@ -737,6 +738,8 @@ class MCTSBatch(DeepAgent):
 			raise _ffi.RubiksHipError(f"MCTS engine error codes {codes}: " + "; ".join(self._ERRORS.get(k, "?") for k in codes)
 			                          + f" (max_path={self.max_path})")
 		self.status = st
+		if self.on_poll is not None:
+			self.on_poll(st)
 		return st
 
 	def _step(self, oh, h, expand: bool = True):
@@ -1058,6 +1061,7 @@ class AStarBatch(DeepAgent):
 		self._h = None
 		self.status = None
 		self.iterations = 0
+		self.on_poll = None                                # callable(status): called with every status the search reads
 
 	def _engine(self):
 		if self._h is None:
@@ -1080,6 +1084,8 @@ class AStarBatch(DeepAgent):
 		if st[:, 6].any():
 			raise _ffi.RubiksHipError(f"batched A* engine error codes {st[:, 6].tolist()}")
 		self.status = st
+		if self.on_poll is not None:
+			self.on_poll(st)
 		return st
 
 	def _step_exact(self, oh, code):

@@ -15,6 +15,8 @@ Fixtures
   astar_trace.npz   unmodified reference AStar driven by an exact-integer stub net
   mcts_trace.npz    unmodified reference MCTS driven by the same stub (one case with a non-uniform exact policy)
   adi_trace.npz     unmodified reference Train.ADI_traindata (train.py:256-339), stub net, all four reward methods
+  evaluator_trace.npz  unmodified reference Evaluator.eval (solving/evaluation.py:56-96) over the unmodified agents and the stubs:
+                    the `res` and `states` matrices (times are wall clock: not data)
 """
 import argparse
 import hashlib
@@ -357,16 +359,54 @@ def adi_traces():
 	np.savez_compressed(os.path.join(OUT, "adi_trace.npz"), **out)
 
 
+def evaluator_traces():
+	"""
+	The unmodified reference `Evaluator.eval` (solving/evaluation.py:56-96): scrambles drawn from the global generator between the
+	searches, one `agent.search` per game, bounded by max_states.  Recorded: res (moves of each solution, -1 = none) and states
+	(len(agent) after each game).  The start states are recorded too, so that a CPU test can replay the games with the oracle.
+	"""
+	from librubiks.solving.evaluation import Evaluator
+	out = {}
+	cases = {
+		"astar": dict(seed=31, games=4, depths=[3, 6, 9, 12], max_states=6_000, agent=lambda: agents.AStar(StubNet(), lambda_=0.2, expansions=30)),
+		"astar_noisy": dict(seed=32, games=3, depths=[8, 14], max_states=5_000, agent=lambda: agents.AStar(NoisyStubNet(), lambda_=0.05, expansions=50)),
+		"astar_deep": dict(seed=35, games=3, depths=range(0), max_states=2_000, agent=lambda: agents.AStar(StubNet(), lambda_=0.5, expansions=10)),
+		"mcts_graph": dict(seed=33, games=4, depths=[2, 4, 5], max_states=4_000, agent=lambda: agents.MCTS(PolicyStubNet(), c=5.0, search_graph=True)),
+		"mcts": dict(seed=36, games=3, depths=[2, 4], max_states=3_000, agent=lambda: agents.MCTS(StubNet(), c=5.0, search_graph=False)),
+		"bfs": dict(seed=34, games=3, depths=[1, 2, 3], max_states=3_000, agent=lambda: agents.BFS()),
+	}
+	for tag, c in cases.items():
+		agent = c["agent"]()
+		starts = []
+		inner = agent.search
+		def recorded(state, *a, inner=inner, starts=starts, **k):
+			starts.append(np.array(state))
+			return inner(state, *a, **k)
+		agent.search = recorded
+		np.random.seed(c["seed"])
+		ev = Evaluator(n_games=c["games"], scrambling_depths=c["depths"], max_time=None, max_states=c["max_states"])
+		res, states, times = ev.eval(agent)
+		deep = c["depths"] == range(0)
+		out[f"{tag}_params"] = np.array([c["seed"], c["games"], c["max_states"], int(deep)])
+		out[f"{tag}_depths"] = np.array([0] if deep else list(c["depths"]))
+		out[f"{tag}_starts"] = np.array(starts, dtype=np.int8)
+		out[f"{tag}_res"] = res.astype(np.int64)
+		out[f"{tag}_states"] = states.astype(np.int64)
+		print(f"evaluator {tag}: res={res.tolist()} states={states.tolist()}")
+	np.savez_compressed(os.path.join(OUT, "evaluator_trace.npz"), **out)
+
+
 if __name__ == "__main__":
 	ap = argparse.ArgumentParser()
 	ap.add_argument("--skip-1m", action="store_true", help="reuse the committed 1 M-state hashes (saves ~1 min)")
 	ap.add_argument("--only", default="")
 	args = ap.parse_args()
 	os.makedirs(OUT, exist_ok=True)
-	todo = args.only.split(",") if args.only else ["tables", "kats", "astar", "mcts", "adi"]
+	todo = args.only.split(",") if args.only else ["tables", "kats", "astar", "mcts", "adi", "evaluator"]
 	if "tables" in todo: tables()
 	if "kats" in todo: kats(args.skip_1m)
 	if "astar" in todo: astar_traces()
 	if "mcts" in todo: mcts_traces()
 	if "adi" in todo: adi_traces()
+	if "evaluator" in todo: evaluator_traces()
 	print("golden vectors written to", OUT)

@@ -1,0 +1,83 @@
+"""
+librubiks_amd.solving.evaluation.Evaluator against what the unmodified reference's Evaluator returned
+(ref:librubiks/solving/evaluation.py:56-96; tests/golden/evaluator_trace.npz, oracle/gen_golden.py::evaluator_traces):
+the games one after the other as the reference plays them, and all games in lock-step on the device -- `res` and `states`
+must be the reference's entry by entry either way.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from librubiks_amd.solving import agents
+from librubiks_amd.solving.evaluation import Evaluator, bernoulli_error
+from oracle.search_oracle import NoisyStubNet, PolicyStubNet, StubNet
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "evaluator_trace.npz"))
+
+CASES = {
+	"astar": lambda: agents.AStar(StubNet(), 0.2, 30, capacity=8_000),
+	"astar_noisy": lambda: agents.AStar(NoisyStubNet(), 0.05, 50, capacity=8_000),
+	"astar_deep": lambda: agents.AStar(StubNet(), 0.5, 10, capacity=4_000),
+	"mcts_graph": lambda: agents.MCTS(PolicyStubNet(), 5.0, True, capacity=4_000),
+	"mcts": lambda: agents.MCTS(StubNet(), 5.0, False, capacity=4_000),
+	"bfs": lambda: agents.BFS(),
+}
+
+
+def _evaluator(tag: str, **kw) -> Evaluator:
+	seed, games, max_states, deep = (int(x) for x in GOLD[f"{tag}_params"])
+	np.random.seed(seed)
+	return Evaluator(games, range(0) if deep else [int(d) for d in GOLD[f"{tag}_depths"]], None, max_states, **kw)
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_games_one_after_the_other(tag):
+	ev = _evaluator(tag)
+	res, states, times = ev.eval(CASES[tag](), batched=False)
+	assert ev.last_mode == "sequential"
+	assert res.shape == states.shape == times.shape == GOLD[f"{tag}_res"].shape
+	assert (res == GOLD[f"{tag}_res"]).all() and (states == GOLD[f"{tag}_states"]).all()
+	assert (times > 0).all()
+
+
+@pytest.mark.parametrize("tag", [t for t in CASES if t != "bfs"])
+@pytest.mark.parametrize("batch_games", [64, 5])
+def test_games_in_lock_step(tag, batch_games):
+	"""All games at once, and in groups of five with a smaller last group."""
+	ev = _evaluator(tag, batch_games=batch_games)
+	res, states, times = ev.eval(CASES[tag]())                  # default: batched, the games are bounded by max_states
+	assert ev.last_mode == "batched"
+	assert (res == GOLD[f"{tag}_res"]).all() and (states == GOLD[f"{tag}_states"]).all()
+	assert (times > 0).all()
+
+
+def test_mcts_in_lock_step_with_the_softmax_in_the_kernel():
+	"""priors="kernel": the step is replayed as a hipGraph; the stub's logits are exact, so the trees are the reference's."""
+	ev = _evaluator("mcts_graph")
+	res, states, _ = ev.eval(agents.MCTS(PolicyStubNet(), 5.0, True, capacity=4_000, priors="kernel"))
+	assert (res == GOLD["mcts_graph_res"]).all() and (states == GOLD["mcts_graph_states"]).all()
+
+
+def test_modes_and_errors():
+	ev = Evaluator(2, [2], max_time=0.5, max_states=500)
+	assert ev.approximate_time() == 1.0 and not ev._isdeep() and Evaluator(1, range(0), max_states=10)._isdeep()
+	np.random.seed(1)
+	ev.eval(agents.AStar(StubNet(), 0.2, 10, capacity=1_000))
+	assert ev.last_mode == "sequential"                         # a time limit per game: games cannot share a clock
+	with pytest.raises(TypeError):
+		Evaluator(2, [2], max_states=500).eval(agents.BFS(), batched=True)
+	with pytest.raises(AssertionError):
+		Evaluator(2, [2]).eval(agents.BFS())
+	assert abs(bernoulli_error(0.5, 100, 0.05) - 0.0979981992270027) < 1e-15     # ref:librubiks/utils/__init__.py:24-30
+	lines = []
+	class Log:
+		def __call__(self, *a, **k): lines.append(" ".join(str(x) for x in a))
+		def section(self, t): lines.append(t)
+		def verbose(self, *a, **k): pass
+	np.random.seed(2)
+	Evaluator(3, [1, 2], max_states=2_000, logger=Log()).eval(agents.AStar(StubNet(), 0.2, 10, capacity=4_000))
+	text = "\n".join(lines)
+	assert "Evaluation of" in text and "Scrambling depth 1" in text and "Share completed: 100.00 %" in text and "Turns to win: 1.00" in text
