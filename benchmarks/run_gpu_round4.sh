@@ -50,6 +50,7 @@ search)
 	step 300 python benchmarks/grow_cost.py 2> $O/grow_cost.err | grep '^{' > $O/grow_cost.json; cut -c1-300 $O/grow_cost.json
 	;;
 evaluator)
+	step 300 python benchmarks/graph_kept.py 2> $O/graph_kept.err | grep '^{' > $O/graph_kept.json; cut -c1-400 $O/graph_kept.json
 	step 900 python benchmarks/evaluator.py 2> $O/evaluator.err | grep '^{' > $O/evaluator.json; cut -c1-700 $O/evaluator.json
 	;;
 astar)

@@ -102,7 +102,8 @@ def _start(rng, depth):
 
 def _net(rng, kinds):
 	k = kinds[int(rng.randint(0, len(kinds)))]
-	return k, {"stub": StubNet, "noisy": lambda: NoisyStubNet(int(rng.randint(0, 5))), "policy": PolicyStubNet}[k]
+	noise_seed = int(rng.randint(0, 5))                             # drawn ONCE: the oracle's net and the engine's must be the same net
+	return k, {"stub": StubNet, "noisy": lambda: NoisyStubNet(noise_seed), "policy": PolicyStubNet}[k]
 
 
 def case_astar(rng):

@@ -81,6 +81,18 @@ def _net_signature(net):
 	return tuple(sig)
 
 
+def _capture_key(net, fs) -> tuple:
+	"""What a captured search step holds of the net: the module, its mode, and the storage of every parameter and buffer (their
+	VALUES are read at replay time, so in-place training between searches keeps a captured step valid; the fused copy `fs` is
+	rebuilt -- a new object -- whenever the values change)."""
+	ptrs = []
+	for get in ("parameters", "buffers"):
+		it = getattr(net, get, None)
+		if callable(it):
+			ptrs += [(t.data_ptr(), t.dtype) for t in it()]
+	return (id(net), bool(getattr(net, "training", False)), tuple(ptrs), id(fs))
+
+
 class DeepAgent(Agent):
 	"""
 	An agent with a value/policy net.  `fused_first_layer` (False, True, "epilogue", "folded"; librubiks_amd.oh_linear)
@@ -419,6 +431,8 @@ class AStar(DeepAgent):
 		self.capacity_exhausted = False
 		self.grown = 0                # times the pool grew in place during the last search
 		self.profile_events = None    # a list: every run-ahead iteration appends four HIP events (before expand, before the net, after it, after commit)
+		self._graph_cache = None      # (key, hipGraph of one iteration, its batch buffer): kept from search to search, see search()
+		self.captures = 0             # hipGraph captures so far (a search on an unchanged engine and net replays the previous search's graph)
 		self.record_pops = False      # debugging aid: keep the popped indices of every iteration in self.pops
 		self.pops = []
 
@@ -433,6 +447,7 @@ class AStar(DeepAgent):
 		return h
 
 	def _free(self):
+		self._graph_cache = None              # it holds the engine's addresses
 		if getattr(self, "_h", None) is not None:
 			_ffi.lib().rk_astar_destroy(self._h)
 			self._h = None
@@ -484,12 +499,14 @@ class AStar(DeepAgent):
 		cap = max(int(min(max_states, self.capacity or self.default_capacity)), K + 2)
 		lib = _ffi.lib()
 		self._fs = self._from_states           # re-copied here if the net changed since the last search
-		if self._fs is not None:
-			oh, code = torch.from_numpy(cube.repeat_state(cube.get_solved(), K)).to(gpu), _ffi.OH_STATES      # (K, 20) int8: valid codes everywhere
+		code = _ffi.OH_STATES if self._fs is not None else _OH_CODES[_oh_dtype(self.net)]
+		cached = self._graph_cache
+		if cached is not None and self.use_hipgraph and cached[2][1] == code and len(cached[2][0]) == K:
+			oh = cached[2][0]                  # the buffer the kept graph was captured on (rows are rewritten before they are read)
+		elif self._fs is not None:
+			oh = torch.from_numpy(cube.repeat_state(cube.get_solved(), K)).to(gpu)      # (K, 20) int8: valid codes everywhere
 		else:
-			oh_dtype = _oh_dtype(self.net)
-			oh = torch.zeros((K, 480), dtype=oh_dtype, device=gpu)
-			code = _OH_CODES[oh_dtype]
+			oh = torch.zeros((K, 480), dtype=_oh_dtype(self.net), device=gpu)
 		status = (C.c_longlong * 8)()
 		h = self._engine(cap)
 		cap = self._h_cap
@@ -503,14 +520,26 @@ class AStar(DeepAgent):
 		while True:                                                  # one round per pool size: the pool grows in place below
 			graph = None
 			if self.use_hipgraph and not self.record_pops:
-				side = torch.cuda.Stream()
-				side.wait_stream(torch.cuda.current_stream())
-				with torch.cuda.stream(side):
-					self._iteration(h, oh, code)                   # a real iteration; also warms the allocator
-				torch.cuda.current_stream().wait_stream(side)
-				graph = torch.cuda.CUDAGraph()                     # (captured again after a growth: it holds the pool's addresses)
-				with torch.cuda.graph(graph):
-					self._iteration(h, oh, code)
+				# The captured iteration holds addresses (engine pools, batch buffer, the net's tensors) and two scalars passed by
+				# value (lambda, the values' dtype) -- nothing of the search itself, which lives in device memory that rk_astar_reset
+				# rewrites.  So the graph is KEPT from search to search and captured again only when one of those changes (a grown
+				# or new engine, another net or fused copy, another lambda): capturing cost every search about 7 ms
+				# (profiles/NOTES.md section 7), as much as a hundred iterations.
+				key = (h.value, cap, float(self.lambda_), code, oh.data_ptr(), _capture_key(self.net, self._fs))
+				if self._graph_cache is not None and self._graph_cache[0] == key:
+					graph = self._graph_cache[1]
+				else:
+					self._graph_cache = None
+					side = torch.cuda.Stream()
+					side.wait_stream(torch.cuda.current_stream())
+					with torch.cuda.stream(side):
+						self._iteration(h, oh, code)               # a real iteration; also warms the allocator
+					torch.cuda.current_stream().wait_stream(side)
+					graph = torch.cuda.CUDAGraph()                 # (captured again after a growth: it holds the pool's addresses)
+					with torch.cuda.graph(graph):
+						self._iteration(h, oh, code)
+					self._graph_cache = (key, graph, (oh, code), (self.net, self._fs))     # the net stays alive with the graph that holds its addresses
+					self.captures += 1
 			budget = int(min(max_states, cap))
 			done = won = err = solved_idx = 0
 			while exact:
@@ -703,6 +732,8 @@ class MCTSBatch(DeepAgent):
 		self.grown = 0
 		self.profile_events = None        # a list: every eager simulation step appends a HIP event pair around its backup + select launch
 		self.on_poll = None               # callable(status): called with every status the search reads (solving/evaluation.py times games with it)
+		self._graph_cache = None          # (key, hipGraph of one step, its batch buffer): kept from search to search, see _capture
+		self.captures = 0                 # hipGraph captures so far
 
 	@property
 	def torch_softmax(self) -> bool:
@@ -718,6 +749,7 @@ class MCTSBatch(DeepAgent):
 		return self._h
 
 	def _free(self):
+		self._graph_cache = None              # it holds the engine's addresses
 		if getattr(self, "_h", None) is not None:
 			_ffi.lib().rk_mcts_destroy(self._h)
 			self._h = None
@@ -741,6 +773,15 @@ class MCTSBatch(DeepAgent):
 		if self.on_poll is not None:
 			self.on_poll(st)
 		return st
+
+	def _kept_buffer(self, code: int):
+		"""The batch buffer of the kept graph, if it fits this search (the step rewrites its rows before the net reads them)."""
+		kept = self._graph_cache
+		if kept is None:
+			return None
+		oh = kept[2]
+		want = torch.int8 if code == _ffi.OH_STATES else {v: k for k, v in _OH_CODES.items()}[code]
+		return oh if len(oh) == 12 * self.n_trees and oh.dtype == want else None
 
 	def _step(self, oh, h, expand: bool = True):
 		lib = _ffi.lib()
@@ -824,13 +865,17 @@ class MCTSBatch(DeepAgent):
 			root_oh = torch.empty((self.n_trees, 20), dtype=torch.int8, device=gpu)
 			_ffi.check(lib.rk_mcts_roots_oh(h, root_oh.data_ptr(), _ffi.OH_STATES, _ffi.stream_ptr()))
 			p, v = _policy_value_f32(self._fs(root_oh))
-			oh = torch.from_numpy(cube.repeat_state(cube.get_solved(), 12 * self.n_trees)).to(gpu)
+			oh = self._kept_buffer(_ffi.OH_STATES)
+			if oh is None:
+				oh = torch.from_numpy(cube.repeat_state(cube.get_solved(), 12 * self.n_trees)).to(gpu)
 		else:
 			oh_dtype = _oh_dtype(self.net)
 			root_oh = torch.empty((self.n_trees, 480), dtype=oh_dtype, device=gpu)
 			_ffi.check(lib.rk_mcts_roots_oh(h, root_oh.data_ptr(), _OH_CODES[oh_dtype], _ffi.stream_ptr()))
 			p, v = _policy_value_f32(self.net(root_oh))                  # agents.py:470-473: the root's softmax runs on the device
-			oh = torch.empty((12 * self.n_trees, 480), dtype=oh_dtype, device=gpu)
+			oh = self._kept_buffer(_OH_CODES[oh_dtype])
+			if oh is None:
+				oh = torch.empty((12 * self.n_trees, 480), dtype=oh_dtype, device=gpu)
 		_ffi.check(lib.rk_mcts_set_root_pv(h, p.data_ptr(), v.data_ptr(), _ffi.stream_ptr()))
 		# every backup + select launch also expands the leaf it found, while another simulation is to follow
 		_ffi.check(lib.rk_mcts_set_expand_ahead(h, int(max_sims) if max_sims is not None else -1))
@@ -845,6 +890,19 @@ class MCTSBatch(DeepAgent):
 		expansion is always done by the backup launch before it, so the captured step leaves rk_mcts_expand out (one launch less
 		per replay); were that ever untrue, the backup kernel stops the tree with error 3 instead of using stale children."""
 		h, oh = self._h, self._oh
+		# The captured step holds addresses (pools, batch buffer, the net's tensors) and scalars passed by value (c, nu, sizes, the
+		# simulation limit of the expand-ahead) --
+		# nothing of the trees, which live in device memory that rk_mcts_reset rewrites.  So the graph is KEPT from search to
+		# search and captured again only when one of those changes (grown or new engine, another net or fused copy).
+		key = (h.value, self._shape, self.c, self.nu, self.priors, self._max_sims, oh.data_ptr(), oh.dtype, _capture_key(self.net, self._fs))
+		hit = self._graph_cache is not None and self._graph_cache[0] == key
+		if hit:
+			for _ in range(warm):                                      # real simulations: after them every tree is expanded ahead
+				self._step(oh, h)
+				self.simulations += 1
+			self._graph = self._graph_cache[1]
+			return
+		self._graph_cache = None
 		side = torch.cuda.Stream()
 		side.wait_stream(torch.cuda.current_stream())
 		with torch.cuda.stream(side):
@@ -855,6 +913,8 @@ class MCTSBatch(DeepAgent):
 		self._graph = torch.cuda.CUDAGraph()
 		with torch.cuda.graph(self._graph):
 			self._step(oh, h, expand=False)
+		self._graph_cache = (key, self._graph, oh, (self.net, self._fs))      # the net stays alive with the graph that holds its addresses
+		self.captures += 1
 
 	@no_grad
 	def _advance(self, n: int):

@@ -87,6 +87,8 @@ class Evaluator:
 			batched = self.can_batch(agent) and self.max_states is not None and not self.max_time
 		if batched and not self.can_batch(agent):
 			raise TypeError(f"{agent} has no batched engine; play its games one after the other")
+		if batched and self.max_states is None:
+			raise ValueError("batched games need max_states: it sizes every game's node pool (max_time, if given, then limits the whole batch)")
 		self.log.section(f"Evaluation of {agent}")
 		D, G = len(self.scrambling_depths), self.n_games
 		self.last_mode = "batched" if batched else "sequential"
@@ -154,10 +156,12 @@ class Evaluator:
 			seen[fresh] = time.perf_counter() - t0
 		b.on_poll = on_poll
 		try:
+			# max_time, if given, is every game's limit on the batch's one clock (the games share the device: each gets less of it
+			# than a game played alone would -- which is why eval() only chooses this form by itself for games without a time limit)
 			if isinstance(b, agents.AStarBatch):
-				solved = b.search(starts, None, self.max_states)
+				solved = b.search(starts, self.max_time, self.max_states)
 			else:
-				solved = b.search(starts, None, max_states=self.max_states, use_graph=b.priors != "reference")
+				solved = b.search(starts, self.max_time, max_states=self.max_states, use_graph=b.priors != "reference")
 		finally:
 			b.on_poll = None
 		seen[seen == 0] = time.perf_counter() - t0

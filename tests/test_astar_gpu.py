@@ -154,3 +154,30 @@ def test_low_precision_net_gets_low_precision_onehot():
 	n = len(agent)
 	pick = np.arange(2, n + 1)
 	assert (orc.multi_rotate(st[par[pick]], act[pick] // 2, 1 - act[pick] % 2) == st[pick]).all()
+
+
+def test_hipgraph_is_kept_from_search_to_search():
+	"""The captured iteration holds addresses and lambda, nothing of the search: searches on an unchanged engine and net replay
+	ONE graph; another lambda, another net, a grown pool each capture once more -- and every search equals the oracle's."""
+	def run(agent, net_of, lam, seed, depth, budget):
+		np.random.seed(seed)
+		start, _, _ = orc.scramble(depth, True)
+		ref = AStarOracle(net_of(), lam, agent.expansions)
+		assert agent.search(start, None, budget) == ref.search(start, budget), (seed, depth)
+		_check_against(agent, *ref.arrays(), ref.action_queue)
+	agent = AStar(StubNet(), 0.3, 20, capacity=20_000, use_hipgraph=True)
+	for seed, depth, budget in ((1, 6, 20_000), (2, 12, 9_000), (3, 3, 20_000), (4, 18, 15_000)):
+		run(agent, StubNet, 0.3, seed, depth, budget)
+	assert agent.captures == 1
+	agent.lambda_ = 0.05                                              # passed to the kernels by value: captured again
+	run(agent, StubNet, 0.05, 5, 10, 12_000)
+	assert agent.captures == 2
+	agent.net = NoisyStubNet()
+	run(agent, NoisyStubNet, 0.05, 6, 12, 12_000)
+	run(agent, NoisyStubNet, 0.05, 7, 9, 12_000)
+	assert agent.captures == 3
+	run(agent, NoisyStubNet, 0.05, 8, 14, 70_000)                     # grows 20 000 -> 40 000 -> 80 000 on the way: one capture per growth
+	grown = agent.grown
+	assert grown >= 1 and agent.captures == 3 + grown
+	run(agent, NoisyStubNet, 0.05, 9, 14, 70_000)                     # the grown engine's graph serves the next search
+	assert agent.grown == 0 and agent.captures == 3 + grown

@@ -71,6 +71,14 @@ def test_modes_and_errors():
 		Evaluator(2, [2], max_states=500).eval(agents.BFS(), batched=True)
 	with pytest.raises(AssertionError):
 		Evaluator(2, [2]).eval(agents.BFS())
+	with pytest.raises(ValueError):
+		Evaluator(2, [2], max_time=1.0).eval(agents.AStar(StubNet(), 0.2, 10), batched=True)
+	# a time limit on a batch: every game stops on the batch's clock
+	np.random.seed(3)
+	ev = Evaluator(4, [25], max_time=0.3, max_states=2_000_000)
+	res, states, times = ev.eval(agents.AStar(StubNet(), 0.5, 10), batched=True)
+	assert ev.last_mode == "batched" and (states > 1000).all() and (times < 5).all()         # solved or stopped by the clock, not by the budget
+	assert (states < 2_000_000 - 120).all()
 	assert abs(bernoulli_error(0.5, 100, 0.05) - 0.0979981992270027) < 1e-15     # ref:librubiks/utils/__init__.py:24-30
 	lines = []
 	class Log:

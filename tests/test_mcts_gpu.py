@@ -372,3 +372,52 @@ def test_a_backup_without_an_expansion_is_refused():
 	_ffi.check(lib.rk_mcts_status(h, status.ctypes.data, st()))
 	assert (status[:, 5] == 3).all() and (status[:, 0] == 1).all() and (status[:, 2] == 1).all()
 	_ffi.check(lib.rk_mcts_destroy(h))
+
+
+def test_hipgraph_is_kept_from_search_to_search():
+	"""The captured step holds addresses and by-value scalars, nothing of the trees: searches on an unchanged engine and net
+	replay ONE graph (single-tree agent and batch); another net or a grown pool capture once more; all equal the oracle."""
+	tree = MCTS(PolicyStubNet(), 1.5, True, capacity=6_000, use_hipgraph=True)
+	tree.max_capacity = 24_000
+	def run(net_of, seed, depth, budget):
+		np.random.seed(seed)
+		start, _, _ = orc.scramble(depth, True)
+		ref = MCTSOracle(net_of(), 1.5, True)
+		assert tree.search(start, None, budget) == ref.search(start, budget), (seed, depth)
+		n = len(ref)
+		a = tree._export()
+		assert a["n"] == n
+		for k in ("states", "neighbors", "N", "W", "L", "V", "P"):
+			assert (a[k][1:n + 1] == getattr(ref, k)[1:n + 1]).all(), (k, seed)
+		assert list(tree.action_queue) == list(ref.action_queue)
+	for seed, depth, budget in ((1, 4, 6_000), (2, 9, 3_000), (3, 2, 6_000), (4, 12, 5_000)):
+		run(PolicyStubNet, seed, depth, budget)
+	assert tree._batch.captures == 1
+	tree.net = StubNet()
+	run(StubNet, 5, 8, 4_000)
+	run(StubNet, 6, 10, 6_000)
+	assert tree._batch.captures == 2
+	run(StubNet, 7, 14, 20_000)                                        # grows on the way (unless solved early): one capture per growth
+	grown = tree.grown
+	assert tree._batch.captures == 2 + grown
+	run(StubNet, 8, 14, 20_000)
+	assert tree._batch.captures == 2 + grown + tree.grown
+	# a batch, searched three times with different starts and budgets
+	T = 5
+	batch = MCTSBatch(StubNet(), 2.0, T, capacity=3_000)
+	for rep in range(3):
+		starts = []
+		for i in range(T):
+			np.random.seed(100 * rep + i)
+			starts.append(orc.scramble(3 + 2 * i + rep, True)[0])
+		starts = np.array(starts)
+		budgets = np.array([900, 3000, 1500, 2500, 600]) + 100 * rep
+		got = batch.search(starts, max_states=budgets, use_graph=True, poll=7)
+		for i in range(T):
+			r = MCTSOracle(StubNet(), 2.0, False)
+			assert r.search(starts[i], int(budgets[i])) == bool(got[i]), (rep, i)
+			a = batch.tree_arrays(i)
+			n = len(r)
+			assert a["n"] == n and (a["N"][1:n + 1] == r.N[1:n + 1]).all() and (a["W"][1:n + 1] == r.W[1:n + 1]).all(), (rep, i)
+			assert list(batch.action_queue_of(i)) == list(r.action_queue), (rep, i)
+	assert batch.captures == 1
