@@ -404,7 +404,7 @@ def test_hipgraph_is_kept_from_search_to_search():
 	assert tree._batch.captures == 2 + grown + tree.grown
 	# a batch, searched three times with different starts and budgets
 	T = 5
-	batch = MCTSBatch(StubNet(), 2.0, T, capacity=3_000)
+	batch = MCTSBatch(StubNet(), 2.0, T, capacity=3_400)
 	for rep in range(3):
 		starts = []
 		for i in range(T):
