@@ -185,7 +185,53 @@ def case_mcts_batch(rng):
 	return what
 
 
-CASES = dict(cube20=case_cube20, cube686=case_cube686, astar=case_astar, astar_batch=case_astar_batch, mcts=case_mcts, mcts_batch=case_mcts_batch)
+def case_sharded(rng):
+	"""The hash-sharded A* at a random world size, all ranks simulated in one process, against the protocol oracle: every
+	iteration's pops and new counts of every rank, every shard, every open queue (tests/test_sharded_gpu.py::_simulate_ranks)."""
+	from oracle.sharded_oracle import ShardedAStarOracle
+	from tests.test_sharded_gpu import _simulate_ranks
+	kind, make = _net(rng, ["stub", "noisy"])
+	what = dict(net=kind, world=int(rng.randint(2, 9)), depth=int(rng.randint(3, 18)), lam=float(rng.choice([0.02, 0.1, 0.5, 1.0])), N=int(rng.choice([4, 30, 150, 500])))
+	what["budget"] = budget = int(rng.randint(12 * what["N"] + 100, 12 * what["N"] + 12_000))
+	start = _start(rng, what["depth"])
+	o = ShardedAStarOracle(make(), what["lam"], what["N"], what["world"])
+	o.search(start, budget)
+	stop, queue, shards, total, iters = _simulate_ranks(what["world"], start, what["lam"], what["N"], budget, capacity=budget, oracle=o, net=make())
+	assert total == o.total_states, ("total", what)
+	return what
+
+
+def case_host_surface(rng):
+	"""The drop-in NumPy surface (host pointers in, fresh arrays out) and the scramblers' seed parity."""
+	n = size(rng, 40_000)
+	s = walk(rng, n, int(rng.randint(0, 20)))
+	what = dict(n=n)
+	faces, dirs = rng.randint(0, 6, n), rng.randint(0, 2, n)
+	keep = s.copy()
+	assert (cube.multi_rotate(s, faces, dirs) == orc.multi_rotate(s, faces, dirs)).all() and (s == keep).all(), ("multi_rotate", what)
+	assert (cube.multi_rotate(s, faces.astype(np.uint8), dirs.astype(np.uint8)) == orc.multi_rotate(s, faces, dirs)).all(), ("multi_rotate u8", what)
+	assert (cube.multi_is_solved(s) == orc.multi_is_solved(s)).all(), ("multi_is_solved", what)
+	m = min(n, 3000)
+	ch = cube.multi_rotate(np.repeat(s[:m], 12, axis=0), *cube.iter_actions(m))
+	assert (ch == orc.expand12(s[:m])).all(), ("fan-out idiom", what)
+	assert (cube.as_oh(s[:m]).cpu().numpy() == orc.as_oh(s[:m])).all(), ("as_oh", what)
+	i = int(rng.randint(0, n))
+	f, d = int(rng.randint(0, 6)), int(rng.randint(0, 2))
+	assert (cube.rotate(s[i], f, d) == orc.rotate(s[i], f, d)).all() and cube.is_solved(s[i]) == orc.is_solved(s[i]), ("rotate", what)
+	seed, depth, games, ws = int(rng.randint(0, 2 ** 31 - 1)), int(rng.randint(1, 40)), int(rng.randint(1, 60)), bool(rng.rand() < 0.5)
+	what.update(seed=seed, depth=depth, games=games, with_solved=ws)
+	np.random.seed(seed)
+	a = cube.scramble(depth, True)
+	b_states, b_oh = cube.sequence_scrambler(games, depth, ws)
+	np.random.seed(seed)
+	ra = orc.scramble(depth, True)
+	rb_states, rb_oh = orc.sequence_scrambler(games, depth, ws)
+	assert all((x == y).all() for x, y in zip(a, ra)), ("scramble", what)
+	assert (b_states == rb_states).all() and (b_oh.cpu().numpy() == rb_oh).all(), ("sequence_scrambler", what)
+	return what
+
+
+CASES = dict(cube20=case_cube20, sharded=case_sharded, host_surface=case_host_surface, cube686=case_cube686, astar=case_astar, astar_batch=case_astar_batch, mcts=case_mcts, mcts_batch=case_mcts_batch)
 
 if __name__ == "__main__":
 	ap = argparse.ArgumentParser()

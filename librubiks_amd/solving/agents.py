@@ -163,8 +163,12 @@ class RandomSearch(Agent):
 
 
 class BFS(Agent):
-	"""Breadth-first search over the 12-move graph (agents.py:92-129); every layer is one fan-out launch."""
+	"""Breadth-first search over the 12-move graph (agents.py:92-129).  The reference pops one state at a time and moves it
+	twelve times; here the children of up to `chunk` queued states come from ONE fan-out launch (with the goal test), and the
+	reference's loop -- same order, same checks before every pop -- then runs over them, so `states`, the action queue and
+	len(agent) are the reference's."""
 	states = dict()
+	chunk = 16_384                          # queued states expanded per launch (their 12 x chunk children are held on the host)
 
 	def search(self, state: np.ndarray, time_limit: float = None, max_states: int = None) -> bool:
 		time_limit, max_states = self.reset(time_limit, max_states)
@@ -173,23 +177,29 @@ class BFS(Agent):
 		if cube.is_solved(state):
 			return True
 		self.states = {state.tobytes(): (None, None)}          # state -> (predecessor key, action)
-		frontier = deque([state])
-		while frontier and time.perf_counter() - t0 < time_limit and len(self) < max_states:
-			parent = frontier.popleft()
-			pkey = parent.tobytes()
-			children, solved = cube.expand(parent[None], return_solved=True)
-			for a in range(cube.action_dim):
-				ckey = children[a].tobytes()
-				if ckey in self.states:
-					continue
-				if solved[a]:
-					self.action_queue.appendleft(a)
-					while self.states[pkey][0] is not None:
-						pkey, act = self.states[pkey]
-						self.action_queue.appendleft(act)
-					return True
-				self.states[ckey] = (pkey, a)
-				frontier.append(children[a])
+		queue = deque([np.ascontiguousarray(state, dtype=np.int8)])
+		while queue and time.perf_counter() - t0 < time_limit and len(self) < max_states:
+			# the states that will be popped next, in order; a first-in-first-out queue only ever grows at the far end, so the
+			# children of its head do not depend on what the loop below appends
+			head = [queue[i] for i in range(min(len(queue), self.chunk, max(1, (max_states - len(self)) // 11 + 1)))]
+			children, solved = cube.expand(np.array(head), return_solved=True)
+			for j in range(len(head)):
+				if not (time.perf_counter() - t0 < time_limit and len(self) < max_states):      # agents.py:105, before every pop
+					return False
+				pkey = queue.popleft().tobytes()
+				for a in range(cube.action_dim):
+					child = children[12 * j + a]
+					ckey = child.tobytes()
+					if ckey in self.states:
+						continue
+					if solved[12 * j + a]:
+						self.action_queue.appendleft(a)
+						while self.states[pkey][0] is not None:
+							pkey, act = self.states[pkey]
+							self.action_queue.appendleft(act)
+						return True
+					self.states[ckey] = (pkey, a)
+					queue.append(child.copy())                      # (a view would keep the whole launch's children alive)
 		return False
 
 	def __str__(self):

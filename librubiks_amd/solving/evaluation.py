@@ -123,13 +123,13 @@ class Evaluator:
 		starts = np.array(starts, dtype=np.int8).reshape(-1, 20)
 		total = len(starts)
 		res, states, times = np.full(total, -1, np.int64), np.zeros(total, np.int64), np.zeros(total)
-		engines = {}
+		b, b_games = None, 0
 		for lo in range(0, total, self.batch_games):
 			hi = min(total, lo + self.batch_games)
 			n = hi - lo
-			if n not in engines:
-				engines = {n: self._batch_agent(agent, n)}        # at most one engine alive: its pools are n x max_states nodes
-			b = engines[n]
+			if n != b_games:                                          # (the last group may be smaller)
+				b = None                                              # at most one engine alive: its pools are n x max_states nodes
+				b, b_games = self._batch_agent(agent, n), n
 			t0 = time.perf_counter()
 			solved, seen = self._run_batch(b, starts[lo:hi], t0)
 			for i in range(n):

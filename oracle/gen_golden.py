@@ -374,6 +374,7 @@ def evaluator_traces():
 		"mcts_graph": dict(seed=33, games=4, depths=[2, 4, 5], max_states=4_000, agent=lambda: agents.MCTS(PolicyStubNet(), c=5.0, search_graph=True)),
 		"mcts": dict(seed=36, games=3, depths=[2, 4], max_states=3_000, agent=lambda: agents.MCTS(StubNet(), c=5.0, search_graph=False)),
 		"bfs": dict(seed=34, games=3, depths=[1, 2, 3], max_states=3_000, agent=lambda: agents.BFS()),
+		"bfs_budget": dict(seed=37, games=2, depths=[4, 7], max_states=5_000, agent=lambda: agents.BFS()),      # the budget ends the deeper games mid-layer
 	}
 	for tag, c in cases.items():
 		agent = c["agent"]()

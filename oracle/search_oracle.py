@@ -140,6 +140,42 @@ def _values(net, states: np.ndarray) -> np.ndarray:
 
 
 # ----------------------------------------------------------------------------------------------------------------
+class BFSOracle:
+	"""agents.py:92-129: first-in-first-out search over the 12-move graph, bounded by the number of states seen (the reference's
+	time limit is not restated: traces are captured with max_states alone)."""
+
+	def __init__(self):
+		self.states, self.action_queue = {}, deque()
+
+	def __len__(self):
+		return len(self.states)                                              # agents.py:128-129
+
+	def search(self, start: np.ndarray, max_states: int) -> bool:
+		self.states, self.action_queue = {}, deque()
+		if orc.is_solved(start):
+			return True
+		self.states = {start.tobytes(): (None, None)}                        # agents.py:103
+		queue = deque([start])
+		while len(self) < max_states:                                        # agents.py:105
+			state = queue.popleft()
+			key = state.tobytes()
+			for a in range(12):
+				child = orc.rotate(state, a // 2, 1 - a % 2)
+				ckey = child.tobytes()
+				if ckey in self.states:
+					continue
+				if orc.is_solved(child):                                     # agents.py:113-118: walk the predecessors back to the start
+					self.action_queue.appendleft(a)
+					while self.states[key][0] is not None:
+						self.action_queue.appendleft(self.states[key][1])
+						key = self.states[key][0]
+					return True
+				self.states[ckey] = (key, a)
+				queue.append(child)
+		return False
+
+
+# ----------------------------------------------------------------------------------------------------------------
 class AStarOracle:
 	"""agents.py:171-413.  Node arrays are 1-based like the reference's (index 0 unused)."""
 

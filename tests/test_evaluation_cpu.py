@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from oracle import cube_oracle as orc
-from oracle.search_oracle import AStarOracle, MCTSOracle, NoisyStubNet, PolicyStubNet, StubNet
+from oracle.search_oracle import AStarOracle, BFSOracle, MCTSOracle, NoisyStubNet, PolicyStubNet, StubNet
 
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "evaluator_trace.npz"))
 
@@ -22,7 +22,8 @@ CASES = {
 	"astar_deep": lambda: AStarOracle(StubNet(), 0.5, 10),
 	"mcts_graph": lambda: MCTSOracle(PolicyStubNet(), 5.0, True),
 	"mcts": lambda: MCTSOracle(StubNet(), 5.0, False),
-	"bfs": None,
+	"bfs": BFSOracle,
+	"bfs_budget": BFSOracle,
 }
 
 
@@ -44,7 +45,7 @@ def test_scrambles_are_drawn_game_by_game(tag):
 	assert (drawn_starts(tag) == GOLD[f"{tag}_starts"]).all()
 
 
-@pytest.mark.parametrize("tag", [t for t, make in CASES.items() if make is not None])
+@pytest.mark.parametrize("tag", list(CASES))
 def test_oracle_replays_the_reference_evaluator(tag):
 	_, games, max_states, _ = (int(x) for x in GOLD[f"{tag}_params"])
 	res, states = [], []

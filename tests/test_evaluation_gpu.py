@@ -24,6 +24,7 @@ CASES = {
 	"mcts_graph": lambda: agents.MCTS(PolicyStubNet(), 5.0, True, capacity=4_000),
 	"mcts": lambda: agents.MCTS(StubNet(), 5.0, False, capacity=4_000),
 	"bfs": lambda: agents.BFS(),
+	"bfs_budget": lambda: agents.BFS(),
 }
 
 
@@ -43,7 +44,7 @@ def test_games_one_after_the_other(tag):
 	assert (times > 0).all()
 
 
-@pytest.mark.parametrize("tag", [t for t in CASES if t != "bfs"])
+@pytest.mark.parametrize("tag", [t for t in CASES if not t.startswith("bfs")])
 @pytest.mark.parametrize("batch_games", [64, 5])
 def test_games_in_lock_step(tag, batch_games):
 	"""All games at once, and in groups of five with a smaller last group."""
