@@ -377,8 +377,8 @@ def test_a_backup_without_an_expansion_is_refused():
 def test_hipgraph_is_kept_from_search_to_search():
 	"""The captured step holds addresses and by-value scalars, nothing of the trees: searches on an unchanged engine and net
 	replay ONE graph (single-tree agent and batch); another net or a grown pool capture once more; all equal the oracle."""
-	tree = MCTS(PolicyStubNet(), 1.5, True, capacity=6_000, use_hipgraph=True)
-	tree.max_capacity = 24_000
+	tree = MCTS(PolicyStubNet(), 1.5, True, capacity=1_500, use_hipgraph=True)
+	tree.max_capacity = 6_000
 	def run(net_of, seed, depth, budget):
 		np.random.seed(seed)
 		start, _, _ = orc.scramble(depth, True)
@@ -390,17 +390,17 @@ def test_hipgraph_is_kept_from_search_to_search():
 		for k in ("states", "neighbors", "N", "W", "L", "V", "P"):
 			assert (a[k][1:n + 1] == getattr(ref, k)[1:n + 1]).all(), (k, seed)
 		assert list(tree.action_queue) == list(ref.action_queue)
-	for seed, depth, budget in ((1, 4, 6_000), (2, 9, 3_000), (3, 2, 6_000), (4, 12, 5_000)):
+	for seed, depth, budget in ((1, 4, 1_500), (2, 9, 900), (3, 2, 1_500), (4, 12, 1_200)):
 		run(PolicyStubNet, seed, depth, budget)
 	assert tree._batch.captures == 1
 	tree.net = StubNet()
-	run(StubNet, 5, 8, 4_000)
-	run(StubNet, 6, 10, 6_000)
+	run(StubNet, 5, 8, 1_000)
+	run(StubNet, 6, 10, 1_500)
 	assert tree._batch.captures == 2
-	run(StubNet, 7, 14, 20_000)                                        # grows on the way (unless solved early): one capture per growth
+	run(StubNet, 7, 14, 5_000)                                        # grows on the way (unless solved early): one capture per growth
 	grown = tree.grown
 	assert tree._batch.captures == 2 + grown
-	run(StubNet, 8, 14, 20_000)
+	run(StubNet, 8, 14, 5_000)
 	assert tree._batch.captures == 2 + grown + tree.grown
 	# a batch, searched three times with different starts and budgets
 	T = 5
