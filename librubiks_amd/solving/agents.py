@@ -617,10 +617,11 @@ class AStar(DeepAgent):
 	def _export(self):
 		if self._cache is None:
 			n = self._n
-			states = np.zeros((n + 1, 20), np.int8)
-			G = np.zeros(n + 1, np.float64)
-			parents = np.zeros(n + 1, np.int64)
-			pact = np.zeros(n + 1, np.int64)
+			rows = max(n + 1, 1000)            # the reference's arrays start with 1000 rows (agents.py:385-394); its tests write G of a reset agent
+			states = np.zeros((rows, 20), np.int8)
+			G = np.zeros(rows, np.float64)
+			parents = np.zeros(rows, np.int64)
+			pact = np.zeros(rows, np.int64)
 			if n and self._h is not None:
 				_ffi.check(_ffi.lib().rk_astar_export(
 					self._h, 1, n, states[1:].ctypes.data, G[1:].ctypes.data, parents[1:].ctypes.data, pact[1:].ctypes.data,

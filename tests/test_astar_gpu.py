@@ -181,3 +181,24 @@ def test_hipgraph_is_kept_from_search_to_search():
 	assert grown >= 1 and agent.captures == 3 + grown
 	run(agent, NoisyStubNet, 0.05, 9, 14, 70_000)                     # the grown engine's graph serves the next search
 	assert agent.grown == 0 and agent.captures == 3 + grown
+
+
+def test_reset_agent_and_cost_like_the_reference_tests():
+	"""ref:tests/test_agents.py:100-112 and :136-145: a reset agent has no indices and no open queue, its arrays can be written
+	(1000 rows from the start, ref:solving/agents.py:385-394), and cost() is lambda * G + (-value) for the given states."""
+	net = TinyNet().cuda().eval()
+	agent = AStar(net, lambda_=1, expansions=2)
+	np.random.seed(2)
+	state, _, _ = cube.scramble(2, force_not_solved=True)
+	agent.search(state, time_limit=1)
+	agent.reset("Tue", "Herlau")
+	assert not len(agent.indices) and not len(agent.open_queue) and len(agent) == 0
+	games = 5
+	states, _ = cube.sequence_scrambler(games, 1, True)
+	agent.reset(1, 1)
+	for i, _ in enumerate(states):
+		agent.G[i] = 1
+	cost = agent.cost(states, i)
+	assert cost.shape == (games,)
+	H = -net(cube.as_oh(states), policy=False, value=True).cpu().squeeze().detach().numpy()
+	assert cost.dtype == np.float64 and (cost == np.float64(1.0) + H).all()
