@@ -434,6 +434,7 @@ class AStar(DeepAgent):
 		self.use_hipgraph = (self.expansions <= 50) if use_hipgraph == "auto" else bool(use_hipgraph)
 		self._h = None
 		self._h_cap = 0
+		self._h_expansions = 0
 		self._n = 0
 		self._root = None
 		self._cache = None
@@ -448,12 +449,12 @@ class AStar(DeepAgent):
 
 	# -- engine lifetime ------------------------------------------------------------------------------------
 	def _engine(self, capacity: int):
-		if self._h is not None and self._h_cap >= capacity:
+		if self._h is not None and self._h_cap >= capacity and self._h_expansions == self.expansions:
 			return self._h
 		self._free()
 		h = C.c_void_p()
 		_ffi.check(_ffi.lib().rk_astar_create(C.byref(h), capacity, self.expansions))
-		self._h, self._h_cap = h, capacity
+		self._h, self._h_cap, self._h_expansions = h, capacity, self.expansions      # (an engine is built for one batch size)
 		return h
 
 	def _free(self):

@@ -202,3 +202,18 @@ def test_reset_agent_and_cost_like_the_reference_tests():
 	assert cost.shape == (games,)
 	H = -net(cube.as_oh(states), policy=False, value=True).cpu().squeeze().detach().numpy()
 	assert cost.dtype == np.float64 and (cost == np.float64(1.0) + H).all()
+
+
+def test_changing_expansions_between_searches():
+	"""An engine is built for one batch size: another `expansions` on the same agent builds another engine (and, in hipGraph
+	mode, captures again); results are the oracle's for the new size."""
+	np.random.seed(21)
+	start, _, _ = orc.scramble(9, True)
+	for graph in (False, True):
+		agent = AStar(StubNet(), 0.2, 10, capacity=20_000, use_hipgraph=graph)
+		for n in (10, 64, 3, 64):
+			agent.expansions = n
+			ref = AStarOracle(StubNet(), 0.2, n)
+			assert agent.search(start, None, 15_000) == ref.search(start, 15_000), (graph, n)
+			_check_against(agent, *ref.arrays(), ref.action_queue)
+		assert agent.captures == (4 if graph else 0)
