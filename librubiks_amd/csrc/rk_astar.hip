@@ -1422,20 +1422,32 @@ int rk_astar_grow(rk_astar_t *h, size_t new_capacity, void *stream)
 		(void)hipGetLastError();
 		return fail(RK_ECAPACITY, "rk_astar_grow: no device memory for a pool of %zu states", new_capacity);
 	}
-	RK_HIP(hipMemcpyAsync(d.states, old.states, C1_old * STATE_BYTES, hipMemcpyDeviceToDevice, st));
-	RK_HIP(hipMemcpyAsync(d.G, old.G, C1_old * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-	RK_HIP(hipMemcpyAsync(d.parents, old.parents, C1_old * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-	RK_HIP(hipMemcpyAsync(d.pact, old.pact, C1_old, hipMemcpyDeviceToDevice, st));
-	RK_HIP(hipMemcpyAsync(d.prank, old.prank, C1_old, hipMemcpyDeviceToDevice, st));
-	RK_HIP(hipMemsetAsync(d.table, 0, (size_t)t * sizeof(uint32_t), st));
-	RK_HIP(hipMemsetAsync(d.mark, 0xFF, C1 * sizeof(uint32_t), st));        // between iterations every mark is NO_MARK
-	for (int j = 0; j < old.q.levels; j++)                                  // a level that moved: both halves as they are
-		for (int k = 0; k < 2; k++)
-			if (d.q.buf[j][k] != old.q.buf[j][k])
-				RK_HIP(hipMemcpyAsync(d.q.buf[j][k], old.q.buf[j][k], (size_t)old.q.cap[j] * sizeof(Rec), hipMemcpyDeviceToDevice, st));
-	hipLaunchKernelGGL(k_astar_rehash, dim3(std::min<unsigned>(blocks(C1_old), 4096u)), dim3(256), 0, st, d);
-	RK_HIP(hipGetLastError());
-	RK_HIP(hipStreamSynchronize(st));
+	// the copies and the rehash; an error in here leaves the engine as it was (the new arrays are given back)
+	auto fill = [&]() -> hipError_t {
+		#define RK_TRY(call) do { const hipError_t e_ = (call); if (e_ != hipSuccess) return e_; } while (0)
+		RK_TRY(hipMemcpyAsync(d.states, old.states, C1_old * STATE_BYTES, hipMemcpyDeviceToDevice, st));
+		RK_TRY(hipMemcpyAsync(d.G, old.G, C1_old * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+		RK_TRY(hipMemcpyAsync(d.parents, old.parents, C1_old * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+		RK_TRY(hipMemcpyAsync(d.pact, old.pact, C1_old, hipMemcpyDeviceToDevice, st));
+		RK_TRY(hipMemcpyAsync(d.prank, old.prank, C1_old, hipMemcpyDeviceToDevice, st));
+		RK_TRY(hipMemsetAsync(d.table, 0, (size_t)t * sizeof(uint32_t), st));
+		RK_TRY(hipMemsetAsync(d.mark, 0xFF, C1 * sizeof(uint32_t), st));       // between iterations every mark is NO_MARK
+		for (int j = 0; j < old.q.levels; j++)                                 // a level that moved: both halves as they are
+			for (int k = 0; k < 2; k++)
+				if (d.q.buf[j][k] != old.q.buf[j][k])
+					RK_TRY(hipMemcpyAsync(d.q.buf[j][k], old.q.buf[j][k], (size_t)old.q.cap[j] * sizeof(Rec), hipMemcpyDeviceToDevice, st));
+		hipLaunchKernelGGL(k_astar_rehash, dim3(std::min<unsigned>(blocks(C1_old), 4096u)), dim3(256), 0, st, d);
+		RK_TRY(hipGetLastError());
+		RK_TRY(hipStreamSynchronize(st));
+		#undef RK_TRY
+		return hipSuccess;
+	};
+	if (const hipError_t e = fill(); e != hipSuccess) {
+		(void)hipStreamSynchronize(st);                                        // nothing may still write into what is freed next
+		for (void *q : fresh) (void)hipFree(q);
+		(void)hipGetLastError();
+		return fail(RK_EHIP, "rk_astar_grow: %s", hipGetErrorString(e));
+	}
 	for (void *q : stale) {
 		for (size_t i = 0; i < h->allocs.size(); i++) if (h->allocs[i] == q) { h->allocs.erase(h->allocs.begin() + (long)i); break; }
 		(void)hipFree(q);

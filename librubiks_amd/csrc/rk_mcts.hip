@@ -800,30 +800,42 @@ int rk_mcts_grow(rk_mcts_t *h, size_t new_capacity, size_t new_max_path, const l
 		(void)hipGetLastError();
 		return fail(RK_ECAPACITY, "rk_mcts_grow: no device memory for %d trees of %zu states", d.T, new_capacity);
 	}
-	if (pool) {
-		RK_HIP(hipMemsetAsync(d.nodes, 0, rows * NODE_BYTES, st));         // rows beyond the old pool: leaves, all statistics zero
-		RK_HIP(hipMemsetAsync(d.table, 0, T * (size_t)ts * sizeof(uint32_t), st));
-		RK_HIP(strided_copy(d.states, (size_t)d.cap1 * STATE_BYTES, old.states, (size_t)old.cap1 * STATE_BYTES, (size_t)old.cap1 * STATE_BYTES, T, st));
-		RK_HIP(strided_copy(d.nodes, (size_t)d.cap1 * NODE_BYTES, old.nodes, (size_t)old.cap1 * NODE_BYTES, (size_t)old.cap1 * NODE_BYTES, T, st));
-	}
-	if (paths) {
-		RK_HIP(strided_copy(d.path_nodes, new_max_path * 4, old.path_nodes, (size_t)old.max_path * 4, (size_t)old.max_path * 4, T, st));
-		RK_HIP(strided_copy(d.path_actions, new_max_path, old.path_actions, (size_t)old.max_path, (size_t)old.max_path, T, st));
-	}
-	if (pool) {
-		hipLaunchKernelGGL(k_mcts_rehash, dim3(std::min<unsigned>(nblocks(old.cap1), 4096u), d.T), dim3(256), 0, st, d);
-		RK_HIP(hipGetLastError());
-	}
 	std::vector<int32_t> ms(T);
 	for (size_t t = 0; t < T; t++) {
 		long long m = h_max_states ? h_max_states[t] : (long long)new_capacity;
 		if (m > (long long)new_capacity) m = (long long)new_capacity;
 		ms[t] = (int32_t)(m < 0 ? 0 : m);
 	}
-	RK_HIP(hipMemcpyAsync(h->max_states_dev, ms.data(), T * sizeof(int32_t), hipMemcpyHostToDevice, st));
-	hipLaunchKernelGGL(k_mcts_set_budgets, dim3(nblocks(T)), dim3(256), 0, st, d, h->max_states_dev);
-	RK_HIP(hipGetLastError());
-	RK_HIP(hipStreamSynchronize(st));                                      // `ms` and the old arrays go away now
+	// the copies, the rehash and the budgets; an error in here leaves the engine as it was (the new arrays are given back)
+	auto fill = [&]() -> hipError_t {
+		#define RK_TRY(call) do { const hipError_t e_ = (call); if (e_ != hipSuccess) return e_; } while (0)
+		if (pool) {
+			RK_TRY(hipMemsetAsync(d.nodes, 0, rows * NODE_BYTES, st));     // rows beyond the old pool: leaves, all statistics zero
+			RK_TRY(hipMemsetAsync(d.table, 0, T * (size_t)ts * sizeof(uint32_t), st));
+			RK_TRY(strided_copy(d.states, (size_t)d.cap1 * STATE_BYTES, old.states, (size_t)old.cap1 * STATE_BYTES, (size_t)old.cap1 * STATE_BYTES, T, st));
+			RK_TRY(strided_copy(d.nodes, (size_t)d.cap1 * NODE_BYTES, old.nodes, (size_t)old.cap1 * NODE_BYTES, (size_t)old.cap1 * NODE_BYTES, T, st));
+		}
+		if (paths) {
+			RK_TRY(strided_copy(d.path_nodes, new_max_path * 4, old.path_nodes, (size_t)old.max_path * 4, (size_t)old.max_path * 4, T, st));
+			RK_TRY(strided_copy(d.path_actions, new_max_path, old.path_actions, (size_t)old.max_path, (size_t)old.max_path, T, st));
+		}
+		if (pool) {
+			hipLaunchKernelGGL(k_mcts_rehash, dim3(std::min<unsigned>(nblocks(old.cap1), 4096u), d.T), dim3(256), 0, st, d);
+			RK_TRY(hipGetLastError());
+		}
+		RK_TRY(hipMemcpyAsync(h->max_states_dev, ms.data(), T * sizeof(int32_t), hipMemcpyHostToDevice, st));
+		hipLaunchKernelGGL(k_mcts_set_budgets, dim3(nblocks(T)), dim3(256), 0, st, d, h->max_states_dev);
+		RK_TRY(hipGetLastError());
+		RK_TRY(hipStreamSynchronize(st));                                  // `ms` and the old arrays go away now
+		#undef RK_TRY
+		return hipSuccess;
+	};
+	if (const hipError_t e = fill(); e != hipSuccess) {
+		(void)hipStreamSynchronize(st);                                    // nothing may still write into what is freed next
+		for (void *q : fresh) (void)hipFree(q);
+		(void)hipGetLastError();
+		return fail(RK_EHIP, "rk_mcts_grow: %s", hipGetErrorString(e));
+	}
 	auto drop = [&](void *q) {
 		for (size_t i = 0; i < h->allocs.size(); i++) if (h->allocs[i] == q) { h->allocs.erase(h->allocs.begin() + (long)i); break; }
 		(void)hipFree(q);
