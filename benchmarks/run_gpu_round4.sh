@@ -49,6 +49,9 @@ search)
 	step 500 python benchmarks/astar_small.py > $O/astar_small.json 2> $O/astar_small.err; cut -c1-300 $O/astar_small.json
 	step 300 python benchmarks/grow_cost.py 2> $O/grow_cost.err | grep '^{' > $O/grow_cost.json; cut -c1-300 $O/grow_cost.json
 	;;
+protocol)
+	step 900 python benchmarks/reference_protocol.py 2> $O/reference_protocol.err > $O/reference_protocol.json; cut -c1-600 $O/reference_protocol.json; tail -3 $O/reference_protocol.err
+	;;
 evaluator)
 	step 300 python benchmarks/graph_kept.py 2> $O/graph_kept.err | grep '^{' > $O/graph_kept.json; cut -c1-400 $O/graph_kept.json
 	step 900 python benchmarks/evaluator.py 2> $O/evaluator.err | grep '^{' > $O/evaluator.json; cut -c1-700 $O/evaluator.json

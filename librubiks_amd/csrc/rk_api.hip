@@ -69,6 +69,35 @@ struct DevBuf {
 // resets the slot cursor when a *_host entry starts (slots are handed out in call order, so sizes stay matched)
 struct ScratchScope { ScratchScope() { g_scratch_next = 0; } };
 
+// SMALL host calls go zero-copy: one page-locked, device-mapped buffer per host thread; the inputs are placed in it with a CPU
+// memcpy, the kernel reads and writes it over the bus, the outputs are copied out after ONE stream synchronisation.  A staged
+// call costs two or three hipMemcpyAsync round trips around its launch (29-37 us for one state through cube.rotate /
+// is_solved, profiles/r04_reference_protocol.json -- what reference code that loops over single states sees); this way it
+// costs the launch and the wait.  Larger calls keep the staged copies (the CPU memcpy into and out of the buffer would cost more
+// than the copies it saves).
+constexpr size_t ZERO_COPY_MAX = 256u << 10;          // staged bytes (inputs + outputs) up to which a call goes this way
+struct PinnedBuf { char *host = nullptr; char *dev = nullptr; int device = -1; bool tried = false; };
+thread_local PinnedBuf g_pinned;
+
+inline size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// the buffer of this thread for the current device, or nullptr (then the caller stages through device memory as before)
+PinnedBuf *pinned_buffer()
+{
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+	PinnedBuf &b = g_pinned;
+	if (b.host && b.device == dev) return &b;
+	if (b.tried && b.device == dev) return nullptr;
+	if (b.host) { (void)hipHostFree(b.host); b.host = b.dev = nullptr; }
+	b.device = dev; b.tried = true;
+	void *h = nullptr, *d = nullptr;
+	if (hipHostMalloc(&h, ZERO_COPY_MAX + 4096, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+	if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return nullptr; }
+	b.host = (char *)h; b.dev = (char *)d;
+	return &b;
+}
+
 }  // namespace
 
 extern "C" {
@@ -357,6 +386,17 @@ int rk_multi_rotate_host(int repr, const int8_t *h_states, const uint8_t *h_acti
 		if (h_actions[i] >= N_ACTIONS) return fail(RK_EINVAL, "rk_multi_rotate_host: action %u at row %zu out of range", h_actions[i], i);
 	const size_t sb = (size_t)state_bytes(repr);
 	hipStream_t st = (hipStream_t)stream;
+	if (up256(n * sb) * 2 + up256(n) <= ZERO_COPY_MAX) {
+		if (PinnedBuf *b = pinned_buffer()) {                 // zero-copy: see ZERO_COPY_MAX
+			const size_t o_act = up256(n * sb), o_out = o_act + up256(n);
+			memcpy(b->host, h_states, n * sb);
+			memcpy(b->host + o_act, h_actions, n);
+			if (int e = rk_multi_rotate(repr, (const int8_t *)b->dev, (const uint8_t *)(b->dev + o_act), (int8_t *)(b->dev + o_out), n, stream)) return e;
+			RK_HIP(hipStreamSynchronize(st));
+			memcpy(h_out, b->host + o_out, n * sb);
+			return RK_OK;
+		}
+	}
 	ScratchScope scope;
 	DevBuf in, act, out;
 	if (int e = in.alloc(n * sb)) return e;
@@ -379,6 +419,17 @@ int rk_expand12_host(int repr, const int8_t *h_parents, int8_t *h_children, uint
 	if (!h_parents || !h_children) return fail(RK_EINVAL, "rk_expand12_host: null pointer");
 	const size_t sb = (size_t)state_bytes(repr);
 	hipStream_t st = (hipStream_t)stream;
+	if (!h_stats && up256(n * sb) + up256(12 * n * sb) + up256(12 * n) <= ZERO_COPY_MAX) {     // (the counters are atomics: they stay in device memory)
+		if (PinnedBuf *b = pinned_buffer()) {                 // zero-copy: see ZERO_COPY_MAX
+			const size_t o_ch = up256(n * sb), o_fl = o_ch + up256(12 * n * sb);
+			memcpy(b->host, h_parents, n * sb);
+			if (int e = rk_expand12(repr, (const int8_t *)b->dev, (int8_t *)(b->dev + o_ch), h_solved ? (uint8_t *)(b->dev + o_fl) : nullptr, nullptr, n, stream)) return e;
+			RK_HIP(hipStreamSynchronize(st));
+			memcpy(h_children, b->host + o_ch, 12 * n * sb);
+			if (h_solved) memcpy(h_solved, b->host + o_fl, 12 * n);
+			return RK_OK;
+		}
+	}
 	ScratchScope scope;
 	DevBuf in, ch, fl, stt;
 	if (int e = in.alloc(n * sb)) return e;
@@ -405,6 +456,16 @@ int rk_multi_is_solved_host(int repr, const int8_t *h_states, uint8_t *h_flags, 
 	if (!h_states) return fail(RK_EINVAL, "rk_multi_is_solved_host: null pointer");
 	const size_t sb = (size_t)state_bytes(repr);
 	hipStream_t st = (hipStream_t)stream;
+	if (!h_stats && up256(n * sb) + up256(n) <= ZERO_COPY_MAX) {     // (the counters are atomics: they stay in device memory)
+		if (PinnedBuf *b = pinned_buffer()) {                 // zero-copy: see ZERO_COPY_MAX
+			const size_t o_fl = up256(n * sb);
+			memcpy(b->host, h_states, n * sb);
+			if (int e = rk_multi_is_solved(repr, (const int8_t *)b->dev, (uint8_t *)(b->dev + o_fl), nullptr, n, stream)) return e;
+			RK_HIP(hipStreamSynchronize(st));
+			if (h_flags) memcpy(h_flags, b->host + o_fl, n);
+			return RK_OK;
+		}
+	}
 	ScratchScope scope;
 	DevBuf in, fl, stt;
 	if (int e = in.alloc(n * sb)) return e;
@@ -439,6 +500,17 @@ int rk_apply_sequences_host(int repr, const uint8_t *h_actions, int depth, int g
 	for (size_t i = 0; i < nact; i++)
 		if (h_actions[i] >= N_ACTIONS) return fail(RK_EINVAL, "rk_apply_sequences_host: action %u out of range", h_actions[i]);
 	hipStream_t st = (hipStream_t)stream;
+	const size_t out_bytes = (size_t)games * rows * STATE_BYTES;
+	if (up256(nact) + up256(out_bytes) <= ZERO_COPY_MAX) {
+		if (PinnedBuf *b = pinned_buffer()) {                 // zero-copy: see ZERO_COPY_MAX
+			const size_t o_out = up256(nact);
+			if (nact) memcpy(b->host, h_actions, nact);
+			if (int e = rk_apply_sequences(repr, (const uint8_t *)b->dev, depth, games, with_solved, only_last, (int8_t *)(b->dev + o_out), stream)) return e;
+			RK_HIP(hipStreamSynchronize(st));
+			memcpy(h_out, b->host + o_out, out_bytes);
+			return RK_OK;
+		}
+	}
 	ScratchScope scope;
 	DevBuf act, out;
 	if (int e = act.alloc(nact)) return e;

@@ -419,7 +419,19 @@ def rotate(state: np.ndarray, face: int, direction: int) -> np.ndarray:
 	if _is_dev(state):
 		acts = torch.tensor([2 * face + (1 - direction)], dtype=torch.uint8, device=gpu)
 		return device.multi_rotate(state.reshape(1, *shape()).contiguous(), acts)[0]
-	return multi_rotate(np.asarray(state)[None], [face], [direction])[0]
+	if isinstance(state, torch.Tensor):
+		return multi_rotate(np.asarray(state)[None], [face], [direction])[0]
+	# one state from the host: straight to the library's host entry (what reference code that loops over `rotate` pays per call)
+	if not (0 <= face <= 5 and 0 <= direction <= 1):
+		raise IndexError("face must be in 0..5 and direction in 0..1")
+	_ffi.require_gpu()
+	src = np.ascontiguousarray(state, dtype=np.int8)
+	if src.size != _row_bytes():
+		raise ValueError(f"one state has shape {shape()}, got {src.shape}")
+	out = np.empty_like(src)
+	act = np.array([2 * face + (1 - direction)], dtype=np.uint8)
+	_ffi.check(_ffi.lib().rk_multi_rotate_host(_repr_id(), src.ctypes.data, act.ctypes.data, out.ctypes.data, 1, _ffi.stream_ptr()))
+	return out
 
 
 _SMALL = 4096     # host arrays up to this many states go straight through the library's *_host entries (no torch hop)
@@ -460,6 +472,14 @@ def expand(states: np.ndarray, return_solved: bool = False):
 	"""
 	_ffi.require_gpu()
 	dev_in = _is_dev(states)
+	if not isinstance(states, torch.Tensor) and 0 < len(states) <= _SMALL // 12:
+		# a few parents from the host (BFS, one-step agents): the library's host entry, no torch hop
+		src = np.ascontiguousarray(states, dtype=np.int8)
+		children = np.empty((12 * len(src), *src.shape[1:]), dtype=np.int8)
+		flags = np.empty(12 * len(src), dtype=np.uint8) if return_solved else None
+		_ffi.check(_ffi.lib().rk_expand12_host(_repr_id(), src.ctypes.data, children.ctypes.data, flags.ctypes.data if return_solved else None, None,
+		                                       len(src), _ffi.stream_ptr()))
+		return (children, flags.astype(bool)) if return_solved else children
 	children, solved = device.expand12(_to_dev_states(states), want_flags=return_solved)
 	if not dev_in:
 		children = _to_host(children)
@@ -547,8 +567,18 @@ def rev_actions(actions: np.ndarray) -> np.ndarray:
 # Scramble logic #   (cube.py:206-234)
 ##################
 def _apply(actions_dg: np.ndarray, with_solved: bool, only_last: bool) -> np.ndarray:
-	acts = torch.from_numpy(np.ascontiguousarray(actions_dg, dtype=np.uint8)).to(gpu)
-	return _to_host(device.apply_sequences(acts, with_solved, only_last))
+	acts = np.ascontiguousarray(actions_dg, dtype=np.uint8)
+	depth, games = acts.shape                   # with_solved: the first state of a game is the solved one, depth - 1 moves follow
+	rows = 1 if only_last else depth
+	if 0 < games * rows <= _SMALL and depth - int(with_solved) >= 0:
+		# small walks (one scramble): the library's host entry, no torch hop
+		if acts.size and int(acts.max()) >= 12:
+			raise IndexError(f"action code {int(acts.max())} outside 0..11")
+		out = np.empty((games * rows, 20), dtype=np.int8)
+		_ffi.check(_ffi.lib().rk_apply_sequences_host(REPR_2024, acts.ctypes.data, depth, games, int(with_solved), int(only_last),
+		                                              out.ctypes.data, _ffi.stream_ptr()))
+		return out
+	return _to_host(device.apply_sequences(torch.from_numpy(acts).to(gpu), with_solved, only_last))
 
 
 def scramble(depth: int, force_not_solved=False):
