@@ -231,7 +231,51 @@ def case_host_surface(rng):
 	return what
 
 
-CASES = dict(cube20=case_cube20, sharded=case_sharded, host_surface=case_host_surface, cube686=case_cube686, astar=case_astar, astar_batch=case_astar_batch, mcts=case_mcts, mcts_batch=case_mcts_batch)
+_LIVE = {}
+
+
+def case_reuse(rng):
+	"""Long-lived agents in hipGraph mode, searched again and again: the captured step is kept from search to search and must be
+	captured anew exactly when something it holds changes -- another net, another lambda, a pool that grew -- never go stale."""
+	what = {}
+	a = _LIVE.get("astar")
+	if a is None or rng.rand() < 0.05:
+		a = _LIVE["astar"] = dict(agent=AStar(StubNet(), 0.3, int(rng.choice([5, 40, 150])), capacity=6_000, use_hipgraph=True), net="stub", seed=0)
+	if rng.rand() < 0.3:                                             # swap the net (or only its noise)
+		a["net"], a["seed"] = str(rng.choice(["stub", "noisy"])), int(rng.randint(0, 3))
+		a["agent"].net = StubNet() if a["net"] == "stub" else NoisyStubNet(a["seed"])
+	if rng.rand() < 0.3:
+		a["agent"].lambda_ = float(rng.choice([0.02, 0.3, 1.0]))
+	agent = a["agent"]
+	budget = int(rng.randint(12 * agent.expansions + 50, 30_000))  # beyond 6 000: the pool grows in place (and stays grown)
+	start = _start(rng, int(rng.randint(2, 20)))
+	what["astar"] = dict(net=a["net"], noise=a["seed"], lam=agent.lambda_, N=agent.expansions, budget=budget, captures_before=agent.captures)
+	ref = AStarOracle(StubNet() if a["net"] == "stub" else NoisyStubNet(a["seed"]), agent.lambda_, agent.expansions)
+	assert agent.search(start, None, budget) == ref.search(start, budget), ("astar solved", what)
+	n = len(ref)
+	rs, rG, rp, ra = ref.arrays()
+	assert len(agent) == n and (agent.states[1:n + 1] == rs).all() and (agent.G[1:n + 1] == rG).all() and (agent.parents[2:n + 1] == rp).all() \
+	       and (agent.parent_actions[2:n + 1] == ra).all() and list(agent.action_queue) == list(ref.action_queue), ("astar arrays", what)
+	m = _LIVE.get("mcts")
+	if m is None or rng.rand() < 0.05:
+		tree = MCTS(StubNet(), float(rng.choice([0.6, 2.0, 50.0])), bool(rng.rand() < 0.5), capacity=1_500, use_hipgraph=True)
+		tree.max_capacity = 12_000
+		m = _LIVE["mcts"] = dict(agent=tree, net="stub")
+	if rng.rand() < 0.3:
+		m["net"] = str(rng.choice(["stub", "policy"]))
+		m["agent"].net = StubNet() if m["net"] == "stub" else PolicyStubNet()
+	tree = m["agent"]
+	budget = int(rng.randint(30, 5_000))
+	start = _start(rng, int(rng.randint(1, 16)))
+	what["mcts"] = dict(net=m["net"], c=tree.c, search_graph=tree.search_graph, budget=budget)
+	ref = MCTSOracle(StubNet() if m["net"] == "stub" else PolicyStubNet(), tree.c, tree.search_graph)
+	assert tree.search(start, None, budget) == ref.search(start, budget), ("mcts solved", what)
+	_tree_equal(tree._export(), ref, what)
+	assert list(tree.action_queue) == list(ref.action_queue), ("mcts queue", what)
+	return what
+
+
+CASES = dict(cube20=case_cube20, sharded=case_sharded, host_surface=case_host_surface, reuse=case_reuse, cube686=case_cube686, astar=case_astar, astar_batch=case_astar_batch, mcts=case_mcts, mcts_batch=case_mcts_batch)
 
 if __name__ == "__main__":
 	ap = argparse.ArgumentParser()
