@@ -423,8 +423,8 @@ long long rk_mcts_graph_path(rk_mcts_t *h, int tree, long long *h_actions, size_
 
 /* ---- host-pointer conveniences (allocate scratch, copy, launch, copy back, synchronise) ----
  * What reference code sees when it calls cube.rotate / multi_rotate / is_solved / scramble with NumPy arrays
- * (cube.py:41-56, :85-89, :206-216).  SMALL calls -- inputs and outputs together up to 256 KiB, i.e. about 6 000 20-byte
- * states through rk_multi_rotate_host or 1 000 parents through rk_expand12_host, without h_stats -- go ZERO-COPY: the arrays
+ * (cube.py:41-56, :85-89, :206-216).  SMALL calls -- inputs and outputs together up to 1 MiB, i.e. about 25 000 20-byte
+ * states through rk_multi_rotate_host or 3 800 parents through rk_expand12_host, without h_stats -- go ZERO-COPY: the arrays
  * pass through one page-locked, device-mapped buffer per host thread, the kernel reads and writes it over the bus, and the
  * call costs one launch and one stream synchronisation (one state: 17-21 us from Python against 29-37 us with staged copies,
  * profiles/r04_reference_protocol.json, r04_latency.json).  Larger calls, and calls that want the counters (atomics, kept in

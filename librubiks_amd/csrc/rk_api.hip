@@ -73,9 +73,10 @@ struct ScratchScope { ScratchScope() { g_scratch_next = 0; } };
 // memcpy, the kernel reads and writes it over the bus, the outputs are copied out after ONE stream synchronisation.  A staged
 // call costs two or three hipMemcpyAsync round trips around its launch (29-37 us for one state through cube.rotate /
 // is_solved, profiles/r04_reference_protocol.json -- what reference code that loops over single states sees); this way it
-// costs the launch and the wait.  Larger calls keep the staged copies (the CPU memcpy into and out of the buffer would cost more
-// than the copies it saves).
-constexpr size_t ZERO_COPY_MAX = 256u << 10;          // staged bytes (inputs + outputs) up to which a call goes this way
+// costs the launch and the wait (10 000 states through multi_rotate: 410 KB, about 70 us from Python against 100 with a torch
+// hop and staged copies).  Larger calls keep the staged copies (the CPU memcpy into and out of the buffer, and the kernel's
+// accesses over the bus, then cost more than the copy engines do).
+constexpr size_t ZERO_COPY_MAX = 1u << 20;            // staged bytes (inputs + outputs) up to which a call goes this way
 struct PinnedBuf { char *host = nullptr; char *dev = nullptr; int device = -1; bool tried = false; };
 thread_local PinnedBuf g_pinned;
 

@@ -434,7 +434,14 @@ def rotate(state: np.ndarray, face: int, direction: int) -> np.ndarray:
 	return out
 
 
-_SMALL = 4096     # host arrays up to this many states go straight through the library's *_host entries (no torch hop)
+#: Host arrays whose call moves up to this many bytes (inputs + outputs) go straight through the library's *_host entries, which pass
+#: them zero-copy through a page-locked, device-mapped buffer (rk_api.hip, ZERO_COPY_MAX: one launch, one wait, no torch hop).
+_ZERO_COPY_BYTES = 1 << 20
+
+
+def _small(n_in: int, n_out: int, extra: int = 0) -> bool:
+	"""n_in input states and n_out output states (plus `extra` bytes of actions / flags) fit the zero-copy path"""
+	return n_in > 0 and (n_in + n_out) * _row_bytes() + extra + 1024 <= _ZERO_COPY_BYTES      # (1 KiB: the buffer's parts are aligned)
 
 
 def _host_actions(faces, dirs, n: int) -> np.ndarray:
@@ -453,7 +460,7 @@ def multi_rotate(states: np.ndarray, faces: np.ndarray, directions: np.ndarray) 
 	n = len(states)
 	if n == 0:
 		return states.clone() if isinstance(states, torch.Tensor) else np.array(states, dtype=np.int8, copy=True)
-	if n <= _SMALL and not isinstance(states, torch.Tensor) and not _is_dev(faces) and not _is_dev(directions):
+	if _small(n, n, n) and not isinstance(states, torch.Tensor) and not _is_dev(faces) and not _is_dev(directions):
 		src = np.ascontiguousarray(states, dtype=np.int8)
 		acts = _host_actions(faces, directions, n)
 		out = np.empty_like(src)
@@ -472,7 +479,7 @@ def expand(states: np.ndarray, return_solved: bool = False):
 	"""
 	_ffi.require_gpu()
 	dev_in = _is_dev(states)
-	if not isinstance(states, torch.Tensor) and 0 < len(states) <= _SMALL // 12:
+	if not isinstance(states, torch.Tensor) and len(states) and _small(len(states), 12 * len(states), 12 * len(states)):
 		# a few parents from the host (BFS, one-step agents): the library's host entry, no torch hop
 		src = np.ascontiguousarray(states, dtype=np.int8)
 		children = np.empty((12 * len(src), *src.shape[1:]), dtype=np.int8)
@@ -500,7 +507,7 @@ def multi_is_solved(states: np.ndarray) -> np.ndarray:
 	_ffi.require_gpu()
 	if len(states) == 0:
 		return np.zeros(0, dtype=bool)
-	if len(states) <= _SMALL and not isinstance(states, torch.Tensor):
+	if _small(len(states), 0, len(states)) and not isinstance(states, torch.Tensor):
 		src = np.ascontiguousarray(states, dtype=np.int8)
 		flags = np.empty(len(src), dtype=np.uint8)
 		_ffi.check(_ffi.lib().rk_multi_is_solved_host(_repr_id(), src.ctypes.data, flags.ctypes.data, None, len(src), _ffi.stream_ptr()))
@@ -570,7 +577,7 @@ def _apply(actions_dg: np.ndarray, with_solved: bool, only_last: bool) -> np.nda
 	acts = np.ascontiguousarray(actions_dg, dtype=np.uint8)
 	depth, games = acts.shape                   # with_solved: the first state of a game is the solved one, depth - 1 moves follow
 	rows = 1 if only_last else depth
-	if 0 < games * rows <= _SMALL and depth - int(with_solved) >= 0:
+	if games * rows > 0 and games * rows * 20 + acts.size + 1024 <= _ZERO_COPY_BYTES and depth - int(with_solved) >= 0:
 		# small walks (one scramble): the library's host entry, no torch hop
 		if acts.size and int(acts.max()) >= 12:
 			raise IndexError(f"action code {int(acts.max())} outside 0..11")
