@@ -437,6 +437,9 @@ int rk_multi_is_solved_host(int repr, const int8_t *h_states, uint8_t *h_flags, 
                             size_t n, void *stream);
 int rk_apply_sequences_host(int repr, const uint8_t *h_actions, int depth, int games, int with_solved,
                             int only_last, int8_t *h_out, void *stream);
+/* cube.as_oh as reference code calls it (cube.py:130-133, :265-277): states from HOST memory, the one-hot written to DEVICE
+ * memory (`d_out`, 16-byte aligned, n x 480 or n x 288 elements of `out_dtype`), where the net reads it.  Synchronises. */
+int rk_as_oh_host(int repr, const int8_t *h_states, void *d_out, int out_dtype, size_t n, void *stream);
 
 #ifdef __cplusplus
 }

@@ -127,6 +127,7 @@ SIGNATURES = {
 	"rk_expand12_host": (_i, [_i, _vp, _vp, _vp, _vp, _sz, _vp]),
 	"rk_multi_is_solved_host": (_i, [_i, _vp, _vp, _vp, _sz, _vp]),
 	"rk_apply_sequences_host": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _vp]),
+	"rk_as_oh_host": (_i, [_i, _vp, _vp, _i, _sz, _vp]),
 }
 
 _lib = None

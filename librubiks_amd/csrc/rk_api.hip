@@ -523,4 +523,28 @@ int rk_apply_sequences_host(int repr, const uint8_t *h_actions, int depth, int g
 	return RK_OK;
 }
 
+int rk_as_oh_host(int repr, const int8_t *h_states, void *d_out, int out_dtype, size_t n, void *stream)
+{
+	if (int e = check_repr(repr)) return e;
+	if (n == 0) return RK_OK;
+	if (!h_states || !d_out) return fail(RK_EINVAL, "rk_as_oh_host: null pointer");
+	const size_t sb = (size_t)state_bytes(repr);
+	hipStream_t st = (hipStream_t)stream;
+	if (up256(n * sb) <= ZERO_COPY_MAX) {
+		if (PinnedBuf *b = pinned_buffer()) {                 // zero-copy: see ZERO_COPY_MAX
+			memcpy(b->host, h_states, n * sb);
+			if (int e = rk_as_oh(repr, (const int8_t *)b->dev, d_out, out_dtype, n, stream)) return e;
+			RK_HIP(hipStreamSynchronize(st));                 // the buffer belongs to the next call from here on
+			return RK_OK;
+		}
+	}
+	ScratchScope scope;
+	DevBuf in;
+	if (int e = in.alloc(n * sb)) return e;
+	RK_HIP(hipMemcpyAsync(in.p, h_states, n * sb, hipMemcpyHostToDevice, st));
+	if (int e = rk_as_oh(repr, (const int8_t *)in.p, d_out, out_dtype, n, stream)) return e;
+	RK_HIP(hipStreamSynchronize(st));
+	return RK_OK;
+}
+
 }  // extern "C"

@@ -522,6 +522,14 @@ def multi_is_solved(states: np.ndarray) -> np.ndarray:
 def as_oh(states: np.ndarray) -> torch.Tensor:
 	"""n states -> (n, 480) [or (n, 288)] float32 one-hot tensor on `librubiks_amd.gpu`; one state -> (1, ...)."""
 	_ffi.require_gpu()
+	if not isinstance(states, torch.Tensor):
+		src = np.ascontiguousarray(states, dtype=np.int8)
+		n = src.size // _row_bytes()
+		if src.size == n * _row_bytes() and _small(n, 0):
+			# states from the host: the library reads them zero-copy and writes the one-hot where the net will read it (no torch hop)
+			out = torch.empty((n, get_oh_shape()), dtype=torch.float32, device=gpu)
+			_ffi.check(_ffi.lib().rk_as_oh_host(_repr_id(), src.ctypes.data, out.data_ptr(), _ffi.OH_F32, n, _ffi.stream_ptr()))
+			return out
 	t = _to_dev_states(states)
 	if t.dim() == len(shape()):
 		t = t.unsqueeze(0)
