@@ -265,6 +265,43 @@ def test_empty_and_errors():
 	assert (got == orc.sequence_states(seq // 2, 1 - seq % 2, False)).all()
 
 
+@pytest.mark.parametrize("n", [1, 777, 26_000, 70_001])
+def test_host_entries_zero_copy_and_staged(n):
+	"""The rk_*_host entries on both sides of the zero-copy limit (1 MiB of arrays per call: below it the arrays pass through a
+	page-locked, device-mapped buffer, above it through device scratch) -- same results; and rk_as_oh_host (host states in,
+	device one-hot out) in both representations and output types."""
+	lib = _ffi.lib()
+	p = random_walk_c(n, 9, seed=n)
+	p[n // 2] = orc.SOLVED
+	acts = np.random.RandomState(n).randint(0, 12, n).astype(np.uint8)
+	out, fl = np.empty_like(p), np.empty(n, np.uint8)
+	_ffi.check(lib.rk_multi_rotate_host(0, p.ctypes.data, acts.ctypes.data, out.ctypes.data, n, None))
+	assert (out == c_oracle.multi_rotate(p, acts)).all()
+	_ffi.check(lib.rk_multi_is_solved_host(0, p.ctypes.data, fl.ctypes.data, None, n, None))
+	assert (fl.astype(bool) == orc.multi_is_solved(p)).all()
+	st = np.zeros(2, np.int64)
+	_ffi.check(lib.rk_multi_is_solved_host(0, p.ctypes.data, fl.ctypes.data, st.ctypes.data, n, None))     # with the counters: staged
+	assert st.tolist() == [int(orc.multi_is_solved(p).sum()), int(np.argmax(orc.multi_is_solved(p)))]
+	m = min(n, 9_000)
+	ch, cf = np.empty((12 * m, 20), np.int8), np.empty(12 * m, np.uint8)
+	_ffi.check(lib.rk_expand12_host(0, p.ctypes.data, ch.ctypes.data, cf.ctypes.data, None, m, None))
+	ref_ch, ref_fl = c_oracle.expand12(p[:m])
+	assert (ch == ref_ch).all() and (cf == ref_fl).all()
+	for dtype, code in ((torch.float32, _ffi.OH_F32), (torch.bfloat16, _ffi.OH_BF16)):
+		oh = torch.empty((n, 480), dtype=dtype, device="cuda")
+		_ffi.check(lib.rk_as_oh_host(0, p.ctypes.data, oh.data_ptr(), code, n, None))
+		assert (oh.float().cpu().numpy() == c_oracle.as_oh(p)).all()
+	assert (cube.as_oh(p).cpu().numpy() == c_oracle.as_oh(p)).all() and cube.as_oh(p[0]).shape == (1, 480)
+	k = min(n, 5_000)
+	s686 = orc.solved_686()[None].repeat(k, axis=0)
+	s686 = c_oracle.multi_rotate686(s686, acts[:k])
+	oh = torch.empty((k, 288), dtype=torch.float32, device="cuda")
+	_ffi.check(lib.rk_as_oh_host(1, s686.ctypes.data, oh.data_ptr(), _ffi.OH_F32, k, None))
+	assert (oh.cpu().numpy() == orc.as_oh686(s686)).all()
+	assert lib.rk_as_oh_host(0, None, oh.data_ptr(), _ffi.OH_F32, 3, None) == -1 and lib.rk_as_oh_host(0, p.ctypes.data, oh.data_ptr(), 7, 3, None) == -1
+	assert lib.rk_as_oh_host(0, None, None, _ffi.OH_F32, 0, None) == 0
+
+
 def test_device_tensors_round_trip_through_dropin_surface():
 	p = random_walk(500, 7, seed=21)
 	dp = dev(p)
