@@ -445,10 +445,15 @@ def _small(n_in: int, n_out: int, extra: int = 0) -> bool:
 
 
 def _host_actions(faces, dirs, n: int) -> np.ndarray:
-	f = np.asarray(faces).astype(np.int64).ravel()
-	d = np.asarray(dirs).astype(np.int64).ravel()
+	f, d = np.asarray(faces).ravel(), np.asarray(dirs).ravel()
 	if len(f) != n or len(d) != n:
 		raise IndexError(f"need {n} faces and directions, got {len(f)} and {len(d)}")
+	if f.dtype == np.uint8 and d.dtype == np.uint8:
+		# what iter_actions() hands out: no negative values to look for, and the arithmetic stays in bytes (d <= 1 keeps 1 - d in range)
+		if n and (f.max() > 5 or d.max() > 1):
+			raise IndexError("face must be in 0..5 and direction in 0..1")
+		return 2 * f + (1 - d)
+	f, d = f.astype(np.int64, copy=False), d.astype(np.int64, copy=False)
 	if n and (f.min() < 0 or f.max() > 5 or d.min() < 0 or d.max() > 1):
 		raise IndexError("face must be in 0..5 and direction in 0..1")
 	return (2 * f + (1 - d)).astype(np.uint8)
