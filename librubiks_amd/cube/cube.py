@@ -456,7 +456,7 @@ def _host_actions(faces, dirs, n: int) -> np.ndarray:
 	f, d = f.astype(np.int64, copy=False), d.astype(np.int64, copy=False)
 	if n and (f.min() < 0 or f.max() > 5 or d.min() < 0 or d.max() > 1):
 		raise IndexError("face must be in 0..5 and direction in 0..1")
-	return (2 * f + (1 - d)).astype(np.uint8)
+	return 2 * f.astype(np.uint8) + (1 - d.astype(np.uint8))          # (validated: the arithmetic can stay in bytes)
 
 
 def multi_rotate(states: np.ndarray, faces: np.ndarray, directions: np.ndarray) -> np.ndarray:
