@@ -73,6 +73,12 @@ int rk_set_pacing(int mode);
  *               (maps.py:107-145).   RK_REPR_686: uint8 (12,48) sticker-slot permutation,
  *               new[slot] = old[perm[a][slot]], slot = 8*face+pos (cube.py:330-347). */
 int rk_tables(int repr, uint8_t *h_out);
+/* The six face definitions the tables are generated from, in the order F, B, T, D, L, R, written to HOST memory as uint8 (6,14):
+ * [0:4] ring of corner slots and [4:8] ring of side slots a positive turn cycles (ring[j] -> ring[j+1]), [8] the corner
+ * orientation that stays while the other two swap, [9] 1 if the turn flips side orientations (maps.py:74-98 `Actions`), [10:14]
+ * the face's four neighbours in positive direction (maps.py:149-156 `neighbors_686`).  What `librubiks.cube.maps` exposes as
+ * `Actions` / `neighbors_686`; the drop-in's maps.py rebuilds both from this entry. */
+int rk_face_definitions(uint8_t *h_out);
 /* Solved state in HOST memory: int8[20] (cube.py:58-65) or int8[288] (cube.py:67-71). */
 int rk_solved(int repr, int8_t *h_out);
 

@@ -30,6 +30,7 @@ SIGNATURES = {
 	"rk_init": (_i, [_i]),
 	"rk_set_pacing": (_i, [_i]),
 	"rk_tables": (_i, [_i, _vp]),
+	"rk_face_definitions": (_i, [_vp]),
 	"rk_solved": (_i, [_i, _vp]),
 	"rk_malloc": (_i, [C.POINTER(_vp), _sz]),
 	"rk_free": (_i, [_vp]),

@@ -130,6 +130,22 @@ int rk_tables(int repr, uint8_t *h_out)
 	return RK_OK;
 }
 
+int rk_face_definitions(uint8_t *h_out)
+{
+	if (!h_out) return fail(RK_EINVAL, "rk_face_definitions: null output");
+	for (int f = 0; f < 6; f++) {
+		uint8_t *o = h_out + 14 * f;
+		for (int j = 0; j < 4; j++) {
+			o[j] = FACES[f].corner[j];
+			o[4 + j] = FACES[f].edge[j];
+			o[10 + j] = NEIGHBOUR[f][j];
+		}
+		o[8] = FACES[f].fixed_ori;
+		o[9] = FACES[f].flip;
+	}
+	return RK_OK;
+}
+
 int rk_solved(int repr, int8_t *h_out)
 {
 	if (int e = check_repr(repr)) return e;

@@ -21,6 +21,7 @@ import torch
 
 from librubiks_amd import gpu, _ffi
 from librubiks_amd._ffi import REPR_2024, REPR_686, INT64_MAX
+from librubiks_amd.cube.maps import SimpleState, get_corner_pos, get_side_pos, get_tensor_map, get_633maps, neighbors_686  # noqa: F401  (cube.py:22)
 
 ####################
 # Action constants #   (cube.py:29-35)
@@ -444,6 +445,15 @@ def _small(n_in: int, n_out: int, extra: int = 0) -> bool:
 	return n_in > 0 and (n_in + n_out) * _row_bytes() + extra + 1024 <= _ZERO_COPY_BYTES      # (1 KiB: the buffer's parts are aligned)
 
 
+def _host_rows(states) -> np.ndarray:
+	"""Host states as a C-contiguous int8 array of whole rows (n, *shape()): what the *_host entries read n * row bytes from.  A
+	single state of shape (20,) has len 20 -- it must not be taken for 20 rows."""
+	src = np.ascontiguousarray(states, dtype=np.int8)
+	if src.ndim != 1 + len(shape()) or src.shape[1:] != shape():
+		raise ValueError(f"states must have shape (n, {', '.join(map(str, shape()))}), got {src.shape}")
+	return src
+
+
 def _host_actions(faces, dirs, n: int) -> np.ndarray:
 	f, d = np.asarray(faces).ravel(), np.asarray(dirs).ravel()
 	if len(f) != n or len(d) != n:
@@ -466,7 +476,7 @@ def multi_rotate(states: np.ndarray, faces: np.ndarray, directions: np.ndarray) 
 	if n == 0:
 		return states.clone() if isinstance(states, torch.Tensor) else np.array(states, dtype=np.int8, copy=True)
 	if _small(n, n, n) and not isinstance(states, torch.Tensor) and not _is_dev(faces) and not _is_dev(directions):
-		src = np.ascontiguousarray(states, dtype=np.int8)
+		src = _host_rows(states)
 		acts = _host_actions(faces, directions, n)
 		out = np.empty_like(src)
 		_ffi.check(_ffi.lib().rk_multi_rotate_host(_repr_id(), src.ctypes.data, acts.ctypes.data, out.ctypes.data, n, _ffi.stream_ptr()))
@@ -486,7 +496,7 @@ def expand(states: np.ndarray, return_solved: bool = False):
 	dev_in = _is_dev(states)
 	if not isinstance(states, torch.Tensor) and len(states) and _small(len(states), 12 * len(states), 12 * len(states)):
 		# a few parents from the host (BFS, one-step agents): the library's host entry, no torch hop
-		src = np.ascontiguousarray(states, dtype=np.int8)
+		src = _host_rows(states)
 		children = np.empty((12 * len(src), *src.shape[1:]), dtype=np.int8)
 		flags = np.empty(12 * len(src), dtype=np.uint8) if return_solved else None
 		_ffi.check(_ffi.lib().rk_expand12_host(_repr_id(), src.ctypes.data, children.ctypes.data, flags.ctypes.data if return_solved else None, None,
@@ -513,7 +523,7 @@ def multi_is_solved(states: np.ndarray) -> np.ndarray:
 	if len(states) == 0:
 		return np.zeros(0, dtype=bool)
 	if _small(len(states), 0, len(states)) and not isinstance(states, torch.Tensor):
-		src = np.ascontiguousarray(states, dtype=np.int8)
+		src = _host_rows(states)
 		flags = np.empty(len(src), dtype=np.uint8)
 		_ffi.check(_ffi.lib().rk_multi_is_solved_host(_repr_id(), src.ctypes.data, flags.ctypes.data, None, len(src), _ffi.stream_ptr()))
 		return flags.astype(bool)
@@ -641,23 +651,7 @@ def sequence_scrambler(games: int, depth: int, with_solved: bool):
 #############
 # Rendering #   (cube.py:149-173, 279-307, 382-388; maps.py:26-51) -- host-side formatting, no cube arithmetic
 #############
-def _sticker_positions():
-	f, b, t, d, l, r = F, B, T, D, L, R
-	corners = (
-		((f, 0, 0), (l, 0, 2), (t, 2, 0)), ((f, 2, 0), (d, 0, 0), (l, 2, 2)),
-		((f, 2, 2), (r, 2, 0), (d, 0, 2)), ((f, 0, 2), (t, 2, 2), (r, 0, 0)),
-		((b, 0, 2), (t, 0, 0), (l, 0, 0)), ((b, 2, 2), (l, 2, 0), (d, 2, 0)),
-		((b, 2, 0), (d, 2, 2), (r, 2, 2)), ((b, 0, 0), (r, 0, 2), (t, 0, 2)),
-	)
-	edges = (
-		((f, 0, 1), (t, 2, 1)), ((f, 1, 0), (l, 1, 2)), ((f, 2, 1), (d, 0, 1)), ((f, 1, 2), (r, 1, 0)),
-		((t, 1, 0), (l, 0, 1)), ((d, 1, 0), (l, 2, 1)), ((d, 1, 2), (r, 2, 1)), ((t, 1, 2), (r, 0, 1)),
-		((b, 0, 1), (t, 0, 1)), ((b, 1, 2), (l, 1, 0)), ((b, 2, 1), (d, 2, 1)), ((b, 1, 0), (r, 1, 2)),
-	)
-	return corners, edges
-
-
-_CORNER_POS, _EDGE_POS = _sticker_positions()
+_CORNER_POS, _EDGE_POS = get_633maps(F, B, T, D, L, R)
 _RING_TO_33 = np.array([0, 3, 6, 7, 8, 5, 2, 1])
 _RING_SHIFT = np.array([0, 6, 6, 4, 2, 4])
 

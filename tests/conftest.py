@@ -38,6 +38,8 @@ def golden():
 			g[name] = {k: z[k] for k in z.files}
 	with open(os.path.join(GOLDEN, "cube_text.json")) as f:
 		g["text"] = json.load(f)
+	with open(os.path.join(GOLDEN, "cube_maps.json")) as f:      # oracle/gen_golden_maps.py
+		g["maps"] = json.load(f)
 	return g
 
 

@@ -66,6 +66,53 @@ def test_tables_from_library(golden):
 	assert cube.shape() == (6, 8, 6) and cube.get_oh_shape() == 288
 
 
+def test_maps_module_is_the_references(golden):
+	"""`librubiks.cube.maps` under its own names (ref:cube/maps.py; re-exported by ref:cube/cube.py:22), rebuilt from the library's
+	face definitions and move table -- against what the unmodified reference module holds (tests/golden/cube_maps.json)."""
+	from librubiks_amd.cube import maps
+	m = golden["maps"]
+	# every public name of the reference's two modules exists on the drop-in (`i` is a loop variable ref:cube/cube.py:33 leaks,
+	# `dataclass` an import of maps.py: neither is API)
+	assert set(m["public_names_cube"]) - {"i"} <= set(dir(cube)), set(m["public_names_cube"]) - set(dir(cube))
+	assert set(m["public_names_maps"]) - {"dataclass"} <= set(dir(maps))
+	for name in ("SimpleState", "get_corner_pos", "get_side_pos", "get_tensor_map", "get_633maps", "neighbors_686"):
+		assert getattr(cube, name) is getattr(maps, name)
+	assert maps.neighbors_686.tolist() == m["neighbors_686"] and str(maps.neighbors_686.dtype) == m["neighbors_686_dtype"]
+	t8, t64 = maps.get_tensor_map(np.int8), maps.get_tensor_map(np.int64)
+	assert str(t8.dtype) == m["tensor_map_int8_dtype"] and str(t64.dtype) == m["tensor_map_int64_dtype"]
+	assert t8.shape == (2, 6, 2, 24) and np.array_equal(t8, np.array(m["tensor_map_int8"])) and np.array_equal(t64, t8)
+	assert np.array_equal(t8, golden["cube_tables"]["delta_maps"])
+	as_lists = lambda part: [[list(map(int, x)) for x in cubie] for cubie in part]
+	c, s = maps.get_633maps(0, 1, 2, 3, 4, 5)
+	assert as_lists(c) == m["maps633_corners"] and as_lists(s) == m["maps633_sides"]
+	assert [as_lists(part) for part in maps.get_633maps(5, 4, 3, 2, 1, 0)] == m["maps633_swapped"]
+	st = maps.SimpleState()
+	for k, v in m["simple_state"].items():
+		assert getattr(st, k).tolist() == v
+	assert str(st) == m["simple_state_str"]
+	assert [[maps.get_corner_pos(p, o) for o in range(3)] for p in range(8)] == m["corner_pos"]
+	assert [[maps.get_side_pos(p, o) for o in range(2)] for p in range(12)] == m["side_pos"]
+	for name, rec in m["action_maps"].items():
+		a = getattr(maps.Actions, name)
+		assert (list(a.corner_map), list(a.side_map), a.corner_static, a.side_switch) == (rec["corner_map"], rec["side_map"], rec["corner_static"], rec["side_switch"])
+	# the solved vector IS SimpleState read through get_corner_pos / get_side_pos (ref:cube/cube.py:58-65)
+	want = [maps.get_corner_pos(p, o) for p, o in zip(st.corners, st.corner_orientations)] + [maps.get_side_pos(p, o) for p, o in zip(st.sides, st.side_orientations)]
+	assert cube.get_solved().tolist() == want
+
+
+def test_host_rows_are_whole_rows():
+	"""A single (20,) state must not be read as 20 rows by the zero-copy host entries (advisor, round 4)."""
+	with pytest.raises(ValueError):
+		cube.cube._host_rows(cube.get_solved())
+	with pytest.raises(ValueError):
+		cube.cube._host_rows(np.zeros((3, 21), np.int8))
+	assert cube.cube._host_rows(np.zeros((3, 20), np.int64)).dtype == np.int8
+	cube.set_is2024(False)
+	with pytest.raises(ValueError):
+		cube.cube._host_rows(np.zeros((3, 20), np.int8))
+	assert cube.cube._host_rows(np.zeros((2, 6, 8, 6), np.int8)).shape == (2, 6, 8, 6)
+
+
 def test_error_reporting_without_fallback():
 	lib = _ffi.lib()
 	assert lib.rk_tables(7, None) == -1 and b"representation" in lib.rk_last_error()

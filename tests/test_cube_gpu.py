@@ -802,3 +802,42 @@ def test_set_pacing_switches_the_form_not_the_results():
 			assert torch.equal(ch, outs[0][0]) and torch.equal(fl, outs[0][1]) and torch.equal(oh, outs[0][2])
 	finally:
 		_ffi.check(lib.rk_set_pacing(-1))
+
+
+# ------------------------------------------------------------------------------------------------- librubiks.cube.maps names
+def test_as_oh_layout_through_the_maps_helpers():
+	"""The body of ref:tests/test_cube.py:129-139: the one-hot of the solved state, rebuilt from SimpleState through
+	get_corner_pos / get_side_pos, with the helpers imported the way the reference's test imports them."""
+	from librubiks_amd import gpu
+	from librubiks_amd.cube.maps import SimpleState, get_corner_pos, get_side_pos
+	state = cube.get_solved()
+	oh = cube.as_oh(state)
+	supposed_state = torch.zeros(20, 24, device=gpu)
+	corners = [get_corner_pos(c, o) for c, o in zip(SimpleState.corners.tolist(), SimpleState.corner_orientations.tolist())]
+	supposed_state[torch.arange(8), corners] = 1
+	sides = [get_side_pos(s, o) for s, o in zip(SimpleState.sides.tolist(), SimpleState.side_orientations.tolist())]
+	supposed_state[torch.arange(8, 20), sides] = 1
+	assert (supposed_state.flatten() == oh).all()
+
+
+def test_tensor_map_moves_states_like_the_kernels():
+	"""`state + maps[dir, face][kind, state]` (ref:cube/cube.py:244-254) with the drop-in's get_tensor_map = the device's rotate."""
+	maps = cube.get_tensor_map(np.int8)
+	kind = np.array([0] * 8 + [1] * 12)
+	s = random_walk(64, 15, seed=5)
+	for face in range(6):
+		for d in range(2):
+			want = s + maps[d, face][kind, s]
+			assert np.array_equal(cube.multi_rotate(s, np.full(64, face), np.full(64, d)), want)
+
+
+def test_host_entries_refuse_a_single_state_as_rows():
+	"""len() of a (20,) state is 20: the zero-copy entries must not read 20 rows from a 20-byte buffer (advisor, round 4)."""
+	one = cube.get_solved()
+	with pytest.raises(ValueError):
+		cube.expand(one)
+	with pytest.raises(ValueError):
+		cube.multi_is_solved(one)
+	with pytest.raises(ValueError):
+		cube.multi_rotate(one, np.zeros(20, np.uint8), np.zeros(20, np.uint8))
+	assert cube.is_solved(one) and cube.expand(one[None]).shape == (12, 20)
