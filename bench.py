@@ -42,7 +42,13 @@ def parse_args(argv=None):
 	ap.add_argument("--steps", type=int, default=300)
 	ap.add_argument("--warmup", type=int, default=30)
 	ap.add_argument("--no-cpu-baseline", action="store_true")
-	ap.add_argument("--no-search-legs", action="store_true", help="skip the configs[2] / configs[3] legs behind the timed region (N = 1 only)")
+	ap.add_argument("--no-search-legs", action="store_true", help="skip the search legs behind the timed region (N = 1: configs[2] / configs[3]; "
+	                "N > 1: configs[4] sharded A* strong + weak and the partitioned MCTS)")
+	ap.add_argument("--search-games", type=int, default=3, help="N > 1: games per scaling mode of the sharded A* leg")
+	ap.add_argument("--search-budget", type=int, default=0, help="N > 1: state budget of the sharded A* leg at world 1 (default: configs[4]'s 2 M)")
+	ap.add_argument("--search-expansions", type=int, default=0, help="N > 1: nodes popped per iteration at world 1 (default: configs[4]'s 700)")
+	ap.add_argument("--search-depth", type=int, default=0, help="N > 1: scramble depth of the sharded A* leg (default: configs[4]'s 20)")
+	ap.add_argument("--mcts-sims", type=int, default=4096, help="N > 1: simulations per tree of the partitioned MCTS leg (0 skips it)")
 	ap.add_argument("--dry-run", action="store_true", help="launch path only: rendezvous, barrier and the MAX over ranks, no GPU work "
 	                "(what the CPU test of `--gpus N` without a launcher runs)")
 	return ap.parse_args(argv)
@@ -66,7 +72,7 @@ READ_BYTES_PER_PARENT = 20
 N_IN_SETS = 32                            # rotating parent sets: 32 x 20 MB = 640 MB of distinct input (> 2 x 256 MiB)
 N_OUT_SETS = 4                            # rotating children/flag sets: 3 x 252 MB pass between two writes of a line
 PACED = os.environ.get("RK_PACE", "1") != "0"
-KERNEL = "rk::k_expand12p<true>" if PACED else "rk::k_expand12r<true, 2, 1, false, 0>"                            # the instantiation launch_expand12 picks at 1 M parents (rocprofv3's spelling)
+KERNEL_PACED, KERNEL_RING = "rk::k_expand12p<true>", "rk::k_expand12r<true, 2, 1, false, 0>"    # the instantiations launch_expand12 picks at 1 M parents (rocprofv3's spelling)
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8.0 TB/s spec (about 6.3 TB/s achievable)
 
 
@@ -253,7 +259,7 @@ def search_legs():
 PMC_FILE = os.path.join("profiles", "r04_expand12_pmc.json")
 
 
-def pmc_traffic():
+def pmc_traffic(kernel):
 	"""
 	HBM bytes per launch from the committed rocprofv3 PMC passes of THIS command (profiles/, written by
 	benchmarks/pmc_summary.py from separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs; FETCH_SIZE doubled per the
@@ -265,7 +271,7 @@ def pmc_traffic():
 			rec = json.load(f)
 	except (OSError, ValueError):
 		return None, None
-	if rec.get("kernel") != KERNEL:
+	if rec.get("kernel") != kernel:
 		return None, {"source": PMC_FILE, "stale": f"recorded for {rec.get('kernel')}"}
 	return rec.get("hbm_bytes_per_launch"), {"source": PMC_FILE, "kernel": rec.get("kernel"), "commit": rec.get("commit"),
 	                                         "fetch_bytes": rec.get("fetch_bytes_per_launch"), "write_bytes": rec.get("write_bytes_per_launch"),
@@ -397,21 +403,49 @@ def main():
 	torch.cuda.synchronize()
 	per = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
 
-	# sanity of the timed work: an output set's children are a real fan-out of the parents last expanded into it (spot check
-	# on the device, head and tail of the batch)
-	undo = torch.arange(12, dtype=torch.uint8, device="cuda").bitwise_xor(1).repeat(4096)
-	for o, k in last_in.items():
+	# The timed work, verified IN FULL (outside the timed region): for every output set, ALL 12 M children of the last launch
+	# into it are moved back by the inverse action and compared with the 1 M parents that launch read -- on the device, in
+	# slices of 1 M children (one rk_multi_rotate + one comparison each); the flags are checked against a goal test of the children.
+	undo_slice = torch.arange(12, dtype=torch.uint8, device="cuda").bitwise_xor(1).repeat(1 << 16)
+	verified_children = 0
+	for o, k in sorted(last_in.items()):
 		parents, (children, solved) = ins[k], outs[o]
-		for lo in (0, N_PARENTS - 4096):
-			probe = cube.device.multi_rotate(children[12 * lo:12 * (lo + 4096)].contiguous(), undo)
-			assert torch.equal(probe.view(4096, 12, 20), parents[lo:lo + 4096].view(4096, 1, 20).expand(4096, 12, 20))
+		for lo in range(0, N_PARENTS, 1 << 16):
+			hi = min(lo + (1 << 16), N_PARENTS)
+			back = cube.device.multi_rotate(children[12 * lo:12 * hi], undo_slice[:12 * (hi - lo)])
+			if not torch.equal(back.view(hi - lo, 12, 20), parents[lo:hi].view(hi - lo, 1, 20).expand(hi - lo, 12, 20)):
+				raise AssertionError(f"output set {o}: children of parents {lo}..{hi} are not the fan-out of parent set {k}")
+			del back
+		if not torch.equal(cube.device.multi_is_solved(children), solved):
+			raise AssertionError(f"output set {o}: solved flags differ from a goal test of the children")
+		verified_children += 12 * N_PARENTS
 	assert int(stats[0]) == 0 or int(stats[1]) < 12 * N_PARENTS
+	import ctypes
+	tau_c, src_c, us_c = ctypes.c_uint(0), ctypes.c_int(0), (ctypes.c_float * 5)()
+	_ffi.check(_ffi.lib().rk_get_pacing(tau_c, src_c, us_c))                    # the store schedule rk_init settled on for this device
+	paced = PACED and tau_c.value > 0
+	kernel = KERNEL_PACED if paced else KERNEL_RING
+
+	# N > 1: the collectives' proof and the search legs are COLLECTIVE -- every rank runs them, rank 0 reports
+	multi = {}
+	if world > 1:
+		from benchmarks import multi_gpu
+		del ins, outs
+		torch.cuda.empty_cache()
+		try:
+			multi.update(multi_gpu.collective_proof(dist, backend))
+		except Exception as e:
+			multi["collective_proof_error"] = f"{type(e).__name__}: {e}"[:400]
+		if not args.no_search_legs:
+			multi.update(multi_gpu.legs(dist, backend, world, rank, games=args.search_games, sims=args.mcts_sims or 4096, mcts=args.mcts_sims > 0,
+			                            budget=args.search_budget or multi_gpu.STRONG_BUDGET, expansions=args.search_expansions or multi_gpu.STRONG_N,
+			                            depth=args.search_depth or multi_gpu.DEPTH))
 
 	if rank == 0:
 		value = world * N_PARENTS * args.steps / elapsed_max
 		achieved = BYTES_PER_PARENT * N_PARENTS / (kernel_ms * 1e-3) / 1e9
 		achieved_read = READ_BYTES_PER_PARENT * N_PARENTS / (kernel_ms * 1e-3) / 1e9
-		traffic, traffic_src = pmc_traffic()
+		traffic, traffic_src = pmc_traffic(kernel)
 		line = {
 			"metric": "cube node-expansions/sec (12-child fan-out) at 1M-state batch",
 			"value": value, "unit": "expansions/s",
@@ -427,11 +461,14 @@ def main():
 			           "input_sets": N_IN_SETS, "output_sets": N_OUT_SETS,
 			           "parallelism": f"independent batches x{world}"},
 			"transitions_per_s": 12 * value,
+			"verified_children": verified_children,          # every child of the last launch into each output set, undone and compared on the device
+			"pace_tau_ps": int(tau_c.value), "pace_source": {0: "compiled default", 1: "calibrated on this device", 2: "environment"}.get(int(src_c.value), "?"),
+			"pace_calibration_us": {"ring": us_c[0], "2000": us_c[1], "2100": us_c[2], "2200": us_c[3], "2400": us_c[4]},
 			"roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
 			             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_provenance": traffic_src,
 			             "achieved_read": achieved_read, "frac_read": achieved_read / HBM_PEAK_GBS,
-			             "kernel": KERNEL, "kernel_form": "paced: a read phase (parents -> Infinity Cache), then one 64-parent tile per wave stored on a 2.10 ns/tile "
-			                                    "schedule (DESIGN 3 step 3; RK_PACE=0 runs the unpaced ring form)" if PACED else "ring form (RK_PACE=0)",
+			             "kernel": kernel, "kernel_form": f"paced: a read phase (parents -> Infinity Cache), then one 64-parent tile per wave stored on a {tau_c.value / 1000:.2f} ns/tile "
+			                                    "schedule (DESIGN 3 step 3; RK_PACE=0 runs the unpaced ring form)" if paced else "ring form (RK_PACE=0, or the calibration chose it)",
 			             "kernel_ms_back_to_back": kernel_ms,
 			             "per_launch_event_pairs_ms": {"min": per[0], "median": per[len(per) // 2], "mean": sum(per) / len(per)},
 			             "kernel_ms_4_input_sets": kernel_ms_4in, "frac_4_input_sets": BYTES_PER_PARENT * N_PARENTS / (kernel_ms_4in * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -445,6 +482,7 @@ def main():
 			# flat copies: the driver's parser keeps flat extra keys
 			line["frac_ring_same_box"] = line["roofline"]["frac_ring_same_box"]
 			line["paced_over_ring_same_box"] = kernel_ms_ring / kernel_ms
+		line.update(multi)
 		if world == 1 and not args.no_search_legs:
 			del ins, outs                                     # 1.6 GB back to the allocator before the pools of the search legs
 			torch.cuda.empty_cache()

@@ -67,6 +67,22 @@ int         rk_init(int device);
  * the form off for this process (the unpaced kernels run at every size), 1 on, -1 back to the environment's choice (RK_PACE,
  * default on).  bench.py uses it to time both forms on the same box in one run (`frac_ring_same_box`). */
 int rk_set_pacing(int mode);
+/* The fan-out's store schedule is measured once per device and process (rk_init does it; about 4 ms, 272 MB of scratch that is freed
+ * again): the ring form and 2.0 / 2.1 / 2.2 / 2.4 ns per 64-parent tile on 1 Mi parents.  The compiled 2.1 ns stay unless another
+ * candidate is more than 3 % faster -- a part whose HBM does not keep that schedule gets the one it does keep, the unpaced form
+ * included.  rk_calibrate_pacing(force != 0) measures again.  Skipped when RK_PACE_TAU_PS, RK_PACE=0 or RK_PACE_CALIBRATE=0 say so.
+ * rk_get_pacing: *tau_ps = picoseconds per tile in force on the current device (0 = unpaced), *source = 0 compiled default (not
+ * calibrated yet), 1 calibrated, 2 fixed by the environment or calibration impossible; h_us (nullable, 5 floats) = measured
+ * microseconds per 1 Mi-parent launch of {ring form, 2.0, 2.1, 2.2, 2.4 ns}, zeros if nothing was measured.  Any pointer may be null. */
+int rk_calibrate_pacing(int force);
+int rk_get_pacing(unsigned int *tau_ps, int *source, float *h_us);
+/* Stream lifetime.  Paced launches on different streams take turns: the library remembers, per device, the
+ * stream of the last paced launch and, when the next one arrives on another stream, asks the runtime about the remembered one
+ * (hipStreamQuery) before it records an event on it.  A caller that DESTROYS a stream it has passed to this library calls
+ * rk_stream_forget(stream) first; the library then holds no reference to it.  (Without the call the query of a destroyed handle is an
+ * error return in the HIP runtime this library is built against and the reference is dropped there -- but that is the runtime's
+ * courtesy, not a contract.)  Streams of a pool that are never destroyed -- torch's -- need nothing. */
+int rk_stream_forget(void *stream);
 
 /* Move tables, written to HOST memory.
  * RK_REPR_2024: uint8 (12,2,24) absolute table T[a][kind][v] = v + maps[dir][face][kind][v]

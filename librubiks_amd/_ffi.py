@@ -29,6 +29,9 @@ SIGNATURES = {
 	"rk_last_error": (C.c_char_p, []),
 	"rk_init": (_i, [_i]),
 	"rk_set_pacing": (_i, [_i]),
+	"rk_calibrate_pacing": (_i, [_i]),
+	"rk_get_pacing": (_i, [C.POINTER(C.c_uint), C.POINTER(C.c_int), C.POINTER(C.c_float)]),
+	"rk_stream_forget": (_i, [_vp]),
 	"rk_tables": (_i, [_i, _vp]),
 	"rk_face_definitions": (_i, [_vp]),
 	"rk_solved": (_i, [_i, _vp]),

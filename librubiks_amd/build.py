@@ -3,8 +3,9 @@ Builds librubiks_hip.so (the C-ABI HIP library) in-tree with hipcc for gfx950.
 
     python -m librubiks_amd.build [--force] [--tune]
 
---tune additionally builds benchmarks/librubiks_hip_tune.so: the same sources with -DRK_TUNING, which adds the
-kernel-shape variants and geometry diagnostics used by benchmarks/tune_*.py.  The shipped library carries none of them.
+--tune additionally builds benchmarks/librubiks_hip_tune.so: the same sources with -DRK_TUNING and csrc/rk_tuning.hip in the
+place of rk_cube_kernels.hip, which adds the kernel-shape variants and geometry diagnostics used by benchmarks/tune_*.py.
+The shipped library carries none of them (rk_tuning.hip is never one of its translation units).
 
 hipcc cross-compiles without a GPU; the .so is git-ignored but travels with the gpurun snapshot.
 """
@@ -27,8 +28,17 @@ FLAGS = [
 ]
 
 
+TUNING_UNIT = "rk_tuning.hip"          # tuning build only: includes rk_cube_kernels.hip and adds the kernel variants / diagnostics
+
+
 def sources():
-	return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+	"""The translation units of the shipped library: every .hip file but the tuning unit."""
+	return sorted(s for s in glob.glob(os.path.join(CSRC, "*.hip")) if os.path.basename(s) != TUNING_UNIT)
+
+
+def tune_sources():
+	"""The tuning build: rk_tuning.hip stands in for rk_cube_kernels.hip (it includes it)."""
+	return sorted([s for s in sources() if os.path.basename(s) != "rk_cube_kernels.hip"] + [os.path.join(CSRC, TUNING_UNIT)])
 
 
 def stale() -> bool:
@@ -44,7 +54,7 @@ TUNE_OUT = os.path.join(HERE, "..", "benchmarks", "librubiks_hip_tune.so")
 
 def build_tune(verbose: bool = False) -> str:
 	"""The tuning build (one compile of everything with -DRK_TUNING; not cached, not shipped)."""
-	cmd = [HIPCC] + FLAGS + ["-DRK_TUNING", "-o", os.path.abspath(TUNE_OUT)] + sources()
+	cmd = [HIPCC] + FLAGS + ["-DRK_TUNING", "-o", os.path.abspath(TUNE_OUT)] + tune_sources()
 	if verbose:
 		print(" ".join(cmd))
 	subprocess.run(cmd, check=True)

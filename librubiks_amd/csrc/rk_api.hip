@@ -117,6 +117,7 @@ int rk_init(int device)
 	RK_HIP(hipGetDeviceProperties(&prop, device));
 	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
 		return fail(RK_EINVAL, "device %d is %s; this library only carries gfx950 code", device, prop.gcnArchName);
+	(void)calibrate_pacing(false);          // once per device and process, about 4 ms; a calibration that cannot run keeps the compiled schedule
 	return RK_OK;
 }
 
@@ -215,6 +216,24 @@ int rk_multi_rotate(int repr, const int8_t *d_states, const uint8_t *d_actions, 
 int rk_set_pacing(int mode)
 {
 	set_pace_override(mode);
+	return RK_OK;
+}
+
+int rk_calibrate_pacing(int force)
+{
+	if (calibrate_pacing(force != 0) != 0) return fail(RK_EHIP, "rk_calibrate_pacing: no current device");
+	return RK_OK;
+}
+
+int rk_get_pacing(unsigned int *tau_ps, int *source, float *h_us)
+{
+	get_pacing(tau_ps, source, h_us);
+	return RK_OK;
+}
+
+int rk_stream_forget(void *stream)
+{
+	forget_stream((hipStream_t)stream);
 	return RK_OK;
 }
 

@@ -26,6 +26,9 @@ void launch_multi_rotate(const int8_t *states, const uint8_t *actions_or_faces, 
 void launch_multi_is_solved(const int8_t *states, uint8_t *flags, long long *stats, size_t n, hipStream_t st);
 int read_bad_actions(hipStream_t st);
 void set_pace_override(int mode);
+int calibrate_pacing(bool force);
+void get_pacing(unsigned *tau_ps, int *source, float *us5);
+void forget_stream(hipStream_t st);
 void launch_apply_sequences(const uint8_t *actions, int moves, int games, int with_solved, int only_last, int8_t *out,
                             hipStream_t st);
 void launch_as_oh(const int8_t *states, void *out, int out_dtype, size_t n, hipStream_t st);

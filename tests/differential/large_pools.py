@@ -5,7 +5,7 @@ pools, not on samples: no state stored twice, every parent link (A*) / neighbour
 open queue is sorted and holds each node once.  (The oracle cannot replay searches of this size; these are the structural
 invariants of tests/test_agents.py:49-94, :122-134 of the reference.)
 
-    python benchmarks/large_pools.py > profiles/r04_large_pools.json
+    python tests/differential/large_pools.py > profiles/r04_large_pools.json
 """
 import json
 import os
@@ -15,7 +15,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from benchmarks.nets import FastStub  # noqa: E402
 from librubiks_amd.solving.agents import AStar, MCTS  # noqa: E402
 from oracle import c_oracle, cube_oracle as orc  # noqa: E402

@@ -5,7 +5,7 @@ paced forms' thresholds and ragged tiles, pool offsets, both representations; A*
 batched engines.  Everything is compared bit for bit.  A failing case is reported with the numbers that reproduce it and ends the
 run with exit code 1.  The oracle is the checker here, as in tests/ (this script is a long-running test, not a benchmark of it).
 
-    python benchmarks/soak.py --minutes 10 --seed 1 > profiles/r04_soak.json
+    python tests/differential/soak.py --minutes 10 --seed 1 > profiles/r04_soak.json
 """
 import argparse
 import json
@@ -17,7 +17,7 @@ import traceback
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from librubiks_amd import cube  # noqa: E402
 from librubiks_amd.solving.agents import AStar, AStarBatch, MCTS, MCTSBatch  # noqa: E402
 from oracle import c_oracle, cube_oracle as orc  # noqa: E402

@@ -1,5 +1,5 @@
 import sys, time, numpy as np, torch
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from librubiks_amd import cube
 from librubiks_amd.solving.agents import AStar, AStarBatch, MCTSBatch
 from oracle import cube_oracle as orc

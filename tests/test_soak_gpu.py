@@ -1,5 +1,5 @@
 """
-A short, seeded stretch of the randomised differential run (benchmarks/soak.py): every engine against the CPU oracle, bit for
+A short, seeded stretch of the randomised differential run (tests/differential/soak.py): every engine against the CPU oracle, bit for
 bit, on randomly drawn cases -- sizes around the paced forms' thresholds and ragged tiles, both representations, the drop-in
 NumPy surface and the scramblers' seed parity, A* / MCTS single and batched with stub / misleading / policy nets, pools that
 grow on the way, eager and hipGraph-replayed steps, the sharded search on 2-8 simulated ranks.  The long form ran for minutes
@@ -8,7 +8,7 @@ grow on the way, eager and hipGraph-replayed steps, the sharded search on 2-8 si
 import numpy as np
 import pytest
 
-from benchmarks import soak
+from tests.differential import soak
 
 pytestmark = pytest.mark.gpu
 
