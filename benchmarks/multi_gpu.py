@@ -93,14 +93,16 @@ def sharded_astar_leg(dist, backend: str, world: int, rank: int, *, weak: bool, 
 		if dist is not None:
 			dist.barrier()
 
-	agent = ShardedAStar(net, lam, N, capacity=cap, poll=poll, fused_first_layer=fused)
+	# the iteration replayed as one hipGraph wherever its collectives are on the device (RCCL) or short-circuit (world 1); RK_SHARD_GRAPH=0/1 overrides
+	want_graph = os.environ.get("RK_SHARD_GRAPH", "1" if (world == 1 or backend == "nccl") else "0") != "0"
+	agent = ShardedAStar(net, lam, N, capacity=cap, poll=poll, fused_first_layer=fused, use_hipgraph=want_graph)
 	np.random.seed(12345)
 	agent.search(cube.scramble(depth, True)[0], time_limit=time_limit, max_states=min(total_budget, 30 * 12 * N))      # pools, GEMM selection, group warm-up
 	starts = []
 	for g in seeds:
 		np.random.seed(g)
 		starts.append(cube.scramble(depth, True)[0])
-	secs = states = iters = solved = rows = 0
+	secs = states = iters = solved = rows = launches = 0
 	stops = []
 	for st in starts:
 		barrier()
@@ -112,9 +114,12 @@ def sharded_astar_leg(dist, backend: str, world: int, rank: int, *, weak: bool, 
 		iters += agent.iterations
 		solved += bool(ok)
 		rows += agent.net_rows_total
+		launches += agent.host_launches
 		stops.append(agent.stop_reason)
 	# the phase split: a second pass over the first game with HIP events between the phases of every iteration (device time on the
 	# search stream; the events themselves cost a few microseconds per phase, so the timed pass above runs without them)
+	graph_state = "replayed" if (agent.use_hipgraph and agent.graph_error is None) else ("eager: " + (agent.graph_error or "not requested"))
+	repeated, rows_fixed = agent.repeated, agent.net_rows_max
 	agent.profile = True
 	barrier()
 	agent.search(starts[0], time_limit=time_limit, max_states=total_budget)
@@ -128,7 +133,8 @@ def sharded_astar_leg(dist, backend: str, world: int, rank: int, *, weak: bool, 
 		pre + "states_per_s": states / secs, pre + "ms_per_iteration": secs / max(iters, 1) * 1e3, pre + "iterations": iters,
 		pre + "total_states": states, pre + "games": len(starts), pre + "solved": solved, pre + "stop_reasons": ",".join(stops),
 		pre + "expansions_per_iteration": N, pre + "budget": total_budget,
-		pre + "net_rows_per_rank": rows / max(iters, 1), pre + "net_rows_bound_12N": 12 * N,
+		pre + "net_rows_per_rank": rows_fixed, pre + "net_rows_bound_12N": 12 * N, pre + "row_shortfall_repeats": repeated,
+		pre + "hipgraph": graph_state, pre + "graph_launches_per_iteration": launches / max(iters, 1) if graph_state == "replayed" else None,
 		pre + "allgather_us": ph.get("all_gather", 0.0) * 1e3, pre + "select_us": ph.get("select+expand", 0.0) * 1e3,
 		pre + "alltoall_us": ph.get("all_to_all", 0.0) * 1e3, pre + "insert_us": ph.get("insert", 0.0) * 1e3,
 		pre + "net_us": ph.get("net", 0.0) * 1e3, pre + "push_us": ph.get("push", 0.0) * 1e3,

@@ -77,11 +77,13 @@ int rk_set_pacing(int mode);
 int rk_calibrate_pacing(int force);
 int rk_get_pacing(unsigned int *tau_ps, int *source, float *h_us);
 /* Stream lifetime.  Paced launches on different streams take turns: the library remembers, per device, the
- * stream of the last paced launch and, when the next one arrives on another stream, asks the runtime about the remembered one
- * (hipStreamQuery) before it records an event on it.  A caller that DESTROYS a stream it has passed to this library calls
- * rk_stream_forget(stream) first; the library then holds no reference to it.  (Without the call the query of a destroyed handle is an
- * error return in the HIP runtime this library is built against and the reference is dropped there -- but that is the runtime's
- * courtesy, not a contract.)  Streams of a pool that are never destroyed -- torch's -- need nothing. */
+ * stream of the last paced launch and, when the next one arrives on another stream, makes it wait (event record + stream wait)
+ * for that stream.  It only ever remembers a stream it may rely on: the null stream, and streams REGISTERED with
+ * rk_stream_register(stream) -- the caller's promise that the stream stays alive until rk_stream_forget(stream), which must be
+ * called before the stream is destroyed.  A paced launch on an unregistered stream takes no turn (it may overlap another paced
+ * launch: slower, never wrong) and nothing about it is kept.  The Python shim registers torch's pooled streams, which are never
+ * destroyed.  Both entries are cheap and idempotent; neither touches the stream. */
+int rk_stream_register(void *stream);
 int rk_stream_forget(void *stream);
 
 /* Move tables, written to HOST memory.
@@ -298,7 +300,8 @@ long long rk_astarb_path(rk_astarb_t *h, int search, long long index, long long 
  * One engine per GPU/rank holds the states it owns, owner(state) = rk_shard_owner(state, world).  An iteration is two
  * collectives with fixed-size device buffers and no host synchronisation in between:
  *   all-gather   rk_astar_shard_gather_ptr: 8 + N doubles per rank = {pool size, won, solved index, error, candidates,
- *                elapsed seconds (host of rank 0 writes slot 5), 0, 0, the rank's N cheapest open costs ascending, +inf}
+ *                seconds since the reset on the rank's DEVICE clock (rank 0's decides "out of time"), 0, 0, the rank's N cheapest
+ *                open costs ascending, +inf} -- the engine writes all of it, the host nothing: the iteration is capturable
  *   rk_astar_shard_select (gathered)  identical stop decision on every rank (won / budget / a pool could overflow /
  *                time / error / nothing open) and the global top-N by (cost, rank, position); expands this rank's share
  *                and buckets the 32-byte child records by owner (stable) into d_send
@@ -323,7 +326,8 @@ int rk_astar_shard_bind(rk_astar_t *h, void *d_gather);
 int rk_astar_shard_reset(rk_astar_t *h, const int8_t *h_start_state, double lambda, void *d_send, void *stream);
 int rk_astar_shard_select(rk_astar_t *h, const void *d_gathered, double time_limit, double max_states, void *d_send, void *stream);
 /* h_out[8] = {stop reason (0 none, 1 won, 2 budget, 3 capacity, 4 time, 5 nothing open, 6 error), winner rank, winner
- * index, total states, this rank's pops, iterations, this rank's states, 0}. */
+ * index, total states, this rank's pops, iterations, this rank's states, the largest error code any rank reported (1 pool
+ * capacity, 2 look-back chain, 3 more new states than net rows: rk_astar_shard_push_rows)}. */
 int rk_astar_shard_decision(rk_astar_t *h, long long *h_out, void *stream);
 int rk_astar_shard_insert(rk_astar_t *h, const void *d_recv, void *d_send, void *d_onehot, int out_dtype, void *stream);
 /* Between insert and push: asynchronous copy of this iteration's new-state count (<= 12 N: all ranks together pop at most N
@@ -331,6 +335,12 @@ int rk_astar_shard_insert(rk_astar_t *h, const void *d_recv, void *d_send, void 
  * on the whole padded batch (librubiks_amd/solving/sharded.py). */
 int rk_astar_shard_new_count(rk_astar_t *h, int *h_out, void *stream);
 int rk_astar_shard_push(rk_astar_t *h, const float *d_values, const void *d_recv, void *d_send, void *stream);
+/* The same with the promise the driver can actually keep without a host round trip: d_values holds the net's values of the FIRST
+ * `rows` new states only (0 < rows <= 12 N; a rank expects 12 N / world new states, the driver evaluates a fixed number a little
+ * above that).  An iteration with more new states than rows sets error 3 in this rank's all-gather contribution: every rank stops
+ * together at the next rk_astar_shard_select with stop reason 6 and h_out[7] = 3, and the driver repeats the search with
+ * rows = 12 N.  Nothing is copied to the host and nothing waits: insert -> net(rows) -> push_rows is a fixed-shape sequence. */
+int rk_astar_shard_push_rows(rk_astar_t *h, const float *d_values, int rows, const void *d_recv, void *d_send, void *stream);
 int rk_astar_shard_flush(rk_astar_t *h, const void *d_recv, void *stream);
 int rk_astar_shard_clear_send(rk_astar_t *h, void *d_send, int records, int offers, void *stream);
 /* h_out = {parent rank, parent index, action} of node `index` on this rank (for the cross-rank path walk). */

@@ -31,6 +31,7 @@ SIGNATURES = {
 	"rk_set_pacing": (_i, [_i]),
 	"rk_calibrate_pacing": (_i, [_i]),
 	"rk_get_pacing": (_i, [C.POINTER(C.c_uint), C.POINTER(C.c_int), C.POINTER(C.c_float)]),
+	"rk_stream_register": (_i, [_vp]),
 	"rk_stream_forget": (_i, [_vp]),
 	"rk_tables": (_i, [_i, _vp]),
 	"rk_face_definitions": (_i, [_vp]),
@@ -98,6 +99,7 @@ SIGNATURES = {
 	"rk_astar_shard_insert": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
 	"rk_astar_shard_new_count": (_i, [_vp, _vp, _vp]),
 	"rk_astar_shard_push": (_i, [_vp, _vp, _vp, _vp, _vp]),
+	"rk_astar_shard_push_rows": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
 	"rk_astar_shard_flush": (_i, [_vp, _vp, _vp]),
 	"rk_astar_shard_clear_send": (_i, [_vp, _vp, _i, _i, _vp]),
 	"rk_astar_shard_parent": (_i, [_vp, C.c_longlong, _vp, _vp]),
@@ -176,10 +178,25 @@ def require_gpu():
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
+_registered_streams = {0}          # the null stream needs no registration
+
+
 def stream_ptr() -> int:
 	"""hipStream_t of torch's current stream, so that kernels order with the caller's torch work.  (The raw accessor skips
 	building a torch.cuda.Stream object: a launch through this shim costs the host about 8 us -- profiles/r03_kernels.json,
-	"LAUNCH FLOOR" -- and a third of that was this call.)"""
-	if _raw_stream is not None:
-		return _raw_stream(torch.cuda.current_device())
-	return torch.cuda.current_stream().cuda_stream
+	"LAUNCH FLOOR" -- and a third of that was this call.)  A stream seen for the first time is registered with the library
+	(rk_stream_register): torch's streams come from a pool and are never destroyed, which is what registration promises.  The owner
+	of a `torch.cuda.ExternalStream` calls `forget_stream` before destroying it."""
+	s = _raw_stream(torch.cuda.current_device()) if _raw_stream is not None else torch.cuda.current_stream().cuda_stream
+	if s not in _registered_streams:
+		lib().rk_stream_register(s)
+		_registered_streams.add(s)
+	return s
+
+
+def forget_stream(stream) -> None:
+	"""Before a stream that was current during a call into this package is destroyed (only external streams ever are)."""
+	s = int(getattr(stream, "cuda_stream", stream) or 0)
+	if s:
+		lib().rk_stream_forget(s)
+		_registered_streams.discard(s)

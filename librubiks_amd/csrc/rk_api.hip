@@ -231,6 +231,12 @@ int rk_get_pacing(unsigned int *tau_ps, int *source, float *h_us)
 	return RK_OK;
 }
 
+int rk_stream_register(void *stream)
+{
+	register_stream((hipStream_t)stream);
+	return RK_OK;
+}
+
 int rk_stream_forget(void *stream)
 {
 	forget_stream((hipStream_t)stream);

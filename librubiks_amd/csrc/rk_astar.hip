@@ -65,9 +65,9 @@ namespace rk {
 
 enum {
 	C_NSTATES = 0, C_NBEFORE, C_NPOP, C_NNEW, C_WON, C_SOLVED, C_DONE, C_BUDGET, C_ITERS, C_ERROR, C_OPEN, C_NCAND, C_NEXP, C_NIN,
-	C_NOFF, C_EPOCH, C_TICKET0 = 16, C_TICKET1, C_TICKET2, C_COUNT = 32
+	C_NOFF, C_EPOCH, C_TICKET0 = 16, C_TICKET1, C_TICKET2, C_CLOCK0 = 20 /* and 21: the search's start on the device clock */, C_COUNT = 32
 };
-enum { ERR_NONE = 0, ERR_CAPACITY = 1, ERR_CHAIN = 2 };
+enum { ERR_NONE = 0, ERR_CAPACITY = 1, ERR_CHAIN = 2, ERR_NET_ROWS = 3 /* sharded: more new states than net rows were evaluated */ };
 
 constexpr int QL = 12;                          // maximal number of queue levels
 constexpr int SORT_CHUNK = 2048;                // records sorted per workgroup in LDS (32 KB) when K > 2048
@@ -745,10 +745,11 @@ void kb_queue_insert(const AstarDev *__restrict__ devs, int new_in_rec1)
 // parent walks its 12 children in order, so the last shortcut child in batch order wins, as NumPy's fancy assignment
 // with repeated indices does); queue bookkeeping; loop guard of the next iteration (agents.py:236); next pop list.
 template <bool SHARDED>
-__device__ __forceinline__ void end_body(const AstarDev &d, int new_in_rec1, int count_iteration)
+__device__ __forceinline__ void end_body(const AstarDev &d, int new_in_rec1, int count_iteration, int rows_evaluated = 0)
 {
 	__shared__ int32_t s_meta[4 * QL], s_old[4 * QL], s_ctr[C_COUNT];
 	__shared__ int s_ncand, s_nexp;
+	__shared__ double s_elapsed;
 	__shared__ Rec s_heads[POP_LDS];
 	const int tid = threadIdx.x;
 	// counters and queue state come in with two parallel loads and go back the same way: the bookkeeping thread below
@@ -779,6 +780,19 @@ __device__ __forceinline__ void end_body(const AstarDev &d, int new_in_rec1, int
 	}
 	if (tid == 0) {
 		const int n_new = s_ctr[C_NNEW];
+		if (SHARDED) {
+			// The driver evaluates the net on a FIXED number of rows (its expected share of the 12 N children plus a margin,
+			// librubiks_amd/solving/sharded.py net_rows) instead of waiting for this count on the host.  More new states than rows:
+			// the values of the rows beyond were never computed -- an error every rank stops on together at the next decision
+			// (the driver then repeats the search with the full-width batch).
+			if (rows_evaluated > 0 && n_new > rows_evaluated && s_ctr[C_ERROR] == ERR_NONE) s_ctr[C_ERROR] = ERR_NET_ROWS;
+			// Rank 0's clock decides "out of time" for everybody; it is the DEVICE's constant 100 MHz clock, started by the first
+			// k_end after the reset -- the host writes nothing per iteration, so the iteration can be replayed as a hipGraph.
+			unsigned long long t0 = (unsigned long long)(uint32_t)s_ctr[C_CLOCK0] | ((unsigned long long)(uint32_t)s_ctr[C_CLOCK0 + 1] << 32);
+			const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+			if (t0 == 0) { t0 = now ? now : 1; s_ctr[C_CLOCK0] = (int32_t)(uint32_t)t0; s_ctr[C_CLOCK0 + 1] = (int32_t)(uint32_t)(t0 >> 32); }
+			s_elapsed = (double)(now - t0) * 1e-8;
+		}
 		MergePlan p;
 		const int nc = new_chunk_of(d.chunk, d.Kpad);
 		make_plan(d.q, s_old, (nc == 0 && n_new > SORT_CHUNK && new_in_rec1) ? d.rec1 : d.rec0, n_new, nc, p);
@@ -825,16 +839,16 @@ __device__ __forceinline__ void end_body(const AstarDev &d, int new_in_rec1, int
 		double *g = d.gather_in;
 		if (tid == 0) {
 			g[0] = (double)s_ctr[C_NSTATES]; g[1] = (double)s_ctr[C_WON]; g[2] = (double)s_ctr[C_SOLVED]; g[3] = (double)s_ctr[C_ERROR];
-			g[4] = (double)s_ncand; g[6] = 0.0; g[7] = 0.0;              // g[5] = elapsed seconds, written by the host of rank 0
+			g[4] = (double)s_ncand; g[5] = s_elapsed; g[6] = 0.0; g[7] = 0.0;   // g[5] = seconds since the reset on this rank's device clock (rank 0's decides)
 		}
 		for (int i = tid; i < d.N; i += blockDim.x) g[8 + i] = i < s_ncand ? key_to_double(d.cand_key[i]) : INFINITY;
 	}
 }
 template <bool SHARDED>
 __global__ __launch_bounds__(1024)
-void k_end(AstarDev d, int new_in_rec1, int count_iteration)
+void k_end(AstarDev d, int new_in_rec1, int count_iteration, int rows_evaluated = 0)
 {
-	end_body<SHARDED>(d, new_in_rec1, count_iteration);
+	end_body<SHARDED>(d, new_in_rec1, count_iteration, rows_evaluated);
 }
 template <bool SHARDED>
 __global__ __launch_bounds__(1024)
@@ -965,7 +979,7 @@ __global__ void k_astar_find(const uint32_t *query, const uint32_t *states, cons
 // nobody reads the G of a node that was already expanded.  When a search ends without a win the host flushes the
 // pending offers with one more all-to-all so that the final arrays equal the reference's (world = 1).
 // ---------------------------------------------------------------------------------------------------------------
-enum { D_STOP = 0, D_WINNER_RANK, D_WINNER_IDX, D_TOTAL, D_NPOP, D_ITERS, D_NSTATES, D_COUNT = 8 };
+enum { D_STOP = 0, D_WINNER_RANK, D_WINNER_IDX, D_TOTAL, D_NPOP, D_ITERS, D_NSTATES, D_ERROR, D_COUNT = 8 };
 enum { STOP_NO = 0, STOP_WON = 1, STOP_BUDGET = 2, STOP_CAPACITY = 3, STOP_TIME = 4, STOP_EMPTY = 5, STOP_ERROR = 6 };
 
 __global__ __launch_bounds__(1024)
@@ -975,7 +989,7 @@ void k_shard_decide(AstarDev d, const double *gathered, double time_limit, doubl
 	const int tid = threadIdx.x, W = d.world, N = d.N, stride = 8 + N;
 	if (tid == 0) {
 		s_mine = 0;
-		double total = 0, biggest = 0, any_err = 0;
+		double total = 0, biggest = 0, any_err = 0, max_err = 0;
 		int winner = -1, cands = 0;
 		for (int r = 0; r < W; r++) {
 			const double *g = gathered + (size_t)r * stride;
@@ -983,6 +997,7 @@ void k_shard_decide(AstarDev d, const double *gathered, double time_limit, doubl
 			biggest = g[0] > biggest ? g[0] : biggest;
 			if (winner < 0 && g[1] != 0.0) winner = r;
 			any_err += g[3];
+			max_err = g[3] > max_err ? g[3] : max_err;
 			cands += (int)g[4];
 		}
 		int stop = STOP_NO;
@@ -1001,6 +1016,7 @@ void k_shard_decide(AstarDev d, const double *gathered, double time_limit, doubl
 		decision[D_TOTAL] = (long long)total;
 		decision[D_ITERS] = d.ctr[C_ITERS];
 		decision[D_NSTATES] = d.ctr[C_NSTATES];
+		decision[D_ERROR] = (long long)max_err;                          // the largest error code any rank reported (ERR_*)
 		if (stop != STOP_NO) d.ctr[C_DONE] = 1;
 	}
 	__syncthreads();
@@ -1238,7 +1254,7 @@ int launch_commit(rk_astar *h, const float *d_values, const uint8_t *recv, hipSt
 	const unsigned grid = std::min<unsigned>(1024u, std::max<unsigned>(blocks((size_t)d.Kpad * 4), min_grid));
 	hipLaunchKernelGGL((k_queue_insert<SHARDED>), dim3(grid), dim3(256), 0, st, d, from);
 	if (!SHARDED) {
-		hipLaunchKernelGGL((k_end<false>), dim3(1), dim3(1024), 0, st, d, from, 1);
+		hipLaunchKernelGGL((k_end<false>), dim3(1), dim3(1024), 0, st, d, from, 1, 0);
 		if (pop_is_wide_host(d)) hipLaunchKernelGGL(k_pop_wide, dim3(blocks((size_t)d.q.levels * d.N)), dim3(256), 0, st, d);
 	}
 	(void)recv;
@@ -1705,7 +1721,7 @@ int rk_astar_shard_reset(rk_astar_t *h, const int8_t *h_start_state, double lamb
 	if (int e = astar_reset_impl(h, h_start_state, lambda, mine, st)) return e;
 	hipLaunchKernelGGL(k_shard_clear_send, dim3(1), dim3(64), 0, st, h->d, (uint8_t *)d_send, 3);
 	// the first all-gather contribution: as k_end<true> would write it
-	hipLaunchKernelGGL((k_end<true>), dim3(1), dim3(1024), 0, st, h->d, 0, 0);
+	hipLaunchKernelGGL((k_end<true>), dim3(1), dim3(1024), 0, st, h->d, 0, 0, 0);
 	RK_HIP(hipGetLastError());
 	RK_HIP(hipStreamSynchronize(st));
 	return RK_OK;
@@ -1772,18 +1788,29 @@ int rk_astar_shard_new_count(rk_astar_t *h, int *h_out, void *stream)
 	return RK_OK;
 }
 
-int rk_astar_shard_push(rk_astar_t *h, const float *d_values, const void *d_recv, void *d_send, void *stream)
+static int shard_push_impl(rk_astar_t *h, const float *d_values, int rows, const void *d_recv, void *d_send, void *stream)
 {
 	if (!h || !h->pending) return fail(RK_ESTATE, "rk_astar_shard_push: no pending insert");
 	if (!d_values || !d_recv || !d_send) return fail(RK_EINVAL, "rk_astar_shard_push: null argument");
+	if (rows < 0 || rows > h->d.K) return fail(RK_EINVAL, "rk_astar_shard_push_rows: %d rows outside 0..12 N = %d", rows, h->d.K);
 	hipStream_t st = (hipStream_t)stream;
 	const AstarDev &d = h->d;
 	const int from = launch_commit<true>(h, d_values, (const uint8_t *)d_recv, st);
 	hipLaunchKernelGGL(k_shard_offers, dim3(blocks((size_t)d.KI, ASCAN)), dim3(ASCAN), 0, st, d, (const uint8_t *)d_recv, (uint8_t *)d_send);
-	hipLaunchKernelGGL((k_end<true>), dim3(1), dim3(1024), 0, st, d, from, 1);
+	hipLaunchKernelGGL((k_end<true>), dim3(1), dim3(1024), 0, st, d, from, 1, rows == d.K ? 0 : rows);
 	RK_HIP(hipGetLastError());
 	h->pending = false;
 	return RK_OK;
+}
+
+int rk_astar_shard_push(rk_astar_t *h, const float *d_values, const void *d_recv, void *d_send, void *stream)
+{
+	return shard_push_impl(h, d_values, 0, d_recv, d_send, stream);
+}
+
+int rk_astar_shard_push_rows(rk_astar_t *h, const float *d_values, int rows, const void *d_recv, void *d_send, void *stream)
+{
+	return shard_push_impl(h, d_values, rows, d_recv, d_send, stream);
 }
 
 /* After the search ended without a win: apply the offers that arrived with the last exchange (no records). */

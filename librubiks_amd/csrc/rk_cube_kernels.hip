@@ -12,9 +12,11 @@
 // Cache, and every tile's stores are then held until the tile's slot on a fixed-rate schedule of the constant 100 MHz clock,
 // because HBM takes an ordered, rate-limited store stream 25 % faster than the same bytes from thousands of independent waves
 // and reads mixed into it cost 2.5 x their share.  Only WHEN a finished tile is stored depends on any of that (RK_PACE=0: never).
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <mutex>
+#include <vector>
 
 #include "rk_device.h"
 #include "rk_kernels.h"
@@ -1336,9 +1338,37 @@ struct PacedTurn {
 		if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
 		return gates()[dev >= 0 && dev < PACE_MAX_DEVICES ? dev : 0];
 	}
-	// rk_stream_forget: the caller is about to destroy `st`; no gate may name it any more
+	// Streams the library may REMEMBER: the null stream, and the streams a caller has registered (rk_stream_register) -- a promise
+	// that the stream stays alive until rk_stream_forget.  Nothing else is ever kept across two calls.  Round 4 remembered whatever
+	// stream the last paced launch ran on and recorded an event on it later; on this HIP runtime touching a destroyed stream's handle
+	// (hipEventRecord, hipStreamQuery alike) is a segmentation fault, not an error return (tests/test_cube_gpu.py,
+	// test_a_stream_destroyed_between_two_paced_launches was written against exactly that).  A paced launch on an unregistered stream
+	// therefore takes no turn: it may overlap another paced launch (slower, never wrong) and leaves the gate alone.
+	struct Registry { std::mutex mu; std::vector<hipStream_t> live; };
+	static Registry &registry() { static Registry r; return r; }
+	static bool registered(hipStream_t st)
+	{
+		if (st == nullptr) return true;
+		Registry &r = registry();
+		std::lock_guard<std::mutex> lk(r.mu);
+		return std::find(r.live.begin(), r.live.end(), st) != r.live.end();
+	}
+	static void add(hipStream_t st)
+	{
+		if (st == nullptr) return;
+		Registry &r = registry();
+		std::lock_guard<std::mutex> lk(r.mu);
+		if (std::find(r.live.begin(), r.live.end(), st) == r.live.end()) r.live.push_back(st);
+	}
+	// rk_stream_forget: the caller is about to destroy `st`; neither the registry nor a gate may name it any more
 	static void forget(hipStream_t st)
 	{
+		if (st == nullptr) return;
+		{
+			Registry &r = registry();
+			std::lock_guard<std::mutex> lk(r.mu);
+			r.live.erase(std::remove(r.live.begin(), r.live.end(), st), r.live.end());
+		}
 		for (int i = 0; i < PACE_MAX_DEVICES; i++) {
 			Gate &g = gates()[i];
 			std::lock_guard<std::mutex> lk(g.mu);
@@ -1362,23 +1392,14 @@ struct PacedTurn {
 	// The event is recorded LAZILY, on the previous paced launch's stream, only when a paced launch arrives on another stream: a
 	// record after every paced launch put a marker between back-to-back launches of one stream and cost the bench 3.4 us per launch
 	// (the next launch's read phase no longer overlapped the previous one's tail: 0.84 -> 0.77 of peak).  Recorded late, the event also
-	// covers whatever else that stream was given since -- waiting for a little more than necessary, never for less.
-	// The remembered stream is only ever touched after the runtime has vouched for it: hipStreamQuery validates the handle against
-	// the device's live streams (an unknown handle is an error return, not a dereference) and says whether anything is still running
-	// on it.  Idle: the previous paced launch has ended, nothing to wait for, no event.  Busy: record + wait.  Anything else (the
-	// owner destroyed the stream without rk_stream_forget): the gate is dropped, nothing of that stream can still be running.
-	// The lifetime contract is in include/rubiks_hip.h (rk_stream_forget).
-	PacedTurn(hipStream_t s, bool paced) : st(s), on(paced && enabled() && !capturing(s))
+	// covers whatever else that stream was given since -- waiting for a little more than necessary, never for less.  The remembered
+	// stream is alive by the registration contract (include/rubiks_hip.h, rk_stream_register / rk_stream_forget).
+	PacedTurn(hipStream_t s, bool paced) : st(s), on(paced && enabled() && registered(s) && !capturing(s))
 	{
 		if (!on) return;
 		Gate &g = gate();
 		std::lock_guard<std::mutex> lk(g.mu);
-		if (!g.valid || g.last == st) return;
-		if (capturing(g.last)) return;
-		const hipError_t q = hipStreamQuery(g.last);
-		if (q == hipSuccess) return;
-		if (q != hipErrorNotReady) { (void)hipGetLastError(); g.valid = false; g.last = nullptr; return; }
-		(void)hipGetLastError();                                                  // (hipErrorNotReady is sticky in hipGetLastError)
+		if (!g.valid || g.last == st || capturing(g.last)) return;
 		if (g.ev == nullptr && hipEventCreateWithFlags(&g.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); g.ev = nullptr; }
 		if (g.ev != nullptr) {
 			if (hipEventRecord(g.ev, g.last) == hipSuccess) (void)hipStreamWaitEvent(st, g.ev, 0);
@@ -1394,6 +1415,7 @@ struct PacedTurn {
 		g.valid = true;
 	}
 };
+void register_stream(hipStream_t st) { PacedTurn::add(st); }
 void forget_stream(hipStream_t st) { PacedTurn::forget(st); }
 
 static void launch_expand12_paced(const int8_t *parents, int8_t *children, uint8_t *solved, long long *stats, size_t n, const PaceConfig &pc,

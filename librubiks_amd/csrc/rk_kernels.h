@@ -28,6 +28,7 @@ int read_bad_actions(hipStream_t st);
 void set_pace_override(int mode);
 int calibrate_pacing(bool force);
 void get_pacing(unsigned *tau_ps, int *source, float *us5);
+void register_stream(hipStream_t st);
 void forget_stream(hipStream_t st);
 void launch_apply_sequences(const uint8_t *actions, int moves, int games, int with_solved, int only_last, int8_t *out,
                             hipStream_t st);

@@ -20,14 +20,22 @@ iterations; steps after the decision are no-ops on the device):
   4. `rk_astar_shard_insert`: first the shortcut offers that arrived (relaxation case 2 of the PREVIOUS iteration, on
      the parents' owner), then membership, first-occurrence de-duplication in arrival order, append, goal test,
      relaxation case 1, one-hot of the new states;
-  5. value net on the NEW states only, `rk_astar_shard_push`: cost, push into the local queue, this iteration's shortcut
+  5. value net on the NEW states only, `rk_astar_shard_push_rows`: cost, push into the local queue, this iteration's shortcut
      offers into the send blocks (they ride on the next all-to-all, so relaxation case 2 costs no collective of its
      own), next candidates, next all-gather contribution.  All ranks together pop at most N nodes, so a rank can receive
      at most 12 N children and appends at most 12 N new states, whatever the world size: the net batch is bounded by
-     12 N rows, not world * 12 N.  A rank expects 12 N / world of them, so the net runs in two pieces: the first
-     ceil(12 N / world) rows at once, without waiting for anything; while the GPU works on them the host reads the
-     iteration's new-state count (4 bytes, asynchronous copy into pinned memory + event) and enqueues the remaining
-     rows, rounded up to 64, only if there are any.  With world = 1 the first piece is the whole batch and nothing waits.
+     12 N rows, not world * 12 N.  A rank EXPECTS 12 N / world of them (owner = hash), so the net runs on a FIXED number of
+     rows a little above that (`net_rows`: mean + 6 sigma of the multinomial share + 64, rounded up to 64) -- no count travels
+     to the host and nothing waits (round 4 read the count back every iteration and blocked on it).  Should an iteration ever
+     bring a rank more new states than rows, the engine says so in its all-gather contribution (error 3), every rank stops
+     at the next decision, and the driver repeats the search with the full 12 N-row batch: the search is a pure function of
+     its inputs, so the repeat gives what a run without the shortfall would have given.
+
+The whole iteration -- all-gather, select, all-to-all, insert, net, push -- is a fixed sequence of launches on fixed buffers with
+nothing written by the host (rank 0's clock for the time limit is the device's, started by the engine at the reset), so with device
+collectives (`nccl`, `rk_comm`) or world = 1 it is captured ONCE as a hipGraph (`use_hipgraph=True`) and replayed: one host launch
+per iteration, one 64-byte read of the decision every `poll` iterations.  The graph is kept from search to search (it holds
+addresses and the by-value scalars lambda / limits / row count, nothing of a search).
 
 The action queue is rebuilt by walking (rank, index) parent references with one small broadcast per hop.
 
@@ -67,19 +75,21 @@ class Transport:
 		self.shortcut = self.world == 1 and not (force_collectives and self.active)
 		self.collectives = 0
 
-	def all_gather(self, mine: torch.Tensor) -> torch.Tensor:
-		"""(world, len(mine)) device tensor of every rank's vector."""
+	def all_gather(self, mine: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+		"""(world, len(mine)) device tensor of every rank's vector; into `out` when given (the search loop's preallocated buffer)."""
 		if self.shortcut:
 			return mine.view(1, -1)
 		self.collectives += 1
-		if self.on_device:
+		if out is None:
 			out = torch.empty((self.world, mine.numel()), dtype=mine.dtype, device=mine.device)
+		if self.on_device:
 			dist.all_gather_into_tensor(out, mine, group=self.group)
 			return out
 		host = mine.cpu()
 		parts = [torch.empty_like(host) for _ in range(self.world)]
 		dist.all_gather(parts, host, group=self.group)
-		return torch.stack(parts).to(mine.device)
+		out.copy_(torch.stack(parts))
+		return out
 
 	def all_to_all(self, send: torch.Tensor, recv: torch.Tensor) -> torch.Tensor:
 		"""send, recv: (world, block) uint8 device tensors; row p of `send` goes to rank p, row q of `recv` comes from rank q."""
@@ -137,9 +147,10 @@ class RcclTransport:
 		except Exception:
 			pass
 
-	def all_gather(self, mine: torch.Tensor) -> torch.Tensor:
+	def all_gather(self, mine: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
 		self.collectives += 1
-		out = torch.empty((self.world, mine.numel()), dtype=mine.dtype, device=mine.device)
+		if out is None:
+			out = torch.empty((self.world, mine.numel()), dtype=mine.dtype, device=mine.device)
 		_ffi.check(_ffi.lib().rk_comm_all_gather(self._h, mine.data_ptr(), out.data_ptr(), mine.numel() * mine.element_size(), _ffi.stream_ptr()))
 		return out
 
@@ -154,12 +165,18 @@ class RcclTransport:
 		return t.cpu().numpy()
 
 
-def first_piece_rows(K: int, world: int) -> int:
-	"""Rows of a rank's net batch that are evaluated without waiting for the iteration's new-state count: all K = 12 N with one
-	rank (nothing ever waits), else a rank's expected share ceil(K / world) rounded up to 64, never more than K."""
+def net_rows(K: int, world: int) -> int:
+	"""
+	Rows of a rank's net batch, FIXED for the whole search: all K = 12 N with one rank; else the rank's expected share of the at
+	most K new states of an iteration (owner = hash: multinomial, mean K / world) plus six standard deviations plus 64, rounded
+	up to 64, never more than K.  N = 700 on 8 ranks: 1 344 of 8 400 rows; a shortfall has a probability of about 1e-9 per rank
+	and iteration, is detected on the device (rk_astar_shard_push_rows) and costs a repeated search, never a wrong one.
+	"""
 	if world <= 1:
 		return K
-	return min(K, -(-(-(-K // world)) // 64) * 64)
+	mu = K / world
+	rows = mu + 6.0 * (mu * (1.0 - 1.0 / world)) ** 0.5 + 64.0
+	return min(K, -(-int(rows + 0.999999) // 64) * 64)
 
 
 def select_pops(heads: np.ndarray, n: int) -> np.ndarray:
@@ -183,20 +200,31 @@ class ShardedAStar(DeepAgent):
 	"""Collective agent: every rank constructs it and calls `search` with the same arguments."""
 
 	def __init__(self, net, lambda_: float, expansions: int, capacity: int = 2_000_000, group=None, force_collectives: bool = False,
-	             poll: int = 1, profile: bool = False, fused_first_layer=False, transport=None):
+	             poll: int = 1, profile: bool = False, fused_first_layer=False, transport=None, use_hipgraph: bool = False, full_rows: bool = False):
 		# fused_first_layer (True / "epilogue" / "folded"): the net's first Linear reads the new nodes' 20-byte states
 		super().__init__(net, fused_first_layer)
 		self.lambda_, self.expansions, self.capacity = lambda_, int(expansions), int(capacity)
 		self.tp = transport if transport is not None else Transport(group, force_collectives)      # torch.distributed unless told otherwise
 		self.poll = max(1, int(poll))
-		self.profile = profile                 # record device-time per phase (HIP events); read `self.phase_ms` afterwards
+		self.profile = profile                 # record device-time per phase (HIP events); read `self.phase_ms` afterwards (eager iterations)
 		self.phase_ms = {}
+		# use_hipgraph: replay the iteration as ONE hipGraph launch (device collectives or world = 1 only; host-staged gloo cannot be
+		# captured).  A capture that fails (a collective the stack cannot capture) is reported in `graph_error` and the search runs eagerly.
+		self.use_hipgraph = bool(use_hipgraph)
+		self.graph_error = None
+		self.captures = 0
+		self.host_launches = 0                 # launches the host issued during the last search's loop (graph replays or eager calls into the library / torch)
+		self.full_rows = bool(full_rows)       # evaluate the net on all 12 N rows (what a search repeated after a row shortfall does)
+		self.repeated = 0                      # searches repeated with the full-width batch after a row shortfall
+		self.rows_override = None              # tests: a row count small enough for the shortfall to happen
 		self._h = None
+		self._bufs = None
+		self._graph_cache = None
 		self.iterations = 0
 		self.total_states = 0
 		self.stop_reason = "running"
 		self._n = 0
-		self.net_rows_max = 0                  # rows pushed through the net: largest iteration / sum over the last search
+		self.net_rows_max = 0                  # rows pushed through the net: per iteration (fixed) / sum over the last search
 		self.net_rows_total = 0
 
 	def _engine(self):
@@ -208,16 +236,60 @@ class ShardedAStar(DeepAgent):
 
 	def __del__(self):
 		try:
+			self._graph_cache = None
 			if self._h is not None:
 				_ffi.lib().rk_astar_destroy(self._h)
 				self._h = None
 		except Exception:
 			pass
 
+	def _buffers(self, h, code, oh_dtype):
+		"""The search's device buffers, allocated once per engine and row type: a kept hipGraph holds their addresses."""
+		lib, tp, K = _ffi.lib(), self.tp, 12 * self.expansions
+		if self._bufs is not None and self._bufs["code"] == code:
+			return self._bufs
+		self._graph_cache = None
+		block, glen = int(lib.rk_astar_shard_block_bytes(h)), int(lib.rk_astar_shard_gather_len(h))
+		send = torch.zeros((tp.world, block), dtype=torch.uint8, device=gpu)
+		mine = torch.zeros(glen, dtype=torch.float64, device=gpu)
+		if code == _ffi.OH_STATES:
+			oh = torch.from_numpy(cube.repeat_state(cube.get_solved(), K)).to(gpu)                  # rows = states: valid codes everywhere
+		else:
+			oh = torch.zeros((K, 480), dtype=oh_dtype, device=gpu)
+		self._bufs = {"code": code, "send": send, "recv": send if tp.shortcut else torch.zeros_like(send), "mine": mine,
+		              "gathered": mine.view(1, -1) if tp.shortcut else torch.zeros((tp.world, glen), dtype=torch.float64, device=gpu), "oh": oh}
+		_ffi.check(lib.rk_astar_shard_bind(h, mine.data_ptr()))
+		return self._bufs
+
+	def _iteration(self, h, b, forward, rows, time_limit, max_states, marks=None):
+		"""One iteration: a fixed sequence of launches on fixed buffers, nothing from the host but the launches themselves."""
+		lib, tp, st = _ffi.lib(), self.tp, _ffi.stream_ptr
+
+		def mark():
+			if marks is not None:
+				e = torch.cuda.Event(enable_timing=True)
+				e.record()
+				marks.append(e)
+
+		mark()
+		gathered = tp.all_gather(b["mine"], b["gathered"])               # collective 1: heads + status
+		mark()
+		_ffi.check(lib.rk_astar_shard_select(h, gathered.data_ptr(), float(time_limit), float(max_states), b["send"].data_ptr(), st()))
+		mark()
+		got = tp.all_to_all(b["send"], b["recv"])                        # collective 2: records (+ last iteration's offers)
+		mark()
+		_ffi.check(lib.rk_astar_shard_insert(h, got.data_ptr(), b["send"].data_ptr(), b["oh"].data_ptr(), b["code"], st()))
+		mark()
+		values = _values_for_engine(h, _sliced_value_forward(forward, b["oh"][:rows]))
+		self._keep = values                                              # the push kernels read it after this call returns
+		mark()
+		_ffi.check(lib.rk_astar_shard_push_rows(h, values.data_ptr(), rows, got.data_ptr(), b["send"].data_ptr(), st()))
+		mark()
+
 	@no_grad
 	def search(self, state: np.ndarray, time_limit: float = None, max_states: int = None) -> bool:
 		_ffi.require_gpu()
-		t0 = time.perf_counter()
+		limits = (time_limit, max_states)
 		time_limit, max_states = self.reset(time_limit, max_states)
 		self.iterations, self.stop_reason = 0, "running"
 		state = np.ascontiguousarray(state, dtype=np.int8)
@@ -227,80 +299,65 @@ class ShardedAStar(DeepAgent):
 		lib, tp, N = _ffi.lib(), self.tp, self.expansions
 		h = self._engine()
 		st = _ffi.stream_ptr
-		block, glen = int(lib.rk_astar_shard_block_bytes(h)), int(lib.rk_astar_shard_gather_len(h))
-		send = torch.zeros((tp.world, block), dtype=torch.uint8, device=gpu)
-		recv = send if tp.shortcut else torch.zeros_like(send)
-		mine = torch.zeros(glen, dtype=torch.float64, device=gpu)
-		_ffi.check(lib.rk_astar_shard_bind(h, mine.data_ptr()))
-		_ffi.check(lib.rk_astar_shard_reset(h, state.ctypes.data, float(self.lambda_), send.data_ptr(), st()))
-		root_owner = lib.rk_shard_owner(state.ctypes.data, tp.world)
 		K = 12 * N                                                       # upper bound of a rank's new states per iteration
-		first = first_piece_rows(K, tp.world)                            # rows evaluated without waiting for the count
+		rows = K if self.full_rows else min(K, self.rows_override or net_rows(K, tp.world))   # rows the net evaluates every iteration
 		self._fs = self._from_states                                     # re-copied here if the net changed since the last search
 		if self._fs is not None:
-			oh = torch.from_numpy(cube.repeat_state(cube.get_solved(), K)).to(gpu)                     # rows = states
-			code, forward = _ffi.OH_STATES, self._fs
+			code, oh_dtype, forward = _ffi.OH_STATES, None, self._fs
 		else:
 			oh_dtype = _oh_dtype(self.net)
-			oh = torch.zeros((K, 480), dtype=oh_dtype, device=gpu)
 			code, forward = _OH_CODES[oh_dtype], self.net
-		n_new_host = torch.zeros(1, dtype=torch.int32).pin_memory() if first < K else None
-		counted = torch.cuda.Event() if first < K else None
-		vals = None                                                      # (K,) values of both pieces, in the net's value dtype
-		self.net_rows_max = self.net_rows_total = 0
+		b = self._buffers(h, code, oh_dtype)
+		_ffi.check(lib.rk_astar_shard_reset(h, state.ctypes.data, float(self.lambda_), b["send"].data_ptr(), st()))
+		root_owner = lib.rk_shard_owner(state.ctypes.data, tp.world)
+		self.net_rows_max, self.net_rows_total, self.host_launches = rows, 0, 0
 		decision = (C.c_longlong * 8)()
-		marks = []                                                       # per iteration: events between the phases
+		marks = []                                                       # per eager iteration: events between the phases
 
-		def mark(row):
-			if self.profile:
-				e = torch.cuda.Event(enable_timing=True)
-				e.record()
-				row.append(e)
+		graph = None
+		if self.use_hipgraph and not self.profile and (tp.shortcut or tp.on_device):
+			# the captured iteration holds addresses (engine, buffers, the net's tensors) and scalars passed by value (lambda, the two
+			# limits, the row count, the values' dtype) -- nothing of the search, which lives in device memory the reset rewrites
+			key = (h.value, rows, code, float(self.lambda_), float(time_limit), float(max_states), b["oh"].data_ptr(), _capture_key(self.net, self._fs))
+			if self._graph_cache is not None and self._graph_cache[0] == key:
+				graph = self._graph_cache[1]
+			else:
+				self._graph_cache = None
+				try:
+					side = torch.cuda.Stream()
+					side.wait_stream(torch.cuda.current_stream())
+					with torch.cuda.stream(side):
+						self._iteration(h, b, forward, rows, time_limit, max_states)      # a real iteration; also warms the allocator and the collectives
+					torch.cuda.current_stream().wait_stream(side)
+					graph = torch.cuda.CUDAGraph()
+					with torch.cuda.graph(graph):
+						self._iteration(h, b, forward, rows, time_limit, max_states)
+					self._graph_cache = (key, graph, (self.net, self._fs))
+					self.captures += 1
+					self.net_rows_total += rows
+				except Exception as e:                                      # e.g. a collective this stack cannot capture: say so, run eagerly
+					self.graph_error = f"{type(e).__name__}: {e}"[:300]
+					self.use_hipgraph, graph, self._graph_cache = False, None, None
+					torch.cuda.synchronize()
+					return self.search(state, *limits)                        # the engine may be mid-iteration: start over, eagerly
 
 		stop, it = 0, 0
 		while True:
-			row = []
-			mark(row)
-			mine[5:6].fill_(time.perf_counter() - t0)                    # rank 0's clock decides for everybody
-			gathered = tp.all_gather(mine)                               # collective 1: heads + status
-			mark(row)
-			_ffi.check(lib.rk_astar_shard_select(h, gathered.data_ptr(), float(time_limit), float(max_states), send.data_ptr(), st()))
-			it += 1
-			if it % self.poll == 0:
-				_ffi.check(lib.rk_astar_shard_decision(h, decision, st()))   # the only host synchronisation
-				stop = int(decision[0])
-				if stop:
-					break
-			mark(row)
-			got = tp.all_to_all(send, recv)                              # collective 2: records (+ last iteration's offers)
-			mark(row)
-			_ffi.check(lib.rk_astar_shard_insert(h, got.data_ptr(), send.data_ptr(), oh.data_ptr(), code, st()))
-			mark(row)
-			if first == K:
-				values = _values_for_engine(h, _sliced_value_forward(forward, oh))
-				rows = K
-			else:
-				_ffi.check(lib.rk_astar_shard_new_count(h, n_new_host.data_ptr(), st()))
-				counted.record()
-				v0 = _values_for_engine(h, _sliced_value_forward(forward, oh[:first]))
-				if vals is None or vals.dtype != v0.dtype:
-					vals = torch.zeros(K, dtype=v0.dtype, device=gpu)
-				vals[:first].copy_(v0)
-				counted.synchronize()                                    # the GPU is busy with the first piece meanwhile
-				rows = first
-				n_new = int(n_new_host[0])
-				if n_new > first:
-					rows = min(K, -(-n_new // 64) * 64)
-					vals[first:rows].copy_(_values_for_engine(h, _sliced_value_forward(forward, oh[first:rows])))
-				values = vals
-			self.net_rows_max = max(self.net_rows_max, rows)
-			self.net_rows_total += rows
-			self._keep = (values, gathered)
-			mark(row)
-			_ffi.check(lib.rk_astar_shard_push(h, values.data_ptr(), got.data_ptr(), send.data_ptr(), st()))
-			mark(row)
-			if self.profile and len(marks) < 4096:
-				marks.append(row)
+			for _ in range(self.poll):
+				if graph is not None:
+					graph.replay()
+					self.host_launches += 1
+				else:
+					row = [] if self.profile else None
+					self._iteration(h, b, forward, rows, time_limit, max_states, row)
+					if row is not None and len(marks) < 4096:
+						marks.append(row)
+				it += 1
+				self.net_rows_total += rows
+			_ffi.check(lib.rk_astar_shard_decision(h, decision, st()))       # the only host synchronisation: every `poll` iterations
+			stop = int(decision[0])
+			if stop:
+				break                                                    # (iterations after the decision were no-ops on the device)
 		self.stop_reason = STOP_REASONS.get(stop, str(stop))
 		self.total_states, self.iterations, self._n = int(decision[3]), int(decision[5]), int(decision[6])
 		if self.profile and marks:
@@ -311,15 +368,21 @@ class ShardedAStar(DeepAgent):
 				tot += [row[i].elapsed_time(row[i + 1]) for i in range(len(names))]
 			self.phase_ms = {n: float(t / len(marks)) for n, t in zip(names, tot)}
 			self.phase_ms["iterations_timed"] = len(marks)
+		if stop == 6 and int(decision[7]) == 3 and not self.full_rows:
+			# a rank received more new states than the net evaluated rows for: repeat with the full-width batch (same result as a
+			# run without the shortfall: the search is deterministic); the agent keeps the full width from now on
+			self.full_rows, self._graph_cache = True, None
+			self.repeated += 1
+			return self.search(state, *limits)
 		if stop == 6:
-			raise _ffi.RubiksHipError(f"rank {tp.rank}: a rank reported an engine error; every rank stops together")
+			raise _ffi.RubiksHipError(f"rank {tp.rank}: a rank reported engine error {int(decision[7])}; every rank stops together")
 		if stop == 1:
 			self._walk(int(decision[1]), int(decision[2]), root_owner)
 			return True
-		# no win: the shortcut offers of the last iteration are still in the send blocks; deliver and apply them
-		got = tp.all_to_all(send, recv)
+		# no win: shortcut offers may still sit in the send blocks; deliver and apply them
+		got = tp.all_to_all(b["send"], b["recv"])
 		_ffi.check(lib.rk_astar_shard_flush(h, got.data_ptr(), st()))
-		_ffi.check(lib.rk_astar_shard_clear_send(h, send.data_ptr(), 1, 1, st()))
+		_ffi.check(lib.rk_astar_shard_clear_send(h, b["send"].data_ptr(), 1, 1, st()))
 		return False
 
 	def _walk(self, rank: int, idx: int, root_owner: int):

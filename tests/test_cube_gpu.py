@@ -875,9 +875,11 @@ def test_calibrated_schedule_is_one_of_the_candidates_and_changes_no_result():
 
 
 def test_a_stream_destroyed_between_two_paced_launches():
-	"""VERDICT r4 #6 / advisor: the turn-taking of paced launches remembers the previous paced launch's stream.  The owner of that
-	stream destroys it -- once after rk_stream_forget (the contract), once without (the library asks the runtime about the handle
-	before touching it) -- and the next paced launch on another stream neither faults nor waits, and its children are right."""
+	"""VERDICT r4 #6 / advisor: the turn-taking of paced launches remembers the previous paced launch's stream -- but only a stream
+	it may rely on: the null stream or a REGISTERED one (rk_stream_register: alive until rk_stream_forget).  (1) A caller's own stream,
+	never registered, runs a paced launch and is destroyed: nothing of it was kept, the next paced launch on torch's stream neither
+	faults nor waits.  (2) Registered, used, forgotten, destroyed: the same.  (3) Two registered live streams do take turns and both
+	results are right.  On this HIP runtime touching a destroyed stream's handle is a segmentation fault, so a fault here IS the test."""
 	hip = C.CDLL("libamdhip64.so")
 	hip.hipStreamCreate.argtypes, hip.hipStreamDestroy.argtypes, hip.hipStreamSynchronize.argtypes = [C.POINTER(C.c_void_p)], [C.c_void_p], [C.c_void_p]
 	lib = _ffi.lib()
@@ -888,17 +890,34 @@ def test_a_stream_destroyed_between_two_paced_launches():
 	children = torch.empty((12 * n, 20), dtype=torch.int8, device="cuda")
 	flags = torch.empty(12 * n, dtype=torch.uint8, device="cuda")
 	torch.cuda.synchronize()
-	for forget in (True, False):
+	for register in (False, True):
 		s = C.c_void_p()
 		assert hip.hipStreamCreate(C.byref(s)) == 0
+		if register:
+			_ffi.check(lib.rk_stream_register(s))
 		_ffi.check(lib.rk_expand12(_ffi.REPR_2024, d_p.data_ptr(), children.data_ptr(), flags.data_ptr(), None, n, s))       # paced, on the caller's own stream
 		assert hip.hipStreamSynchronize(s) == 0
-		if forget:
+		assert np.array_equal(children.cpu().numpy(), want)
+		if register:
 			_ffi.check(lib.rk_stream_forget(s))
 		assert hip.hipStreamDestroy(s) == 0
-		children.zero_()
-		torch.cuda.synchronize()
-		ch, fl = cube.device.expand12(d_p)                              # paced, on torch's stream: the gate still names the dead stream unless forgotten
+		ch, fl = cube.device.expand12(d_p)                              # paced, on torch's stream
 		torch.cuda.synchronize()
 		assert np.array_equal(ch.cpu().numpy(), want)
-	assert lib.rk_stream_forget(None) == 0
+	# two live registered streams: the second launch waits for the first (an event on the first's stream), results are both right
+	a, b = C.c_void_p(), C.c_void_p()
+	assert hip.hipStreamCreate(C.byref(a)) == 0 and hip.hipStreamCreate(C.byref(b)) == 0
+	_ffi.check(lib.rk_stream_register(a)); _ffi.check(lib.rk_stream_register(b))
+	children2 = torch.zeros_like(children)
+	torch.cuda.synchronize()
+	_ffi.check(lib.rk_expand12(_ffi.REPR_2024, d_p.data_ptr(), children.data_ptr(), flags.data_ptr(), None, n, a))
+	_ffi.check(lib.rk_expand12(_ffi.REPR_2024, d_p.data_ptr(), children2.data_ptr(), flags.data_ptr(), None, n, b))
+	assert hip.hipStreamSynchronize(b) == 0 and hip.hipStreamSynchronize(a) == 0
+	assert torch.equal(children, children2) and np.array_equal(children2.cpu().numpy(), want)
+	for s in (a, b):
+		_ffi.check(lib.rk_stream_forget(s))
+		assert hip.hipStreamDestroy(s) == 0
+	ch, _ = cube.device.expand12(d_p)
+	torch.cuda.synchronize()
+	assert np.array_equal(ch.cpu().numpy(), want)
+	assert lib.rk_stream_forget(None) == 0 and lib.rk_stream_register(None) == 0

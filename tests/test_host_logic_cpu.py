@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from librubiks_amd.solving.agents import DeepAgent, NET_SLICE_ROWS, _net_signature, _sliced_value_forward
-from librubiks_amd.solving.sharded import first_piece_rows
+from librubiks_amd.solving.sharded import net_rows
 
 
 class TinyNet(torch.nn.Module):
@@ -81,12 +81,15 @@ def test_sliced_value_forward_equals_one_forward():
 	assert torch.equal(_sliced_value_forward(both, rows, 256).reshape(-1), rows[:, 0] + 1)
 
 
-def test_first_piece_of_the_sharded_net_batch():
-	for N in (1, 10, 27, 100, 700, 1000):
+def test_fixed_rows_of_the_sharded_net_batch():
+	"""The net of a sharded search runs on a FIXED number of rows per iteration (no count travels to the host): a rank's expected
+	share of the 12 N children plus six standard deviations plus 64, in multiples of 64, never more than 12 N."""
+	for N in (1, 10, 27, 100, 700, 1000, 5600):
 		K = 12 * N
-		assert first_piece_rows(K, 1) == K                                # one rank: the whole batch at once, nothing waits
+		assert net_rows(K, 1) == K                                        # one rank: the whole batch
 		for world in (2, 3, 8, 64):
-			f = first_piece_rows(K, world)
-			assert -(-K // world) <= f <= K and (f % 64 == 0 or f == K)
-			assert f < -(-K // world) + 64
-	assert first_piece_rows(8400, 8) == 1088 and first_piece_rows(8400, 2) == 4224
+			f = net_rows(K, world)
+			mu = K / world
+			assert min(K, mu + 6 * (mu * (1 - 1 / world)) ** 0.5 + 64) <= f <= K and (f % 64 == 0 or f == K)
+			assert f < mu + 6 * mu ** 0.5 + 64 + 64 or f == K
+	assert net_rows(8400, 8) == 1344 and net_rows(8400, 2) == 4544 and net_rows(67200, 8) == 9024

@@ -546,3 +546,140 @@ def test_rk_comm_transport_world1(tmp_path):
 	assert (z["states"] == rs).all() and (z["G"] == rG).all() and (z["parents"] == rp).all() and (z["pact"] == ra).all()
 	assert z["queue"].tolist() == list(ref.action_queue)
 	assert int(z["collectives"]) >= 2 * int(z["iters"])                        # two collectives per iteration went through RCCL
+
+
+# ------------------------------------------------------------------------------------------------- round 5: the iteration is host-free and capturable
+@pytest.mark.parametrize("tag", ["a", "b", "d", "e", "f"])
+def test_world1_captured_iteration_reproduces_reference_traces(golden, tag):
+	"""the sharded iteration -- gather, select, exchange, insert, net, push -- replayed as ONE hipGraph launch
+	(world 1: the collectives short-circuit) gives the reference's traces bit for bit; the graph is kept from search to search."""
+	t = golden["astar_trace"]
+	_, _, expansions, max_states = (int(x) for x in t[f"{tag}_params"])
+	agent = ShardedAStar(NoisyStubNet() if tag in ("e", "f") else StubNet(), float(t[f"{tag}_lambda"]), expansions, capacity=max_states + 16,
+	                     use_hipgraph=True, poll=3)
+	for again in range(2):
+		solved = agent.search(t[f"{tag}_start"], None, max_states)
+		assert agent.graph_error is None and agent.captures == 1                     # captured once, replayed by the second search
+		assert agent.host_launches >= agent.iterations - 1                           # one launch per iteration (the first one ran eagerly, before the capture)
+		n = int(t[f"{tag}_n"])
+		assert solved == bool(t[f"{tag}_solved"]) and len(agent) == n
+		states, G, parents, pact = agent.local_arrays()
+		assert (states[1:] == t[f"{tag}_states"]).all() and (G[1:] == t[f"{tag}_G"]).all()
+		assert (parents[2:] == t[f"{tag}_parents"]).all() and (pact[2:] == t[f"{tag}_parent_actions"]).all()
+		assert list(agent.action_queue) == t[f"{tag}_action_queue"].tolist()
+
+
+def _captured_collectives_world1(rank, port, out_path, tags, how):
+	"""One rank, collectives FORCED and on the device (torch's nccl = RCCL, or rk_comm): the captured iteration contains the
+	all-gather and the all-to-all themselves."""
+	import json
+	import torch.distributed as dist
+	from librubiks_amd.solving.sharded import RcclTransport
+	from tests.conftest import GOLDEN
+	torch.cuda.set_device(0)
+	t = dict(np.load(os.path.join(GOLDEN, "astar_trace.npz")))
+	if how == "nccl":
+		os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+		dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+	out = {}
+	try:
+		for tag in tags:
+			_, _, expansions, max_states = (int(x) for x in t[f"{tag}_params"])
+			kw = {"force_collectives": True} if how == "nccl" else {"transport": RcclTransport(RcclTransport.unique_id(), 0, 1)}
+			agent = ShardedAStar(NoisyStubNet() if tag in ("e", "f") else StubNet(), float(t[f"{tag}_lambda"]), expansions, capacity=max_states + 16,
+			                     use_hipgraph=True, poll=4, **kw)
+			assert agent.tp.on_device and not agent.tp.shortcut
+			solved = agent.search(t[f"{tag}_start"], None, max_states)
+			states, G, parents, pact = agent.local_arrays()
+			ok = (solved == bool(t[f"{tag}_solved"]) and len(agent) == int(t[f"{tag}_n"]) and (states[1:] == t[f"{tag}_states"]).all()
+			      and (G[1:] == t[f"{tag}_G"]).all() and (parents[2:] == t[f"{tag}_parents"]).all() and (pact[2:] == t[f"{tag}_parent_actions"]).all()
+			      and list(agent.action_queue) == t[f"{tag}_action_queue"].tolist())
+			out[tag] = {"equal": bool(ok), "graph_error": agent.graph_error, "captures": agent.captures, "launches": agent.host_launches,
+			            "iterations": agent.iterations, "collectives": agent.tp.collectives}
+			del agent
+	finally:
+		if how == "nccl":
+			dist.destroy_process_group()
+	with open(out_path, "w") as f:
+		json.dump(out, f)
+
+
+@pytest.mark.parametrize("how", ["nccl", "rk_comm"])
+def test_captured_iteration_with_device_collectives_world1(tmp_path, how):
+	"""VERDICT r4 #2 "done": with the collectives forced at world 1 over RCCL (torch's nccl backend; the C ABI's rk_comm) the
+	captured loop gives the reference traces a / b / d / e / f bit for bit, with at most one host launch per iteration.  A stack
+	that cannot capture a collective must say so (graph_error) and still give the traces, eagerly."""
+	import json
+	out = str(tmp_path / "cap.json")
+	mp.spawn(_captured_collectives_world1, args=(_free_port(), out, ["a", "b", "d", "e", "f"], how), nprocs=1, join=True)
+	z = json.load(open(out))
+	print(how, z)
+	for tag, r in z.items():
+		assert r["equal"], (tag, r)
+		if r["graph_error"] is None:
+			assert r["captures"] == 1 and r["launches"] >= r["iterations"] - 1
+
+
+def _rank_row_shortfall(rank, world, port, out_dir):
+	import torch.distributed as dist
+	os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+	dist.init_process_group("gloo", rank=rank, world_size=world)
+	try:
+		torch.cuda.set_device(0)
+		np.random.seed(19)
+		start, _, _ = orc.scramble(7, True)
+		agent = ShardedAStar(StubNet(), 0.1, 300, capacity=60_000, poll=3)
+		agent.rows_override = 64                                             # far below a rank's share of 3 600 children: the shortfall happens at once
+		solved = agent.search(start, None, 60_000)
+		states, G, parents, pact = agent.local_arrays()
+		np.savez(os.path.join(out_dir, f"sf_r{rank}.npz"), solved=solved, states=states[1:], G=G[1:], parents=parents[1:], pact=pact[1:],
+		         prank=agent.local_parent_ranks()[1:], iters=agent.iterations, repeated=agent.repeated, full=agent.full_rows, rows=agent.net_rows_max,
+		         queue=np.array(agent.action_queue, dtype=np.int64), start=start)
+	finally:
+		dist.destroy_process_group()
+
+
+def test_row_shortfall_repeats_the_search_with_the_full_batch(tmp_path):
+	"""The net runs on a fixed number of rows; an iteration that brings a rank more new states than that is detected ON THE DEVICE
+	(rk_astar_shard_push_rows: error 3 in the all-gather), every rank stops together, and the driver repeats the search with
+	12 N rows.  Forced here with 64 rows: both ranks repeat exactly once and end with the protocol oracle's shards."""
+	from oracle.sharded_oracle import ShardedAStarOracle
+	world = 2
+	mp.spawn(_rank_row_shortfall, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+	z = [np.load(tmp_path / f"sf_r{r}.npz") for r in range(world)]
+	assert all(int(x["repeated"]) == 1 and bool(x["full"]) and int(x["rows"]) == 3600 for x in z)
+	o = ShardedAStarOracle(StubNet(), 0.1, 300, world)
+	stop = o.search(z[0]["start"], 60_000)
+	assert (stop == 1) == bool(z[0]["solved"]) and int(z[0]["iters"]) == o.iterations and z[0]["queue"].tolist() == list(o.action_queue)
+	for r in range(world):
+		os_, oG, op, orank, oa = o.arrays(r)
+		assert (z[r]["states"] == os_).all() and (z[r]["G"] == oG).all() and (z[r]["parents"] == op).all()
+		assert (z[r]["prank"] == orank).all() and (z[r]["pact"] == oa).all()
+
+
+def test_device_clock_ends_a_search_on_time():
+	"""The time limit is decided on the device (rank 0's constant-rate clock, started at the reset): a search that runs for
+	T seconds without a limit stops with reason "time" shortly after a limit of T / 4, without the host writing anything per
+	iteration (eager and captured alike)."""
+	import time
+	for use_graph in (False, True):
+		agent = ShardedAStar(StubNet(), 0.05, 20, capacity=4_000_000, poll=8, use_hipgraph=use_graph)
+		found = False
+		for seed in range(5, 12):
+			np.random.seed(seed)
+			start, _, _ = orc.scramble(20, True)
+			agent.search(start, None, 50_000)                                     # engine, buffers, capture
+			torch.cuda.synchronize()
+			t0 = time.perf_counter()
+			agent.search(start, None, 4_000_000)
+			T = time.perf_counter() - t0
+			if agent.stop_reason != "budget" or T < 0.2:
+				continue                                                          # solved, or too quick to cut short: another scramble
+			found = True
+			t0 = time.perf_counter()
+			solved = agent.search(start, T / 4, 4_000_000)
+			dt = time.perf_counter() - t0
+			assert not solved and agent.stop_reason == "time" and T / 4 <= dt < 0.75 * T, (use_graph, agent.stop_reason, T, dt)
+			assert agent.total_states < 4_000_000 - 12 * 20
+			break
+		assert found
