@@ -423,6 +423,13 @@ int rk_mcts_backup_select(rk_mcts_t *h, const float *d_probs, const float *d_val
  * copy kernels of every simulation. */
 int rk_mcts_backup_select_logits(rk_mcts_t *h, const void *d_logits, int logits_stride, const void *d_values, int values_stride,
                                  int dtype, void *stream);
+/* The same for the trees first_tree ... first_tree + n_trees - 1 only; d_logits / d_values hold THEIR n_trees*12 rows (row 0 = child
+ * 0 of tree first_tree; their children lie at rk_mcts_children() + first_tree*12*20 bytes).  Trees are independent searches
+ * (agents.py:415-645 runs one at a time), so a step may advance the batch in parts, on different streams: while one part's
+ * latency-bound descent runs, the other part's net forward has the chip (MCTSBatch overlap_halves).  Every tree still sees exactly
+ * the reference's sequence select, expand, net, backup. */
+int rk_mcts_backup_select_logits_range(rk_mcts_t *h, int first_tree, int n_trees, const void *d_logits, int logits_stride,
+                                       const void *d_values, int values_stride, int dtype, void *stream);
 /* Device pointer to the (T*12, 20) int8 child states of the pending simulation (what rk_mcts_children_oh encodes): a net
  * whose first layer reads states (rk_ohl_forward) can take them where they lie. */
 const int8_t *rk_mcts_children(rk_mcts_t *h);

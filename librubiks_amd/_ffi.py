@@ -122,6 +122,7 @@ SIGNATURES = {
 	"rk_mcts_children_oh": (_i, [_vp, _vp, _i, _vp]),
 	"rk_mcts_backup_select": (_i, [_vp, _vp, _vp, _vp]),
 	"rk_mcts_backup_select_logits": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp]),
+	"rk_mcts_backup_select_logits_range": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
 	"rk_mcts_children": (_vp, [_vp]),
 	"rk_mcts_status": (_i, [_vp, _vp, _vp]),
 	"rk_mcts_export": (_i, [_vp, _i, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -326,12 +326,14 @@ __device__ __forceinline__ void child_policy(const void *probs, size_t row, int 
 // simulation: one launch and its dependent start-up less per simulation) -- as long as another simulation will follow,
 // i.e. this simulation's number is below ahead_limit (< 0: no limit).  The order of the reference's steps is unchanged:
 // select, expand, net, backup.
+// first_tree: the launch covers the trees first_tree ... first_tree + gridDim.x - 1 and `probs` / `values` hold THEIR rows only (row 0
+// = child 0 of tree first_tree): what a step that advances the batch in two halves on two streams passes (MCTSBatch overlap_halves).
 template <int IN>
 __global__ __launch_bounds__(64)
-void k_mcts_backup_select(MctsDev d, const void *probs, const void *values, int p_stride, int v_stride, int ahead_limit)
+void k_mcts_backup_select(MctsDev d, const void *probs, const void *values, int p_stride, int v_stride, int ahead_limit, int first_tree)
 {
 	__shared__ u32x4 s_act[36];
-	const int t = blockIdx.x, lane = threadIdx.x;
+	const int t = blockIdx.x + first_tree, lane = threadIdx.x;
 	if (ahead_limit != 0) stage_action_tables(s_act, lane);            // (one wave: visible to it without a barrier after the fence below)
 	const bool active = lane < 12;
 	const size_t node0 = (size_t)t * d.cap1;
@@ -346,7 +348,8 @@ void k_mcts_backup_select(MctsDev d, const void *probs, const void *values, int 
 	const int plen = tr.v[TR_PLEN], sims_before = tr.v[TR_SIMS];
 	const int idx = active ? d.child_idx[cbase] : 0;
 	const bool is_new = active && d.child_new[cbase] != 0;
-	const float vf = active ? net_scalar<IN>(values, cbase * (size_t)v_stride) : 0.0f;
+	const size_t rbase = (size_t)blockIdx.x * 12 + lane;                   // this child's row in the net's outputs of this launch
+	const float vf = active ? net_scalar<IN>(values, rbase * (size_t)v_stride) : 0.0f;
 	if (is_done) {
 		if (ahead_limit != 0 && active) d.child_new[cbase] = 0;            // (k_mcts_expand does this when it runs)
 		return;
@@ -362,7 +365,7 @@ void k_mcts_backup_select(MctsDev d, const void *probs, const void *values, int 
 		const Node child = node_of(d, node0, idx);
 		child.V() = v;                                                     // agents.py:557
 		float pk[12];
-		child_policy<IN>(probs, cbase, p_stride, pk);
+		child_policy<IN>(probs, rbase, p_stride, pk);
 		#pragma unroll
 		for (int k = 0; k < 12; k++) {
 			child.P()[k] = (double)pk[k];                                  // agents.py:556
@@ -967,7 +970,26 @@ int rk_mcts_backup_select(rk_mcts_t *h, const float *d_probs, const float *d_val
 {
 	if (!h || !h->ready) return fail(RK_ESTATE, "rk_mcts_backup_select: reset the engine first");
 	if (!d_probs || !d_values) return fail(RK_EINVAL, "rk_mcts_backup_select: null pointer");
-	hipLaunchKernelGGL(k_mcts_backup_select<0>, dim3(h->d.T), dim3(64), 0, (hipStream_t)stream, h->d, (const void *)d_probs, (const void *)d_values, 12, 1, h->ahead_limit);
+	hipLaunchKernelGGL(k_mcts_backup_select<0>, dim3(h->d.T), dim3(64), 0, (hipStream_t)stream, h->d, (const void *)d_probs, (const void *)d_values, 12, 1, h->ahead_limit, 0);
+	RK_HIP(hipGetLastError());
+	if (!capturing((hipStream_t)stream)) h->ahead = h->ahead_limit != 0;
+	return RK_OK;
+}
+
+static int backup_select_logits_impl(rk_mcts_t *h, int first_tree, int n_trees, const void *d_logits, int logits_stride, const void *d_values, int values_stride,
+                                     int dtype, void *stream)
+{
+	if (!h || !h->ready) return fail(RK_ESTATE, "rk_mcts_backup_select_logits: reset the engine first");
+	if (!d_logits || !d_values) return fail(RK_EINVAL, "rk_mcts_backup_select_logits: null pointer");
+	if (logits_stride < 12 || values_stride < 1) return fail(RK_EINVAL, "rk_mcts_backup_select_logits: strides are in elements, at least 12 and 1");
+	if (first_tree < 0 || n_trees < 1 || first_tree + n_trees > h->d.T)
+		return fail(RK_EINVAL, "rk_mcts_backup_select_logits_range: trees %d..%d outside 0..%d", first_tree, first_tree + n_trees, h->d.T);
+	if (dtype == RK_OH_F32)
+		hipLaunchKernelGGL(k_mcts_backup_select<1>, dim3(n_trees), dim3(64), 0, (hipStream_t)stream, h->d, d_logits, d_values, logits_stride, values_stride, h->ahead_limit, first_tree);
+	else if (dtype == RK_OH_BF16)
+		hipLaunchKernelGGL(k_mcts_backup_select<2>, dim3(n_trees), dim3(64), 0, (hipStream_t)stream, h->d, d_logits, d_values, logits_stride, values_stride, h->ahead_limit, first_tree);
+	else
+		return fail(RK_EINVAL, "rk_mcts_backup_select_logits: logits and values must be float32 or bfloat16");
 	RK_HIP(hipGetLastError());
 	if (!capturing((hipStream_t)stream)) h->ahead = h->ahead_limit != 0;
 	return RK_OK;
@@ -975,18 +997,13 @@ int rk_mcts_backup_select(rk_mcts_t *h, const float *d_probs, const float *d_val
 
 int rk_mcts_backup_select_logits(rk_mcts_t *h, const void *d_logits, int logits_stride, const void *d_values, int values_stride, int dtype, void *stream)
 {
-	if (!h || !h->ready) return fail(RK_ESTATE, "rk_mcts_backup_select_logits: reset the engine first");
-	if (!d_logits || !d_values) return fail(RK_EINVAL, "rk_mcts_backup_select_logits: null pointer");
-	if (logits_stride < 12 || values_stride < 1) return fail(RK_EINVAL, "rk_mcts_backup_select_logits: strides are in elements, at least 12 and 1");
-	if (dtype == RK_OH_F32)
-		hipLaunchKernelGGL(k_mcts_backup_select<1>, dim3(h->d.T), dim3(64), 0, (hipStream_t)stream, h->d, d_logits, d_values, logits_stride, values_stride, h->ahead_limit);
-	else if (dtype == RK_OH_BF16)
-		hipLaunchKernelGGL(k_mcts_backup_select<2>, dim3(h->d.T), dim3(64), 0, (hipStream_t)stream, h->d, d_logits, d_values, logits_stride, values_stride, h->ahead_limit);
-	else
-		return fail(RK_EINVAL, "rk_mcts_backup_select_logits: logits and values must be float32 or bfloat16");
-	RK_HIP(hipGetLastError());
-	if (!capturing((hipStream_t)stream)) h->ahead = h->ahead_limit != 0;
-	return RK_OK;
+	return backup_select_logits_impl(h, 0, h ? h->d.T : 1, d_logits, logits_stride, d_values, values_stride, dtype, stream);
+}
+
+int rk_mcts_backup_select_logits_range(rk_mcts_t *h, int first_tree, int n_trees, const void *d_logits, int logits_stride, const void *d_values,
+                                       int values_stride, int dtype, void *stream)
+{
+	return backup_select_logits_impl(h, first_tree, n_trees, d_logits, logits_stride, d_values, values_stride, dtype, stream);
 }
 
 const int8_t *rk_mcts_children(rk_mcts_t *h)

@@ -421,3 +421,65 @@ def test_hipgraph_is_kept_from_search_to_search():
 			assert a["n"] == n and (a["N"][1:n + 1] == r.N[1:n + 1]).all() and (a["W"][1:n + 1] == r.W[1:n + 1]).all(), (rep, i)
 			assert list(batch.action_queue_of(i)) == list(r.action_queue), (rep, i)
 	assert batch.captures == 1
+
+
+class _ExactModel(torch.nn.Module):
+	"""A net of the reference's structure (shared_net / policy_net / value_net, ref:model.py:117-141) whose arithmetic is EXACT in
+	float32 whatever the batch shape or the order of any sum: small-integer weights, ReLU, no normalisation.  The fused first layer
+	and the GEMMs of a half batch therefore produce the very bits the full batch produces."""
+	def __init__(self):
+		super().__init__()
+		g = torch.Generator().manual_seed(9)
+		ints = lambda *shape: torch.randint(-2, 3, shape, generator=g).float()
+		self.shared_net = torch.nn.Sequential(torch.nn.Linear(480, 16), torch.nn.ReLU(), torch.nn.Linear(16, 8), torch.nn.ReLU())
+		self.policy_net = torch.nn.Sequential(torch.nn.Linear(8, 12))
+		self.value_net = torch.nn.Sequential(torch.nn.Linear(8, 1))
+		with torch.no_grad():
+			for lin in (self.shared_net[0], self.shared_net[2], self.policy_net[0], self.value_net[0]):
+				lin.weight.copy_(ints(*lin.weight.shape))
+				lin.bias.copy_(ints(*lin.bias.shape))
+			self.policy_net[0].weight.mul_(0.125)                        # logits in eighths: distinct priors, still exact
+			self.value_net[0].weight.mul_(0.25)
+
+	def forward(self, x, policy=True, value=True):
+		x = self.shared_net(x)
+		out = ([self.policy_net(x)] if policy else []) + ([self.value_net(x)] if value else [])
+		return out if len(out) > 1 else out[0]
+
+
+@pytest.mark.parametrize("n_trees", [7, 16])
+def test_two_halves_on_two_streams_change_no_tree(n_trees):
+	"""the captured step that advances the batch as two halves on two streams, skewed by half a step (one half's
+	backup + descent under the other half's net forward), against the single-stream captured step and the eager step: every tree's
+	states, neighbours, leaves, P, V, N, W, L, status and action queue are the same -- also when the budget ends trees at different
+	simulations, when the pools grow in place on the way, and when the kept graph is replayed by a second search."""
+	net = _ExactModel().cuda().eval()
+	starts = []
+	for i in range(n_trees):
+		np.random.seed(500 + i)
+		starts.append(orc.scramble(3 + i % 9, True)[0])
+	starts = np.array(starts)
+	budgets = np.array([1500 + 700 * (i % 4) for i in range(n_trees)])
+
+	def run(overlap, use_graph, **kw):
+		agent = MCTSBatch(net, 0.8, n_trees, capacity=kw.pop("capacity", 5000), fused_first_layer=True, overlap_halves=overlap, **kw)
+		out = []
+		for again in range(2):                                           # the second search replays the kept graph
+			solved = agent.search(starts, max_states=budgets, max_sims=400, use_graph=use_graph, poll=7)
+			out.append((solved.copy(), agent.status.copy(), [agent.tree_arrays(t) for t in range(n_trees)], [list(agent.action_queue_of(t)) for t in range(n_trees)]))
+		return agent, out
+
+	_, eager = run(False, False)
+	_, single = run(False, True)
+	halves_agent, halves = run(True, True)
+	assert halves_agent.captures == 1 and halves_agent._graph_cache[0][0] == "halves"
+	grow_agent, grown = run(True, True, capacity=600, max_capacity=8000)
+	assert grow_agent.grown >= 1
+	for other in (single, halves, grown):
+		for (s0, st0, tr0, q0), (s1, st1, tr1, q1) in zip(eager, other):
+			assert (s0 == s1).all() and (st0[:, :5] == st1[:, :5]).all() and q0 == q1
+			for a, b in zip(tr0, tr1):
+				assert a["n"] == b["n"]
+				for k in ("states", "neighbors", "leaves", "P", "V", "N", "W", "L"):
+					assert (a[k][:a["n"] + 1] == b[k][:a["n"] + 1]).all(), k
+	assert 0 < eager[0][0].sum() < n_trees or n_trees == 7                   # solved and unsolved trees in the batch
