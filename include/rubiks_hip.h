@@ -169,6 +169,16 @@ int rk_multi_is_solved(int repr, const int8_t *d_states, uint8_t *d_flags, long 
 int rk_apply_sequences(int repr, const uint8_t *d_actions, int depth, int games, int with_solved,
                        int only_last, int8_t *d_out, void *stream);
 
+/* The cube part of one Autodidactic-Iteration rollout in ONE launch (train.py:277-292): d_actions uint8 (depth, games) as for
+ * rk_apply_sequences (not only_last) ->
+ *   d_states        (games*depth, 20)    the states along every game's walk, game-major            (cube.py:218-232; train.py:277)
+ *   d_state_flags   (games*depth) uint8  1 where such a state is solved, nullable                  (train.py:281)
+ *   d_children      (12*games*depth, 20) their children, parent-major, action-minor                (train.py:285)
+ *   d_child_flags   (12*games*depth) uint8 1 where a child is solved                               (train.py:292)
+ *   d_stats         int64[2], nullable, as rk_expand12's: [0] += solved children, [1] = min(first solved child, previous value)
+ * The same bytes as rk_apply_sequences + rk_multi_is_solved + rk_expand12, without writing the states once and reading them twice. */
+int rk_rollout_fanout(int repr, const uint8_t *d_actions, int depth, int games, int with_solved, int8_t *d_states, uint8_t *d_state_flags,
+                      int8_t *d_children, uint8_t *d_child_flags, long long *d_stats, void *stream);
 /* as_oh (cube.py:130-133, 265-277; 686: cube.py:363-369): one-hot encode n states into
  * (n, 480) [2024] or (n, 288) [686] elements of out_dtype (RK_OH_*); d_out 16-byte aligned. */
 int rk_as_oh(int repr, const int8_t *d_states, void *d_out, int out_dtype, size_t n, void *stream);

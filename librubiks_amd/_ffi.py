@@ -52,6 +52,7 @@ SIGNATURES = {
 	"rk_states_from_soa": (_i, [_vp, _vp, _sz, _vp]),
 	"rk_multi_is_solved": (_i, [_i, _vp, _vp, _vp, _sz, _vp]),
 	"rk_apply_sequences": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _vp]),
+	"rk_rollout_fanout": (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
 	"rk_as_oh": (_i, [_i, _vp, _vp, _i, _sz, _vp]),
 	"rk_ohl_create": (_i, [C.POINTER(_vp), _vp, _i, _vp, _i, _vp]),
 	"rk_ohl_destroy": (_i, [_vp]),

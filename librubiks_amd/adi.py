@@ -29,13 +29,11 @@ def adi_traindata(net, rollout_games: int, rollout_depth: int, alpha: float, rew
 	faces = np.random.randint(0, 6, (rollout_depth, rollout_games))
 	dirs = np.random.randint(0, 2, (rollout_depth, rollout_games))
 	acts = torch.from_numpy((2 * faces + (1 - dirs)).astype(np.uint8)).to(gpu)
-	states = cube.device.apply_sequences(acts, with_solved, False)                               # (games*depth, 20)
+	# walks, goal test of the scrambled states, fan-out and its goal test: ONE launch              train.py:277, :281, :285, :292
+	states, solved_scrambled, substates, solved_sub = cube.device.rollout_fanout(acts, with_solved)  # (games*depth, 20), ..., (12*games*depth, 20), ...
 	n = len(states)
 	oh_states = cube.device.as_oh(states)
-	solved_scrambled = cube.device.multi_is_solved(states).bool()                                 # train.py:281
-	# fan-out + goal test in one launch                                                           train.py:285, :292
-	substates, solved_sub = cube.device.expand12(states)
-	solved_sub = solved_sub.bool()
+	solved_scrambled, solved_sub = solved_scrambled.bool(), solved_sub.bool()
 	rewards = torch.where(solved_sub, torch.tensor(0.0 if reward_method == "reward0" else 1.0, device=gpu),
 	                      torch.tensor(-1.0, device=gpu))                                         # train.py:294-296
 	# value of every child, in slices so that the one-hot batch stays bounded                      train.py:301-303

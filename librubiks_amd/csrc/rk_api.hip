@@ -392,6 +392,25 @@ int rk_apply_sequences(int repr, const uint8_t *d_actions, int depth, int games,
 	return RK_OK;
 }
 
+int rk_rollout_fanout(int repr, const uint8_t *d_actions, int depth, int games, int with_solved, int8_t *d_states, uint8_t *d_state_flags,
+                      int8_t *d_children, uint8_t *d_child_flags, long long *d_stats, void *stream)
+{
+	if (int e = check_repr(repr)) return e;
+	if (repr != RK_REPR_2024) return fail(RK_EINVAL, "rk_rollout_fanout: only the 20-byte representation is implemented");
+	if (depth < 0 || games < 0) return fail(RK_EINVAL, "rk_rollout_fanout: negative size");
+	with_solved = with_solved ? 1 : 0;
+	const int moves = depth - with_solved;
+	if (games == 0 || moves < 0 || moves + with_solved == 0) return RK_OK;
+	if (!d_states || !d_children || !d_child_flags || (moves > 0 && !d_actions)) return fail(RK_EINVAL, "rk_rollout_fanout: null pointer");
+	if (misaligned(d_states, 4) || misaligned(d_children, 16) || misaligned(d_child_flags, 4))
+		return fail(RK_EINVAL, "rk_rollout_fanout: states / child flags must be 4-byte aligned, children 16-byte aligned");
+	if (d_stats && misaligned(d_stats, 8)) return fail(RK_EINVAL, "rk_rollout_fanout: stats must be 8-byte aligned");
+	if ((size_t)games * depth > ((size_t)1 << 31)) return fail(RK_EINVAL, "rk_rollout_fanout: more than 2^31 states");
+	launch_rollout_fanout(d_actions, moves, games, with_solved, d_states, d_state_flags, d_children, d_child_flags, d_stats, (hipStream_t)stream);
+	RK_HIP(hipGetLastError());
+	return RK_OK;
+}
+
 int rk_as_oh(int repr, const int8_t *d_states, void *d_out, int out_dtype, size_t n, void *stream)
 {
 	if (int e = check_repr(repr)) return e;

@@ -862,6 +862,89 @@ void k_apply_sequences(const uint8_t *__restrict__ actions, int moves, int games
 }
 
 // ================================================================================================================
+// rollout_fanout: the cube part of one ADI rollout in ONE launch                                   train.py:277-292
+//   states of `games` random walks along their `rows` steps (cube.py:218-232, game-major)  +  is each of them solved (train.py:281)
+//   +  their 12 children, parent-major (train.py:285)  +  is each child solved (train.py:292).
+// Round 4 ran this as three launches (k_apply_sequences, k_multi_is_solved, k_expand12r) on 225 k states -- 13 MB of states and
+// 61 MB of children, every launch in the band where the 3-5 us a launch costs before its first byte is a quarter of it, and the
+// states written by the first were read back by the other two.  Here a lane owns ONE state (game g, row r): it walks the game's
+// first moves itself (r + 1 of them, r with the solved state in front; 15 on average, twelve v_perm each -- nothing next to
+// the 272 bytes the state costs in stores; the walks of a tile read a handful of action bytes that sit in two or three cache
+// lines) and hands it to the fan-out's own expand_lane.  Nothing is read back: 1 action byte in, 20 + 1 + 240 + 12 bytes out.
+// ================================================================================================================
+__global__ __launch_bounds__(EXP_WAVES * WAVE)
+void k_rollout_fanout(const uint8_t *__restrict__ actions, int moves, int games, int with_solved, uint32_t *__restrict__ states,
+                      uint8_t *__restrict__ state_flags, u32x4 *__restrict__ children, uint32_t *__restrict__ solved, long long *__restrict__ stats)
+{
+	__shared__ u32x4 s_act[36];
+	__shared__ u32x4 s_rows[48];
+	__shared__ ExpandWaveLdsT<1> s_wave[EXP_WAVES];
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	stage_action_tables(s_act, tid);
+	if (tid < 48) {
+		const uint32_t *src = reinterpret_cast<const uint32_t *>(D_TAB.rows) + 4 * tid;
+		s_rows[tid] = u32x4{src[0], src[1], src[2], src[3]};
+	}
+	__syncthreads();
+	const int rows = moves + (with_solved ? 1 : 0);
+	const size_t n = (size_t)games * rows;
+	const size_t p0 = ((size_t)blockIdx.x * EXP_WAVES + wv) * EXP_ROUND;           // first state of this wave's tile
+	if (p0 >= n) return;                                                       // (after the only barrier)
+	const int np = n - p0 < (size_t)EXP_ROUND ? (int)(n - p0) : EXP_ROUND;
+	const size_t me = p0 + (lane < np ? lane : np - 1);                            // lanes past the end redo the last state; never stored
+	const int g = (int)(me / rows), r = (int)(me - (size_t)g * rows);
+	const int todo = with_solved ? r : r + 1;
+	uint32_t par[5] = {SOLVED_DW[0], SOLVED_DW[1], SOLVED_DW[2], SOLVED_DW[3], SOLVED_DW[4]};
+	uint32_t worst = 0;
+	for (int d = 0; d < todo; d++) {
+		uint32_t a = actions[(size_t)d * games + g];
+		worst = a > worst ? a : worst;
+		a = a < 12u ? a : 0u;
+		uint32_t tab[12];
+		load_action_table(s_act, a, tab);
+		move5(par, tab);
+	}
+	if (worst >= 12u) atomicOr(&g_bad_actions, 1u);                                // never taken on valid input
+	const ExpandCtx c{s_rows, s_wave[wv].stage, s_wave[wv].flags, lane};
+	// the tile's states, coalesced through the head of the staging area
+	uint32_t *stage_dw = reinterpret_cast<uint32_t *>(c.stage);
+	#pragma unroll
+	for (int j = 0; j < 5; j++) stage_dw[lane * 5 + j] = par[j];
+	wave_lds_fence();
+	#pragma unroll
+	for (int k = 0; k < 5; k++) {
+		const int idx = k * 64 + lane;
+		if (idx < np * STATE_DWORDS) states[p0 * STATE_DWORDS + idx] = stage_dw[idx];
+	}
+	if (state_flags != nullptr && lane < np) state_flags[p0 + lane] = is_solved5(par) ? 1 : 0;
+	wave_lds_fence();
+	// ... and their children, as the fan-out's ragged tile writes them
+	uint32_t out[60], fl[3];
+	expand_lane<true>(c, par, out, fl);
+	c.flags[lane * 3 + 0] = fl[0];
+	c.flags[lane * 3 + 1] = fl[1];
+	c.flags[lane * 3 + 2] = fl[2];
+	#pragma unroll
+	for (int v = 0; v < 15; v++)
+		c.stage[lane * 15 + v] = u32x4{out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]};
+	wave_lds_fence();
+	u32x4 *dst = children + p0 * 15;
+	const int nvec = np * 15;
+	#pragma unroll
+	for (int v = 0; v < 15; v++) {
+		const int idx = v * 64 + lane;
+		if (idx < nvec) store16<1>(dst, idx, c.stage[idx]);
+	}
+	uint32_t *fdst = solved + p0 * 3;
+	#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		const int idx = k * 64 + lane;
+		if (idx < np * 3) fdst[idx] = c.flags[idx];
+	}
+	report_solved<true>(fl, lane < np, (p0 + lane) * 12, stats);
+}
+
+// ================================================================================================================
 // as_oh: (n, 20) int8 -> (n, 480) one-hot, oh[r][24 i + s[r][i]] = 1                            cube.py:265-277
 // Algorithmic bytes per state: 20 read + 480 * sizeof(T) written (1 920 for f32): a pure store stream.  A workgroup
 // encodes TILE states per step; each thread emits 16-byte chunks (4 f32 or 8 half/bf16 columns of one cubie).
@@ -1628,6 +1711,15 @@ void launch_multi_is_solved(const int8_t *states, uint8_t *flags, long long *sta
 	PacedTurn turn(st, paced);
 	hipLaunchKernelGGL(k_multi_is_solved, dim3(grid), dim3(ROW_WAVES * WAVE), 0, st, (const uint32_t *)states, flags, stats, n, n_tiles,
 	                   paced ? tau_cfg : 0u, pc.lead, paced ? next_pace_cell() : (unsigned long long *)nullptr);
+}
+
+void launch_rollout_fanout(const uint8_t *actions, int moves, int games, int with_solved, int8_t *states, uint8_t *state_flags, int8_t *children,
+                           uint8_t *child_flags, long long *stats, hipStream_t st)
+{
+	const size_t n = (size_t)games * (moves + (with_solved ? 1 : 0));
+	const unsigned grid = grid_for((n + EXP_ROUND - 1) / EXP_ROUND, EXP_WAVES, 1u << 22);
+	hipLaunchKernelGGL(k_rollout_fanout, dim3(grid), dim3(EXP_WAVES * WAVE), 0, st, actions, moves, games, with_solved, (uint32_t *)states, state_flags,
+	                   (u32x4 *)children, (uint32_t *)child_flags, stats);
 }
 
 void launch_apply_sequences(const uint8_t *actions, int moves, int games, int with_solved, int only_last, int8_t *out, hipStream_t st)

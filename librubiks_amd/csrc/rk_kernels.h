@@ -32,6 +32,8 @@ void register_stream(hipStream_t st);
 void forget_stream(hipStream_t st);
 void launch_apply_sequences(const uint8_t *actions, int moves, int games, int with_solved, int only_last, int8_t *out,
                             hipStream_t st);
+void launch_rollout_fanout(const uint8_t *actions, int moves, int games, int with_solved, int8_t *states, uint8_t *state_flags_or_null,
+                           int8_t *children, uint8_t *child_flags, long long *stats_or_null, hipStream_t st);
 void launch_as_oh(const int8_t *states, void *out, int out_dtype, size_t n, hipStream_t st);
 
 void launch_rotate686(const int8_t *states, const uint8_t *actions, int8_t *out, size_t n_out, bool fanout, hipStream_t st,

@@ -395,6 +395,23 @@ class device:
 		return out
 
 	@staticmethod
+	def rollout_fanout(actions: torch.Tensor, with_solved: bool):
+		"""actions uint8 (depth, games) -> (states (games*depth, 20), states_solved uint8, children (12*games*depth, 20), children_solved uint8):
+		the walks of `apply_sequences`, the goal test of every state, their fan-out and its goal test in ONE launch (train.py:277-292)."""
+		_ffi.require_gpu()
+		_check_dev(actions, torch.uint8, "actions")
+		device._validate(actions)
+		depth, games = actions.shape
+		n = games * depth
+		states = torch.empty((n, 20), dtype=torch.int8, device=gpu)
+		state_flags = torch.empty(n, dtype=torch.uint8, device=gpu)
+		children = torch.empty((12 * n, 20), dtype=torch.int8, device=gpu)
+		child_flags = torch.empty(12 * n, dtype=torch.uint8, device=gpu)
+		_ffi.check(_ffi.lib().rk_rollout_fanout(REPR_2024, actions.data_ptr(), depth, games, int(with_solved), states.data_ptr(), state_flags.data_ptr(),
+		                                        children.data_ptr(), child_flags.data_ptr(), None, _ffi.stream_ptr()))
+		return states, state_flags, children, child_flags
+
+	@staticmethod
 	def as_oh(states: torch.Tensor, out: torch.Tensor = None, dtype: torch.dtype = torch.float32) -> torch.Tensor:
 		"""One-hot (n, 480 | 288) of `dtype` (float32, float16 or bfloat16)   (cube.py:265-277, 363-369)."""
 		_ffi.require_gpu()

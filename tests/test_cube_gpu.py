@@ -921,3 +921,33 @@ def test_a_stream_destroyed_between_two_paced_launches():
 	torch.cuda.synchronize()
 	assert np.array_equal(ch.cpu().numpy(), want)
 	assert lib.rk_stream_forget(None) == 0 and lib.rk_stream_register(None) == 0
+
+
+# ------------------------------------------------------------------------------------------------- ADI rollout in one launch
+@pytest.mark.parametrize("games,depth,with_solved", [(1, 1, False), (1, 1, True), (3, 7, True), (5, 13, False), (64, 1, False), (77, 30, True), (7500, 30, False)])
+def test_rollout_fanout_is_walk_plus_goal_test_plus_fanout(games, depth, with_solved):
+	"""rk_rollout_fanout (VERDICT r4 #4b): the states along every game's walk, their goal test, their 12 children and the children's
+	goal test in one launch -- against the oracle's sequence_scrambler / fan-out on the same draws (ref:cube/cube.py:218-232,
+	ref:train.py:277-292) and against the three launches it replaces.  Sizes around the 64-state tiles, up to the reference's
+	rollout (7 500 games x 30)."""
+	rng = np.random.RandomState(1000 * games + depth)
+	faces, dirs = rng.randint(0, 6, (depth, games)), rng.randint(0, 2, (depth, games))
+	acts = dev((2 * faces + (1 - dirs)).astype(np.uint8))
+	states, sfl, children, cfl = cube.device.rollout_fanout(acts, with_solved)
+	# the oracle's walk: game-major rows, the solved state in front when asked (and then only depth - 1 moves)
+	cur = orc.repeat_state(orc.SOLVED, games)
+	seq = [cur] if with_solved else []
+	for d in range(depth - int(with_solved)):
+		cur = orc.multi_rotate(cur, faces[d], dirs[d])
+		seq.append(cur)
+	want = np.stack(seq, axis=1).reshape(games * depth, 20)
+	assert np.array_equal(states.cpu().numpy(), want)
+	assert np.array_equal(sfl.cpu().numpy().astype(bool), orc.multi_is_solved(want))
+	want_ch, want_fl = c_oracle.expand12(want, threads=8)
+	assert np.array_equal(children.cpu().numpy(), want_ch) and np.array_equal(cfl.cpu().numpy(), want_fl)
+	if with_solved:
+		assert sfl[::depth].all() and int(cfl.sum()) >= 0
+	# ... and the three launches it replaces
+	s3 = cube.device.apply_sequences(acts, with_solved, False)
+	ch3, fl3 = cube.device.expand12(s3)
+	assert torch.equal(s3, states) and torch.equal(ch3, children) and torch.equal(fl3, cfl) and torch.equal(cube.device.multi_is_solved(s3), sfl)
