@@ -430,8 +430,8 @@ class _ExactModel(torch.nn.Module):
 	def __init__(self):
 		super().__init__()
 		g = torch.Generator().manual_seed(9)
-		ints = lambda *shape: torch.randint(-2, 3, shape, generator=g).float()
-		self.shared_net = torch.nn.Sequential(torch.nn.Linear(480, 16), torch.nn.ReLU(), torch.nn.Linear(16, 8), torch.nn.ReLU())
+		ints = lambda *shape: torch.randint(-1, 2, shape, generator=g).float()
+		self.shared_net = torch.nn.Sequential(torch.nn.Linear(480, 64), torch.nn.ReLU(), torch.nn.Linear(64, 8), torch.nn.ReLU())   # (the fused layer wants a multiple of 64 outputs)
 		self.policy_net = torch.nn.Sequential(torch.nn.Linear(8, 12))
 		self.value_net = torch.nn.Sequential(torch.nn.Linear(8, 1))
 		with torch.no_grad():
