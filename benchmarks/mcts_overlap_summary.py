@@ -1,6 +1,6 @@
 """
 Reads the rocprofv3 kernel trace of `benchmarks/mcts_overlap.py --trace-marks` and answers VERDICT r4 #3's question with the
-timestamps: per form (the forms are separated by the marker fill kernels of 3 elements), how long the backup + select kernels ran,
+timestamps: per form (a marker launch of rk::k_multi_is_solved precedes every form's timed part), how long the backup + select kernels ran,
 how much of that time lay UNDER another kernel (any kernel of another stream running at the same time), the busy time of the
 device per simulation step, and the average duration of the net's kernels at full and at half batch size.
 
@@ -22,12 +22,11 @@ def main():
 		sys.exit(f"no kernel_trace.csv under {d}")
 	with open(hits[-1], newline="") as f:
 		rows = sorted(csv.DictReader(f), key=lambda r: int(r["Start_Timestamp"]))
-	# split at the marker: an elementwise fill of 3 elements (grid of one workgroup) -- the only such launches are ours
+	# split at the marker: rk::k_multi_is_solved is launched only by mcts_overlap.py, once in front of every form's timed part
 	forms, cur = [], []
 	names = ["(before the first marker)", "one_stream", "two_halves", "two_halves_eager"]
 	for r in rows:
-		g = int(r.get("Grid_Size") or r.get("Grid_Size_X") or 0)
-		if "fill" in r["Kernel_Name"].lower() and g <= 256 and cur and "FillFunctor<float>" in r["Kernel_Name"]:
+		if "k_multi_is_solved" in r["Kernel_Name"]:
 			forms.append(cur)
 			cur = []
 			continue
@@ -40,8 +39,11 @@ def main():
 		iv = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in ks]
 		sel = [(s, e) for s, e, n in iv if "k_mcts_backup_select" in n]
 		other = sorted((s, e) for s, e, n in iv if "k_mcts_backup_select" not in n)
-		# the timed part only: the last 90 % of the select launches (the first ones are warm-up and capture)
-		sel = sel[len(sel) // 10:]
+		# up to the next form's set-up: stop at the first gap of more than 20 ms between select launches
+		for i in range(1, len(sel)):
+			if sel[i][0] - sel[i - 1][1] > 20_000_000:
+				sel = sel[:i]
+				break
 		if not sel:
 			continue
 		lo, hi = sel[0][0], sel[-1][1]

@@ -474,7 +474,7 @@ def test_two_halves_on_two_streams_change_no_tree(n_trees):
 	halves_agent, halves = run(True, True)
 	assert halves_agent.captures == 1 and halves_agent._graph_cache[0][0] == "halves"
 	grow_agent, grown = run(True, True, capacity=600, max_capacity=8000)
-	assert grow_agent.grown >= 1
+	assert grow_agent.capacity > 600                                         # the pools grew in place during the first search
 	for other in (single, halves, grown):
 		for (s0, st0, tr0, q0), (s1, st1, tr1, q1) in zip(eager, other):
 			assert (s0 == s1).all() and (st0[:, :5] == st1[:, :5]).all() and q0 == q1
