@@ -25,8 +25,10 @@ def main():
 	# split at the marker: rk::k_multi_is_solved is launched only by mcts_overlap.py, once in front of every form's timed part
 	forms, cur = [], []
 	names = ["(before the first marker)", "one_stream", "two_halves", "two_halves_eager"]
+	seen_mcts = False                                                    # (the scrambles' own goal tests come before any MCTS kernel)
 	for r in rows:
-		if "k_multi_is_solved" in r["Kernel_Name"]:
+		seen_mcts = seen_mcts or "k_mcts_" in r["Kernel_Name"]
+		if seen_mcts and "k_multi_is_solved" in r["Kernel_Name"]:
 			forms.append(cur)
 			cur = []
 			continue
