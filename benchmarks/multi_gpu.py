@@ -103,13 +103,15 @@ def sharded_astar_leg(dist, backend: str, world: int, rank: int, *, weak: bool, 
 		np.random.seed(g)
 		starts.append(cube.scramble(depth, True)[0])
 	secs = states = iters = solved = rows = launches = 0
-	stops = []
+	stops, game_secs, game_iters = [], [], []
 	for st in starts:
 		barrier()
 		t0 = time.perf_counter()
 		ok = agent.search(st, time_limit=time_limit, max_states=total_budget)
 		torch.cuda.synchronize()
-		secs += _max_over_ranks(time.perf_counter() - t0, dist, backend)
+		game_secs.append(_max_over_ranks(time.perf_counter() - t0, dist, backend))
+		game_iters.append(agent.iterations)
+		secs += game_secs[-1]
 		states += agent.total_states
 		iters += agent.iterations
 		solved += bool(ok)
@@ -120,6 +122,17 @@ def sharded_astar_leg(dist, backend: str, world: int, rank: int, *, weak: bool, 
 	# search stream; the events themselves cost a few microseconds per phase, so the timed pass above runs without them)
 	graph_state = "replayed" if (agent.use_hipgraph and agent.graph_error is None) else ("eager: " + (agent.graph_error or "not requested"))
 	repeated, rows_fixed = agent.repeated, agent.net_rows_max
+	# the other way of driving the same iteration, on game 0 (eager launches if the timed games replayed the graph): says on THIS box and
+	# world size whether the host's launch bill or the GPU bounds the iteration
+	eager_ms = None
+	if graph_state == "replayed":
+		agent.use_hipgraph = False
+		barrier()
+		t0 = time.perf_counter()
+		agent.search(starts[0], time_limit=time_limit, max_states=total_budget)
+		torch.cuda.synchronize()
+		eager_ms = _max_over_ranks(time.perf_counter() - t0, dist, backend) / max(agent.iterations, 1) * 1e3
+		agent.use_hipgraph = True
 	agent.profile = True
 	barrier()
 	agent.search(starts[0], time_limit=time_limit, max_states=total_budget)
@@ -135,6 +148,7 @@ def sharded_astar_leg(dist, backend: str, world: int, rank: int, *, weak: bool, 
 		pre + "expansions_per_iteration": N, pre + "budget": total_budget,
 		pre + "net_rows_per_rank": rows_fixed, pre + "net_rows_bound_12N": 12 * N, pre + "row_shortfall_repeats": repeated,
 		pre + "hipgraph": graph_state, pre + "graph_launches_per_iteration": launches / max(iters, 1) if graph_state == "replayed" else None,
+		pre + "ms_per_iteration_game0": game_secs[0] / max(game_iters[0], 1) * 1e3, pre + "ms_per_iteration_game0_eager": eager_ms,
 		pre + "allgather_us": ph.get("all_gather", 0.0) * 1e3, pre + "select_us": ph.get("select+expand", 0.0) * 1e3,
 		pre + "alltoall_us": ph.get("all_to_all", 0.0) * 1e3, pre + "insert_us": ph.get("insert", 0.0) * 1e3,
 		pre + "net_us": ph.get("net", 0.0) * 1e3, pre + "push_us": ph.get("push", 0.0) * 1e3,
