@@ -186,29 +186,20 @@ def search_legs():
 	torch.cuda.synchronize()
 	empty_us = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2] * 1e3
 	out["event_pair_overhead_us"] = empty_us
-	# ---- the cube part of one ADI rollout (ref:train.py:277-292) at the reference's size, 7 500 games x 30: one launch against the three
-	#      it replaces (walks, goal test, fan-out), HIP events around back-to-back repetitions
+	# ---- the cube part of one ADI rollout (ref:train.py:277-292) at the reference's size, 7 500 games x 30: walks, goal tests and fan-out
+	#      in ONE launch (rk_rollout_fanout; before / after against the three launches it replaced: benchmarks/adi_cube.py, profiles/r05_adi_cube.json)
 	acts = torch.randint(0, 12, (30, 7500), device="cuda", dtype=torch.uint8)
-
-	def timed(fn, reps=50):
-		fn()
-		a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-		torch.cuda.synchronize()
-		a.record()
-		for _ in range(reps):
-			fn()
-		b.record()
-		torch.cuda.synchronize()
-		return a.elapsed_time(b) / reps * 1e3
-
-	def three_launches():
-		st = cube.device.apply_sequences(acts, True, False)
-		return st, cube.device.multi_is_solved(st), cube.device.expand12(st)
-
-	out["adi_cube_us"] = timed(lambda: cube.device.rollout_fanout(acts, True))
-	out["adi_cube_us_three_launches"] = timed(three_launches)
-	out["adi_cube_config"] = ("7 500 games x 30 rows (225 000 states, 2.7 M children): rk_rollout_fanout against rk_apply_sequences + rk_multi_is_solved + "
-	                          "rk_expand12; includes torch's allocation of the outputs in both")
+	for _ in range(3):
+		cube.device.rollout_fanout(acts, True)
+	ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+	torch.cuda.synchronize()
+	ea.record()
+	for _ in range(50):
+		cube.device.rollout_fanout(acts, True)
+	eb.record()
+	torch.cuda.synchronize()
+	out["adi_cube_us"] = ea.elapsed_time(eb) / 50 * 1e3
+	out["adi_cube_config"] = "7 500 games x 30 rows (225 000 states, 2.7 M children, 61 MB written): rk_rollout_fanout through cube.device (torch allocates the outputs inside the clock)"
 	del acts
 	# ---- configs[2]: A* ------------------------------------------------------------------------------------------
 	lam, N, depth, budget, games = 0.16, 1000, 14, 150_000, 5

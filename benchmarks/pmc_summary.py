@@ -29,14 +29,28 @@ def _one(directory: str, suffix: str) -> str:
 	return hits[-1]
 
 
+def _grid(row) -> int:
+	return int(row.get("Grid_Size") or row.get("Grid_Size_X") or 0)
+
+
+def modal_grid(rows) -> int:
+	"""The launch shape the command's timed region uses: the most frequent grid size among the kernel's dispatches (the process may
+	launch the same kernel at other sizes beside it -- a leg on 225 k parents, say -- which must not enter the headline's average)."""
+	counts = {}
+	for r in rows:
+		counts[_grid(r)] = counts.get(_grid(r), 0) + 1
+	return max(counts, key=counts.get) if counts else 0
+
+
 def counter_rows(directory: str, counter: str, kernel: str):
-	vals, name = [], None
+	rows = []
 	with open(_one(directory, "counter_collection.csv"), newline="") as f:
 		for row in csv.DictReader(f):
 			if row["Counter_Name"] == counter and kernel in row["Kernel_Name"]:
-				vals.append(float(row["Counter_Value"]))
-				name = row["Kernel_Name"]
-	return vals, name
+				rows.append(row)
+	g = modal_grid(rows)
+	rows = [r for r in rows if _grid(r) == g]
+	return [float(r["Counter_Value"]) for r in rows], (rows[-1]["Kernel_Name"] if rows else None)
 
 
 def short_name(full: str) -> str:
@@ -77,14 +91,16 @@ def main():
 				r[0] = short_name(r[0]) if len(r[0]) < 400 else short_name(r[0])[:120] + "..."
 				w.writerow(r)
 		# median of the kernel's dispatch durations from the trace of the same run
-		dur = []
+		hits = []
 		with open(_one(args.stats, "kernel_trace.csv"), newline="") as f:
 			for row in csv.DictReader(f):
 				if args.kernel in row["Kernel_Name"]:
-					dur.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+					hits.append(row)
+		g = modal_grid(hits)
+		dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in hits if _grid(r) == g]
 		if dur:
-			print(json.dumps({"kernel": args.kernel, "dispatches": len(dur), "avg_ns": statistics.fmean(dur), "median_ns": statistics.median(dur),
-			                  "min_ns": min(dur), "max_ns": max(dur)}))
+			print(json.dumps({"kernel": args.kernel, "grid_work_items": g, "dispatches": len(dur), "dispatches_of_other_shapes": len(hits) - len(dur),
+			                  "avg_ns": statistics.fmean(dur), "median_ns": statistics.median(dur), "min_ns": min(dur), "max_ns": max(dur)}))
 
 	if args.fetch and args.write and args.out_pmc:
 		fv, name_f = counter_rows(args.fetch, "FETCH_SIZE", args.kernel)

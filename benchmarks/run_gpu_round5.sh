@@ -24,6 +24,9 @@ bench)
 		--command "python3 bench.py --steps 64 --warmup 8 --no-cpu-baseline --no-search-legs" --out-pmc $O/expand12_pmc.json --out-stats $O/expand12_kernel_stats.csv > $O/pmc_summary.log 2>&1; cut -c1-400 $O/pmc_summary.log
 	python benchmarks/search_legs_summary.py --stats $O/prof_stats --bench-log $O/bench_prof.log --out $O/search_legs.json --out-stats $O/search_legs_kernel_stats.csv > $O/search_legs.log 2>&1; cut -c1-600 $O/search_legs.log
 	find $O -name "*kernel_trace.csv" -size +40M -delete
+	step 200 python benchmarks/adi_cube.py > $O/adi_cube.json 2> $O/adi_cube.err; cat $O/adi_cube.json
+	step 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_adi -- python3 benchmarks/adi_cube.py > $O/adi_cube_prof.log 2>&1
+	python benchmarks/kernel_trace_by_grid.py $O/prof_adi --min-calls 50 > $O/adi_cube_kernels.csv; cat $O/adi_cube_kernels.csv
 	;;
 sharded)
 	# configs[4] on the one-GPU box: world 1 eager against the captured iteration (the phase split rides in the same object), then the

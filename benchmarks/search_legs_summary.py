@@ -50,10 +50,29 @@ def main():
 	sel = [r for r in rows if "k_mcts_backup_select" in r["Name"]]
 	sel_calls = sum(int(r["Calls"]) for r in sel)
 	sel_us = sum(float(r["TotalDurationNs"]) for r in sel) / max(sel_calls, 1) / 1e3
+	# round 5: the process also runs the step that advances the batch as two halves (launches over half the trees); the figure that
+	# belongs beside the bench line's `mcts_select_us` (an event pair around the launch over ALL trees) is the average of the
+	# full-batch launches only -- taken from the kernel trace by grid size (the largest grid the kernel was launched with)
+	half_calls = half_us = None
+	traces = sorted(glob.glob(os.path.join(a.stats, "**", "*kernel_trace.csv"), recursive=True))
+	if traces:
+		by_grid = {}
+		with open(traces[-1], newline="") as f:
+			for r in csv.DictReader(f):
+				if "k_mcts_backup_select" in r["Kernel_Name"]:
+					g = int(r.get("Grid_Size") or r.get("Grid_Size_X") or 0)
+					by_grid.setdefault(g, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+		if by_grid:
+			full = max(by_grid)
+			sel_calls, sel_us = len(by_grid[full]), sum(by_grid[full]) / len(by_grid[full]) / 1e3
+			rest = [d for g, v in by_grid.items() if g != full for d in v]
+			if rest:
+				half_calls, half_us = len(rest), sum(rest) / len(rest) / 1e3
 	rec = {
 		"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 300 --warmup 30 --no-cpu-baseline",
 		"astar_iterations_in_process": iters, "astar_engine_us_per_iteration_rocprof": engine_us, "astar_kernels": astar,
 		"mcts_backup_select_launches": sel_calls, "mcts_select_us_rocprof": sel_us,
+		"mcts_backup_select_half_batch_launches": half_calls, "mcts_select_us_rocprof_half_batch": half_us,
 		"bench_line": {k: line.get(k) for k in ("event_pair_overhead_us", "astar_engine_us_per_iteration", "astar_engine_us_per_iteration_less_event_overhead",
 		                                         "astar_net_share", "astar_ms_per_iteration", "astar_states_per_s", "mcts_select_us",
 		                                         "mcts_select_us_less_event_overhead", "mcts_ms_per_step", "mcts_tree_sims_per_s")} if line else None,
