@@ -285,7 +285,7 @@ def search_legs():
 	return out
 
 
-PMC_FILE = os.path.join("profiles", "r04_expand12_pmc.json")
+PMC_FILE = os.path.join("profiles", "r05_expand12_pmc.json")
 
 
 def pmc_traffic(kernel):
