@@ -11,7 +11,7 @@ if [ -f $O/bench/bench.log ]; then
 	cp $O/bench/expand12_pmc.json $P/r05_expand12_pmc.json; cp $O/bench/expand12_kernel_stats.csv $P/r05_expand12_kernel_stats.csv
 	grep '^{"kernel": "k_expand12p"' $O/bench/pmc_summary.log > $P/r05_expand12_trace_summary.json
 	cp $O/bench/search_legs.json $P/r05_search_legs.json; cp $O/bench/search_legs_kernel_stats.csv $P/r05_search_legs_kernel_stats.csv
-	[ -s $O/bench/adi_cube.json ] && { cp $O/bench/adi_cube.json $P/r05_adi_cube.json; cp $O/bench/adi_cube_kernels.csv $P/r05_adi_cube_kernels.csv; }
+	[ -s $O/bench/adi_cube.json ] && cp $O/bench/adi_cube.json $P/r05_adi_cube.json     # (r05_adi_cube_kernels.csv holds BOTH versions of the walk: assembled by hand from two runs, not overwritten here)
 fi
 if [ -f $O/sharded/w1_graph.json ]; then
 	{ for f in w1_eager w1_graph w1_eager_stub w1_graph_stub; do echo "{\"run\": \"$f\", \"record\": $(last $O/sharded/$f.json)}"; done; } > $P/r05_sharded_rehearsal.json
