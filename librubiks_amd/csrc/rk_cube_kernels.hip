@@ -885,10 +885,10 @@ void k_apply_sequences(const uint8_t *__restrict__ actions, int moves, int games
 //   +  their 12 children, parent-major (train.py:285)  +  is each child solved (train.py:292).
 // Round 4 ran this as three launches (k_apply_sequences, k_multi_is_solved, k_expand12r) on 225 k states -- 13 MB of states and
 // 61 MB of children, every launch in the band where the 3-5 us a launch costs before its first byte is a quarter of it, and the
-// states written by the first were read back by the other two.  Here a lane owns ONE state (game g, row r): it walks the game's
-// first moves itself (r + 1 of them, r with the solved state in front; 15 on average, twelve v_perm each -- nothing next to
-// the 272 bytes the state costs in stores; the walks of a tile read a handful of action bytes that sit in two or three cache
-// lines) and hands it to the fan-out's own expand_lane.  Nothing is read back: 1 action byte in, 20 + 1 + 240 + 12 bytes out.
+// states written by the first were read back by the other two.  Here a lane owns ONE state (game g, row r): the lanes of a game
+// compute their states TOGETHER (a prefix scan over the moves' permutation tables, see below; games of more than 64 rows: every
+// lane walks for itself) and hand them to the fan-out's own expand_lane.  Nothing is read back: 1 action byte in,
+// 20 + 1 + 240 + 12 bytes out.
 // ================================================================================================================
 __global__ __launch_bounds__(EXP_WAVES * WAVE)
 void k_rollout_fanout(const uint8_t *__restrict__ actions, int moves, int games, int with_solved, uint32_t *__restrict__ states,
@@ -906,27 +906,64 @@ void k_rollout_fanout(const uint8_t *__restrict__ actions, int moves, int games,
 	__syncthreads();
 	const int rows = moves + (with_solved ? 1 : 0);
 	const size_t n = (size_t)games * rows;
-	const size_t p0 = ((size_t)blockIdx.x * EXP_WAVES + wv) * EXP_ROUND;           // first state of this wave's tile
+	// rows <= 64: a wave's tile is a whole number of games (2 games x 30 rows = 60 lanes for the reference's rollout) and the walks
+	// are a parallel prefix over the lanes of a game (below); longer games: 64 consecutive states, every lane walks for itself
+	const bool scan = rows <= EXP_ROUND;
+	const int tile_states = scan ? (EXP_ROUND / rows) * rows : EXP_ROUND;
+	const size_t p0 = ((size_t)blockIdx.x * EXP_WAVES + wv) * tile_states;         // first state of this wave's tile
 	if (p0 >= n) return;                                                       // (after the only barrier)
-	const int np = n - p0 < (size_t)EXP_ROUND ? (int)(n - p0) : EXP_ROUND;
+	const int np = n - p0 < (size_t)tile_states ? (int)(n - p0) : tile_states;
 	const size_t me = p0 + (lane < np ? lane : np - 1);                            // lanes past the end redo the last state; never stored
 	const int g = (int)(me / rows), r = (int)(me - (size_t)g * rows);
-	const int todo = with_solved ? r : r + 1;
 	uint32_t par[5] = {SOLVED_DW[0], SOLVED_DW[1], SOLVED_DW[2], SOLVED_DW[3], SOLVED_DW[4]};
 	uint32_t worst = 0;
-	constexpr int CH = 16;
-	for (int d0 = 0; d0 < todo; d0 += CH) {
-		uint32_t acts[CH];
-		fetch_actions<CH>(actions, (size_t)games, (size_t)g, d0, todo, acts);
-		#pragma unroll
-		for (int k = 0; k < CH; k++) {
-			if (d0 + k < todo) {
-				uint32_t a = acts[k];
-				worst = a > worst ? a : worst;
-				a = a < 12u ? a : 0u;
-				uint32_t tab[12];
-				load_action_table(s_act, a, tab);
-				move5(par, tab);
+	if (scan) {
+		// A move is a permutation of the 24 corner codes and of the 24 edge codes: a 48-byte table, twelve dwords.  Moves COMPOSE --
+		// (B after A)[v] = B[A[v]], four codes per lut4 -- so the state of row r is the composition of the game's first moves applied
+		// to the solved state, and the compositions of all rows of a game are an inclusive prefix scan over its lanes: log2(rows)
+		// steps of twelve cross-lane dwords and twelve lut4 each, in registers, instead of up to `rows` dependent moves per wave
+		// (thirty LDS round trips + v_perm chains: the walk was most of this kernel's 28 us; rocprofv3, profiles/r05_adi_cube_kernels.csv).
+		uint32_t X[12];
+		const int mv = with_solved ? r - 1 : r;                                // the move that leads to row r (none for the solved row)
+		if (mv >= 0) {
+			uint32_t a = actions[(size_t)mv * games + g];
+			worst = a;
+			a = a < 12u ? a : 0u;
+			load_action_table(s_act, a, X);
+		} else {
+			#pragma unroll
+			for (int j = 0; j < 6; j++) X[j] = X[6 + j] = 0x03020100u + 0x04040404u * (uint32_t)j;   // the identity table
+		}
+		for (int off = 1; off < rows; off <<= 1) {
+			uint32_t Y[12];
+			const int src = (lane - off) & 63;
+			#pragma unroll
+			for (int j = 0; j < 12; j++) Y[j] = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)X[j]);
+			if (r >= off) {                                                  // the lane `off` rows back is a row of the SAME game
+				uint32_t Z[12];
+				#pragma unroll
+				for (int j = 0; j < 6; j++) { Z[j] = lut4(Y[j], X); Z[6 + j] = lut4(Y[6 + j], X + 6); }   // the earlier moves first, then mine
+				#pragma unroll
+				for (int j = 0; j < 12; j++) X[j] = Z[j];
+			}
+		}
+		move5(par, X);
+	} else {
+		const int todo = with_solved ? r : r + 1;
+		constexpr int CH = 16;
+		for (int d0 = 0; d0 < todo; d0 += CH) {
+			uint32_t acts[CH];
+			fetch_actions<CH>(actions, (size_t)games, (size_t)g, d0, todo, acts);
+			#pragma unroll
+			for (int k = 0; k < CH; k++) {
+				if (d0 + k < todo) {
+					uint32_t a = acts[k];
+					worst = a > worst ? a : worst;
+					a = a < 12u ? a : 0u;
+					uint32_t tab[12];
+					load_action_table(s_act, a, tab);
+					move5(par, tab);
+				}
 			}
 		}
 	}
@@ -1745,8 +1782,9 @@ void launch_multi_is_solved(const int8_t *states, uint8_t *flags, long long *sta
 void launch_rollout_fanout(const uint8_t *actions, int moves, int games, int with_solved, int8_t *states, uint8_t *state_flags, int8_t *children,
                            uint8_t *child_flags, long long *stats, hipStream_t st)
 {
-	const size_t n = (size_t)games * (moves + (with_solved ? 1 : 0));
-	const unsigned grid = grid_for((n + EXP_ROUND - 1) / EXP_ROUND, EXP_WAVES, 1u << 22);
+	const size_t rows = (size_t)(moves + (with_solved ? 1 : 0)), n = (size_t)games * rows;
+	const size_t tile_states = rows <= (size_t)EXP_ROUND ? (EXP_ROUND / rows) * rows : (size_t)EXP_ROUND;      // whole games per wave (the kernel's own rule)
+	const unsigned grid = grid_for((n + tile_states - 1) / tile_states, EXP_WAVES, 1u << 22);
 	hipLaunchKernelGGL(k_rollout_fanout, dim3(grid), dim3(EXP_WAVES * WAVE), 0, st, actions, moves, games, with_solved, (uint32_t *)states, state_flags,
 	                   (u32x4 *)children, (uint32_t *)child_flags, stats);
 }

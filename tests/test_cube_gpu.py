@@ -924,12 +924,14 @@ def test_a_stream_destroyed_between_two_paced_launches():
 
 
 # ------------------------------------------------------------------------------------------------- ADI rollout in one launch
-@pytest.mark.parametrize("games,depth,with_solved", [(1, 1, False), (1, 1, True), (3, 7, True), (5, 13, False), (64, 1, False), (77, 30, True), (7500, 30, False)])
+@pytest.mark.parametrize("games,depth,with_solved", [(1, 1, False), (1, 1, True), (3, 7, True), (5, 13, False), (64, 1, False), (77, 30, True), (7500, 30, False),
+                                                      (9, 64, True), (11, 33, False), (70, 2, True), (3, 70, True), (2, 100, False), (1000, 3, False)])
 def test_rollout_fanout_is_walk_plus_goal_test_plus_fanout(games, depth, with_solved):
 	"""rk_rollout_fanout (VERDICT r4 #4b): the states along every game's walk, their goal test, their 12 children and the children's
 	goal test in one launch -- against the oracle's sequence_scrambler / fan-out on the same draws (ref:cube/cube.py:218-232,
 	ref:train.py:277-292) and against the three launches it replaces.  Sizes around the 64-state tiles, up to the reference's
-	rollout (7 500 games x 30)."""
+	rollout (7 500 games x 30); games of up to 64 rows go through the prefix scan over the moves' permutations (whole games per wave:
+	1, 2, 3, 7, 13, 30, 33, 64 rows), longer ones through the per-lane walk (70, 100 rows)."""
 	rng = np.random.RandomState(1000 * games + depth)
 	faces, dirs = rng.randint(0, 6, (depth, games)), rng.randint(0, 2, (depth, games))
 	acts = dev((2 * faces + (1 - dirs)).astype(np.uint8))
