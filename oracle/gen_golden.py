@@ -186,6 +186,9 @@ def kats(skip_1m: bool):
 	d["as633_out"] = np.array([cube.as633(s) for s in d["as633_states"]])
 	text["iter_actions_2"] = cube.iter_actions(2).tolist()
 	text["rev_actions"] = cube.rev_actions(np.arange(12)).tolist()
+	# the public names of the module a drop-in has to carry (cube/cube.py:22 re-exports the maps helpers; modules are not names of the API)
+	import types
+	text["public_names_cube"] = sorted(n for n, v in vars(cube).items() if not n.startswith("_") and not isinstance(v, types.ModuleType))
 
 	# 6x8x6 representation
 	cube.set_is2024(False)
