@@ -455,20 +455,9 @@ def main():
 	paced = PACED and tau_c.value > 0
 	kernel = KERNEL_PACED if paced else KERNEL_RING
 
-	# N > 1: the collectives' proof and the search legs are COLLECTIVE -- every rank runs them, rank 0 reports
-	multi = {}
 	if world > 1:
-		from benchmarks import multi_gpu
 		del ins, outs
 		torch.cuda.empty_cache()
-		try:
-			multi.update(multi_gpu.collective_proof(dist, backend))
-		except Exception as e:
-			multi["collective_proof_error"] = f"{type(e).__name__}: {e}"[:400]
-		if not args.no_search_legs:
-			multi.update(multi_gpu.legs(dist, backend, world, rank, games=args.search_games, sims=args.mcts_sims or 4096, mcts=args.mcts_sims > 0,
-			                            budget=args.search_budget or multi_gpu.STRONG_BUDGET, expansions=args.search_expansions or multi_gpu.STRONG_N,
-			                            depth=args.search_depth or multi_gpu.DEPTH))
 
 	if rank == 0:
 		value = world * N_PARENTS * args.steps / elapsed_max
@@ -511,7 +500,6 @@ def main():
 			# flat copies: the driver's parser keeps flat extra keys
 			line["frac_ring_same_box"] = line["roofline"]["frac_ring_same_box"]
 			line["paced_over_ring_same_box"] = kernel_ms_ring / kernel_ms
-		line.update(multi)
 		if world == 1 and not args.no_search_legs:
 			del ins, outs                                     # 1.6 GB back to the allocator before the pools of the search legs
 			torch.cuda.empty_cache()
@@ -524,6 +512,44 @@ def main():
 				line["cpu_baseline"] = cpu_baseline()
 			except Exception as e:
 				line["cpu_baseline"] = {"value": None, "unit": "expansions/s", "cores": 0, "kind": "port", "sample": "failed", "error": f"{type(e).__name__}: {e}"[:400]}
+	else:
+		line = None
+
+	# N > 1: the collectives' proof and the search legs are COLLECTIVE -- every rank runs them, rank 0 reports.  They run behind the
+	# headline's line, under a watchdog: should a leg hang (a collective that never completes on hardware the build never saw), every
+	# rank leaves after RK_BENCH_LEGS_TIMEOUT seconds and rank 0 still prints the line with what was finished -- the fan-out number of
+	# the scaling run is never lost to a leg.
+	if world > 1:
+		import threading
+		from benchmarks import multi_gpu
+		multi, finished = {}, threading.Event()
+		limit = float(os.environ.get("RK_BENCH_LEGS_TIMEOUT", "240"))
+
+		def bail():
+			if finished.is_set():
+				return
+			if rank == 0:
+				line.update(multi)
+				line["multi_gpu_legs_error"] = f"the multi-GPU legs did not finish within {limit:.0f} s (RK_BENCH_LEGS_TIMEOUT); keys above are the legs that did"
+				print(json.dumps(line), flush=True)
+			os._exit(0)
+
+		watchdog = threading.Timer(limit, bail)
+		watchdog.daemon = True
+		watchdog.start()
+		try:
+			multi.update(multi_gpu.collective_proof(dist, backend))
+		except Exception as e:
+			multi["collective_proof_error"] = f"{type(e).__name__}: {e}"[:400]
+		if not args.no_search_legs:
+			multi_gpu.legs(dist, backend, world, rank, games=args.search_games, sims=args.mcts_sims or 4096, mcts=args.mcts_sims > 0,
+			               budget=args.search_budget or multi_gpu.STRONG_BUDGET, expansions=args.search_expansions or multi_gpu.STRONG_N,
+			               depth=args.search_depth or multi_gpu.DEPTH, out=multi)
+		finished.set()
+		watchdog.cancel()
+		if rank == 0:
+			line.update(multi)
+	if rank == 0:
 		print(json.dumps(line), flush=True)
 	if dist is not None:
 		dist.barrier()

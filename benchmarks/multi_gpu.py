@@ -192,11 +192,11 @@ def partitioned_mcts_leg(dist, backend: str, world: int, rank: int, *, trees_per
 
 
 def legs(dist, backend: str, world: int, rank: int, *, games: int = 3, sims: int = 4096, trees_per_rank: int = 256, budget: int = STRONG_BUDGET,
-         expansions: int = STRONG_N, depth: int = DEPTH, mcts: bool = True) -> dict:
+         expansions: int = STRONG_N, depth: int = DEPTH, mcts: bool = True, out: dict = None) -> dict:
 	"""Everything `bench.py --gpus N` adds for N > 1.  A leg that fails says so in `<leg>_error` and the others still run -- but a rank
 	that raises inside a collective leaves its peers waiting, so errors are caught per leg on EVERY rank alike (the legs are
-	deterministic: what fails on one rank fails on all)."""
-	out = {}
+	deterministic: what fails on one rank fails on all).  `out` is filled leg by leg, so a caller with a watchdog can report what was finished."""
+	out = {} if out is None else out
 	for name, fn in (("sharded", lambda: sharded_astar_leg(dist, backend, world, rank, weak=False, games=games, budget=budget, expansions=expansions, depth=depth)),
 	                 ("sharded_weak", lambda: sharded_astar_leg(dist, backend, world, rank, weak=True, games=games, budget=budget, expansions=expansions, depth=depth)),
 	                 ("pmcts", (lambda: partitioned_mcts_leg(dist, backend, world, rank, trees_per_rank=trees_per_rank, sims=sims)) if mcts else None)):

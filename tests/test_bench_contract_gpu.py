@@ -87,3 +87,18 @@ def test_bench_two_ranks_without_a_launcher():
 			states += o.total_states
 			iters += o.iterations
 		assert (r[pre + "total_states"], r[pre + "iterations"]) == (states, iters), pre
+
+
+def test_a_hanging_leg_does_not_lose_the_headline():
+	"""The multi-GPU legs run under a watchdog: when they do not finish in time (here: a limit of half a second) every rank leaves and
+	rank 0 still prints the ONE line -- the fan-out value, the contract fields -- with `multi_gpu_legs_error` saying what happened."""
+	env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+	env.update(RK_BENCH_BACKEND="gloo", RK_BENCH_SEARCH_NET="stub", RK_BENCH_LEGS_TIMEOUT="0.5")
+	out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1"],
+	                     capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+	assert out.returncode == 0, out.stderr[-3000:]
+	lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+	assert len(lines) == 1
+	r = json.loads(lines[0])
+	assert r["n_gpus"] == 2 and r["value"] > 0 and r["verified_children"] == 48_000_000 and "roofline" in r
+	assert "did not finish within" in r["multi_gpu_legs_error"] and "sharded_weak_states_per_s" not in r
