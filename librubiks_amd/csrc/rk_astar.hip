@@ -544,7 +544,7 @@ __device__ __forceinline__ void records_sort_body(const AstarDev &d, const float
 	__shared__ Rec s[CHUNK];
 	constexpr int T = CHUNK / 2;
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-	const int n_new = d.ctr[C_NNEW];
+	const int n_new = min(d.ctr[C_NNEW], d.Kpad);                       // (never more than the launches were sized for: see shard_push_impl)
 	const uint32_t n_before = (uint32_t)d.ctr[C_NBEFORE];
 	const int base = blockIdx.x * CHUNK;
 	if (base >= n_new) return;                                          // uniform for the workgroup
@@ -612,7 +612,7 @@ void kb_records_sort(const AstarDev *__restrict__ devs, const float *values, con
 __device__ __forceinline__ void merge_pass_body(const AstarDev &d, int L, int from)
 {
 	const int e = blockIdx.x * blockDim.x + threadIdx.x;
-	const int n_new = d.ctr[C_NNEW];
+	const int n_new = min(d.ctr[C_NNEW], d.Kpad);
 	if (e >= d.Kpad || n_new <= SORT_CHUNK) return;                     // a single chunk is already sorted (only launched when K > 2048)
 	const int used = ((n_new + SORT_CHUNK - 1) / SORT_CHUNK) * SORT_CHUNK;
 	const Rec *src = from ? d.rec1 : d.rec0;
@@ -658,14 +658,14 @@ __device__ __forceinline__ void queue_insert_body(const AstarDev &d, int new_in_
 	if (threadIdx.x < 4 * QL) s_qmeta[threadIdx.x] = d.q.meta[threadIdx.x];     // one parallel load instead of a dependent chain
 	__syncthreads();
 	if (threadIdx.x == 0) {
-		const int n_new = d.ctr[C_NNEW];
+		const int n_new = min(d.ctr[C_NNEW], d.Kpad);
 		// after merge passes (one run out of more than eight chunks) the result ping-pongs; otherwise the sorted run(s) are in rec0
 		make_plan(d.q, s_qmeta, (nc == 0 && n_new > SORT_CHUNK && new_in_rec1) ? d.rec1 : d.rec0, n_new, nc, s_plan);
 	}
 	__syncthreads();
 	if (small && s_plan.total > 0) {
 		// K <= 2048: the sorted runs of new records (16-32 KB) are staged in LDS, so the merge searches them on the CU
-		const int n_new = d.ctr[C_NNEW];
+		const int n_new = min(d.ctr[C_NNEW], d.Kpad);
 		for (int i = threadIdx.x; i < n_new; i += blockDim.x) s_newrecs[i] = d.rec0[i];
 		__syncthreads();
 		if ((int)threadIdx.x < s_plan.n_new_runs) s_plan.run[threadIdx.x] = s_newrecs + threadIdx.x * SMALL_CHUNK;
@@ -779,13 +779,14 @@ __device__ __forceinline__ void end_body(const AstarDev &d, int new_in_rec1, int
 		}
 	}
 	if (tid == 0) {
-		const int n_new = s_ctr[C_NNEW];
+		const int n_new_all = s_ctr[C_NNEW];
+		const int n_new = min(n_new_all, d.Kpad);                          // what the sort / insert launches of this iteration covered
 		if (SHARDED) {
 			// The driver evaluates the net on a FIXED number of rows (its expected share of the 12 N children plus a margin,
 			// librubiks_amd/solving/sharded.py net_rows) instead of waiting for this count on the host.  More new states than rows:
 			// the values of the rows beyond were never computed -- an error every rank stops on together at the next decision
 			// (the driver then repeats the search with the full-width batch).
-			if (rows_evaluated > 0 && n_new > rows_evaluated && s_ctr[C_ERROR] == ERR_NONE) s_ctr[C_ERROR] = ERR_NET_ROWS;
+			if (rows_evaluated > 0 && n_new_all > rows_evaluated && s_ctr[C_ERROR] == ERR_NONE) s_ctr[C_ERROR] = ERR_NET_ROWS;
 			// Rank 0's clock decides "out of time" for everybody; it is the DEVICE's constant 100 MHz clock, started by the first
 			// k_end after the reset -- the host writes nothing per iteration, so the iteration can be replayed as a hipGraph.
 			unsigned long long t0 = (unsigned long long)(uint32_t)s_ctr[C_CLOCK0] | ((unsigned long long)(uint32_t)s_ctr[C_CLOCK0 + 1] << 32);
@@ -1233,9 +1234,9 @@ void launch_append(rk_astar *h, const uint8_t *recv, void *d_onehot, int out_dty
 
 // records + sort + merge passes + queue insert + end of iteration; returns through the launches only
 template <bool SHARDED>
-int launch_commit(rk_astar *h, const float *d_values, const uint8_t *recv, hipStream_t st)
+int launch_commit(rk_astar *h, const float *d_values, const uint8_t *recv, hipStream_t st, const AstarDev *geometry = nullptr)
 {
-	const AstarDev &d = h->d;
+	const AstarDev &d = geometry ? *geometry : h->d;                    // (sharded: the sort geometry of this iteration, see shard_push_impl)
 	int from = 0;
 	if (d.chunk == SMALL_CHUNK) {
 		hipLaunchKernelGGL((k_records_sort<SMALL_CHUNK>), dim3(d.Kpad / SMALL_CHUNK), dim3(SMALL_CHUNK / 2), 0, st, d, d_values);
@@ -1279,8 +1280,11 @@ static int astar_create_impl(rk_astar_t **out, size_t capacity, int max_expansio
 	d.N = max_expansions; d.K = 12 * max_expansions;
 	d.KI = d.K * world;                                   // a rank can receive every rank's children
 	const int kin = world == 1 ? d.K : d.KI;
-	d.chunk = kin <= SORT_CHUNK ? SMALL_CHUNK : SORT_CHUNK;
-	d.Kpad = ((kin + d.chunk - 1) / d.chunk) * d.chunk;
+	// The NEW records of an iteration are at most K = 12 N on any rank, whatever the world size (all ranks together pop N nodes), so
+	// the sort / merge / insert geometry follows K.  (Rounds 2-4 sized it by the incoming SLOTS, world * K: at world 8 every
+	// iteration launched six merge passes over 33 mostly empty chunks where there are at most five chunks of records.)
+	d.chunk = d.K <= SORT_CHUNK ? SMALL_CHUNK : SORT_CHUNK;
+	d.Kpad = ((d.K + d.chunk - 1) / d.chunk) * d.chunk;
 	d.cap1 = (uint32_t)(capacity + 1);
 	uint64_t t = 1024;
 	while (t < 2 * (uint64_t)capacity + 2) t <<= 1;
@@ -1794,8 +1798,18 @@ static int shard_push_impl(rk_astar_t *h, const float *d_values, int rows, const
 	if (!d_values || !d_recv || !d_send) return fail(RK_EINVAL, "rk_astar_shard_push: null argument");
 	if (rows < 0 || rows > h->d.K) return fail(RK_EINVAL, "rk_astar_shard_push_rows: %d rows outside 0..12 N = %d", rows, h->d.K);
 	hipStream_t st = (hipStream_t)stream;
-	const AstarDev &d = h->d;
-	const int from = launch_commit<true>(h, d_values, (const uint8_t *)d_recv, st);
+	// The caller promises values for the first `rows` new states and the engine stops the search if there are more (error 3), so this
+	// iteration's sort / merge / insert need not be sized for K = 12 N records: `rows` of them at most.  At world 8, N = 700 that is one
+	// pass over 1 344 records in 256-record chunks staged in LDS (the K <= 2048 form) instead of five 2 048-record chunks; at
+	// N = 5 600 (weak) five chunks handed to the insert as they are instead of 33 chunks and five merge passes.  Every kernel of the
+	// sequence receives the same geometry by value; should the promise break, they cover `Kpad` records and no more (clamped), and
+	// k_end<true> reports it.
+	AstarDev d = h->d;
+	if (rows > 0 && rows < d.K) {
+		if (rows <= SORT_CHUNK) d.chunk = SMALL_CHUNK;
+		d.Kpad = std::min(d.Kpad, ((rows + d.chunk - 1) / d.chunk) * d.chunk);
+	}
+	const int from = launch_commit<true>(h, d_values, (const uint8_t *)d_recv, st, &d);
 	hipLaunchKernelGGL(k_shard_offers, dim3(blocks((size_t)d.KI, ASCAN)), dim3(ASCAN), 0, st, d, (const uint8_t *)d_recv, (uint8_t *)d_send);
 	hipLaunchKernelGGL((k_end<true>), dim3(1), dim3(1024), 0, st, d, from, 1, rows == d.K ? 0 : rows);
 	RK_HIP(hipGetLastError());
