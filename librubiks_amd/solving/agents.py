@@ -81,6 +81,12 @@ def _net_signature(net):
 	return tuple(sig)
 
 
+#: How every search step is captured: errors of the capture are judged per THREAD.  In a process with a torch.distributed process group
+#: the NCCL (RCCL) watchdog thread polls events while the main thread captures; under the default "global" mode such a call from another
+#: thread invalidates the capture -- a sporadic failure of the first search of a rank (seen once in the round-5 test runs).
+CAPTURE = {"capture_error_mode": "thread_local"}
+
+
 def _capture_key(net, fs) -> tuple:
 	"""What a captured search step holds of the net: the module, its mode, and the storage of every parameter and buffer (their
 	VALUES are read at replay time, so in-place training between searches keeps a captured step valid; the fused copy `fs` is
@@ -547,7 +553,7 @@ class AStar(DeepAgent):
 						self._iteration(h, oh, code)               # a real iteration; also warms the allocator
 					torch.cuda.current_stream().wait_stream(side)
 					graph = torch.cuda.CUDAGraph()                 # (captured again after a growth: it holds the pool's addresses)
-					with torch.cuda.graph(graph):
+					with torch.cuda.graph(graph, **CAPTURE):
 						self._iteration(h, oh, code)
 					self._graph_cache = (key, graph, (oh, code), (self.net, self._fs))     # the net stays alive with the graph that holds its addresses
 					self.captures += 1
@@ -929,7 +935,7 @@ class MCTSBatch(DeepAgent):
 				self.simulations += 1
 		torch.cuda.current_stream().wait_stream(side)
 		self._graph = torch.cuda.CUDAGraph()
-		with torch.cuda.graph(self._graph):
+		with torch.cuda.graph(self._graph, **CAPTURE):
 			self._step(oh, h, expand=False)
 		self._graph_cache = (key, self._graph, oh, (self.net, self._fs))      # the net stays alive with the graph that holds its addresses
 		self.captures += 1
@@ -986,7 +992,7 @@ class MCTSBatch(DeepAgent):
 		del pa, va
 		XA, VA = self._half_bufs
 		self._graph = torch.cuda.CUDAGraph()
-		with torch.cuda.graph(self._graph):
+		with torch.cuda.graph(self._graph, **CAPTURE):
 			cur = torch.cuda.current_stream()
 			side.wait_stream(cur)                                      # fork
 			self._backup_half(0, na, XA, VA)                           # phase 1, this stream: backup + select A
@@ -1331,7 +1337,7 @@ class AStarBatch(DeepAgent):
 			torch.cuda.current_stream().wait_stream(side)
 			self.iterations += 1
 			graph = torch.cuda.CUDAGraph()
-			with torch.cuda.graph(graph):
+			with torch.cuda.graph(graph, **CAPTURE):
 				self._step(oh, code)
 		# Steps after a search is done are no-ops on the device but still run the net on the padded batch, so the host must not
 		# poll too rarely: a search grows by at most K states per iteration, so no live search can run out of budget in fewer

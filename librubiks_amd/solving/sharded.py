@@ -55,7 +55,7 @@ import torch
 import torch.distributed as dist
 
 from librubiks_amd import gpu, no_grad, _ffi, cube
-from librubiks_amd.solving.agents import DeepAgent, _capture_key, _values_for_engine, _sliced_value_forward, _oh_dtype, _OH_CODES
+from librubiks_amd.solving.agents import CAPTURE, DeepAgent, _capture_key, _values_for_engine, _sliced_value_forward, _oh_dtype, _OH_CODES
 
 STOP_REASONS = {0: "running", 1: "won", 2: "budget", 3: "capacity", 4: "time", 5: "nothing open", 6: "engine error"}
 
@@ -330,7 +330,7 @@ class ShardedAStar(DeepAgent):
 						self._iteration(h, b, forward, rows, time_limit, max_states)      # a real iteration; also warms the allocator and the collectives
 					torch.cuda.current_stream().wait_stream(side)
 					graph = torch.cuda.CUDAGraph()
-					with torch.cuda.graph(graph):
+					with torch.cuda.graph(graph, **CAPTURE):
 						self._iteration(h, b, forward, rows, time_limit, max_states)
 					self._graph_cache = (key, graph, (self.net, self._fs))
 					self.captures += 1
