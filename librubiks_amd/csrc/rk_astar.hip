@@ -65,7 +65,8 @@ namespace rk {
 
 enum {
 	C_NSTATES = 0, C_NBEFORE, C_NPOP, C_NNEW, C_WON, C_SOLVED, C_DONE, C_BUDGET, C_ITERS, C_ERROR, C_OPEN, C_NCAND, C_NEXP, C_NIN,
-	C_NOFF, C_EPOCH, C_TICKET0 = 16, C_TICKET1, C_TICKET2, C_CLOCK0 = 20 /* and 21: the search's start on the device clock */, C_COUNT = 32
+	C_NOFF, C_EPOCH, C_TICKET0 = 16, C_TICKET1, C_TICKET2, C_CLOCK0 = 20 /* and 21: the search's start on the device clock */,
+	C_DECIDE_ACC = 22, C_DECIDE_TICKET = 23 /* k_shard_decide: pops counted so far, workgroups done */, C_COUNT = 32
 };
 enum { ERR_NONE = 0, ERR_CAPACITY = 1, ERR_CHAIN = 2, ERR_NET_ROWS = 3 /* sharded: more new states than net rows were evaluated */ };
 
@@ -190,7 +191,9 @@ __global__ void k_astar_root(AstarDev d, const uint32_t *root, int insert)
 constexpr int POP_LDS = 6144;                   // 96 KB of 16-byte records
 
 // Candidates are handled by threads first, first + stride, ...: one workgroup (end-of-iteration kernel) or a grid (k_pop_wide).
-__device__ __forceinline__ bool pop_is_wide(const AstarDev &d) { return d.world == 1 && d.q.levels * d.N > POP_LDS; }
+// (sharded engines too, round 5: every rank offers its N cheapest whatever the world size -- N = 5 600 in the weak-scaling run at 8 ranks --
+//  and one workgroup walking levels * N candidates through global memory was 130 us of a rank's iteration, benchmarks/sharded_sim8.py)
+__device__ __forceinline__ bool pop_is_wide(const AstarDev &d) { return d.q.levels * d.N > POP_LDS; }
 
 __device__ __forceinline__ void pop_select(const AstarDev &d, const int32_t *meta, int n_cand, int n_exp, Rec *s_heads, int first, int stride)
 {
@@ -842,7 +845,8 @@ __device__ __forceinline__ void end_body(const AstarDev &d, int new_in_rec1, int
 			g[0] = (double)s_ctr[C_NSTATES]; g[1] = (double)s_ctr[C_WON]; g[2] = (double)s_ctr[C_SOLVED]; g[3] = (double)s_ctr[C_ERROR];
 			g[4] = (double)s_ncand; g[5] = s_elapsed; g[6] = 0.0; g[7] = 0.0;   // g[5] = seconds since the reset on this rank's device clock (rank 0's decides)
 		}
-		for (int i = tid; i < d.N; i += blockDim.x) g[8 + i] = i < s_ncand ? key_to_double(d.cand_key[i]) : INFINITY;
+		// (wide selection: the candidates are not known yet -- k_pop_wide follows, then k_shard_heads writes these)
+		if (!pop_is_wide(d)) for (int i = tid; i < d.N; i += blockDim.x) g[8 + i] = i < s_ncand ? key_to_double(d.cand_key[i]) : INFINITY;
 	}
 }
 template <bool SHARDED>
@@ -894,6 +898,14 @@ __global__ __launch_bounds__(256)
 void k_pop_wide(AstarDev d)
 {
 	pop_wide_body(d);
+}
+// sharded engines with a wide selection: the rank's candidate costs for the next all-gather, behind k_pop_wide
+__global__ __launch_bounds__(256)
+void k_shard_heads(AstarDev d)
+{
+	const int n_cand = d.ctr[C_NCAND];
+	double *g = d.gather_in;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.N; i += gridDim.x * blockDim.x) g[8 + i] = i < n_cand ? key_to_double(d.cand_key[i]) : INFINITY;
 }
 __global__ __launch_bounds__(256)
 void kb_pop_wide(const AstarDev *__restrict__ devs)
@@ -983,10 +995,15 @@ __global__ void k_astar_find(const uint32_t *query, const uint32_t *states, cons
 enum { D_STOP = 0, D_WINNER_RANK, D_WINNER_IDX, D_TOTAL, D_NPOP, D_ITERS, D_NSTATES, D_ERROR, D_COUNT = 8 };
 enum { STOP_NO = 0, STOP_WON = 1, STOP_BUDGET = 2, STOP_CAPACITY = 3, STOP_TIME = 4, STOP_EMPTY = 5, STOP_ERROR = 6 };
 
-__global__ __launch_bounds__(1024)
+// A grid of 256-thread workgroups, one thread per candidate of this rank (round 5; rounds 2-4: ONE workgroup -- at the weak-scaling
+// run's N = 5 600 on 8 ranks every thread walked five or six candidates through seven binary searches of thirteen dependent loads:
+// 130 us of the iteration, benchmarks/sharded_sim8.py).  Every workgroup derives the stop decision for itself (eight header reads),
+// counts its candidates among the global top N, and the last one to finish (a ticket) publishes the pop count and the decision.
+__global__ __launch_bounds__(256)
 void k_shard_decide(AstarDev d, const double *gathered, double time_limit, double max_states, long long *decision)
 {
-	__shared__ int s_mine, s_stop;
+	__shared__ int s_mine, s_stop, s_winner, s_last;
+	__shared__ double s_total, s_maxerr;
 	const int tid = threadIdx.x, W = d.world, N = d.N, stride = 8 + N;
 	if (tid == 0) {
 		s_mine = 0;
@@ -1010,22 +1027,16 @@ void k_shard_decide(AstarDev d, const double *gathered, double time_limit, doubl
 		else if (total + (double)(12 * N) > max_states) stop = STOP_BUDGET;
 		else if (biggest + (double)(12 * N) > (double)(d.cap1 - 1)) stop = STOP_CAPACITY;       // a rank's pool could overflow
 		else if (cands == 0) stop = STOP_EMPTY;
-		s_stop = stop;
-		decision[D_STOP] = stop;
-		decision[D_WINNER_RANK] = winner;
-		decision[D_WINNER_IDX] = winner >= 0 ? (long long)gathered[(size_t)winner * stride + 2] : 0;
-		decision[D_TOTAL] = (long long)total;
-		decision[D_ITERS] = d.ctr[C_ITERS];
-		decision[D_NSTATES] = d.ctr[C_NSTATES];
-		decision[D_ERROR] = (long long)max_err;                          // the largest error code any rank reported (ERR_*)
-		if (stop != STOP_NO) d.ctr[C_DONE] = 1;
+		s_stop = stop; s_winner = winner; s_total = total; s_maxerr = max_err;
 	}
 	__syncthreads();
 	if (s_stop == STOP_NO) {
 		// my candidates' global ranks by (cost, rank, position); the n globally cheapest are popped
 		const double *mine = gathered + (size_t)d.rank * stride + 8;
 		const int n_mine = (int)gathered[(size_t)d.rank * stride + 4];
-		for (int i = tid; i < n_mine; i += blockDim.x) {
+		const int i = blockIdx.x * blockDim.x + tid;
+		bool in = false;
+		if (i < n_mine) {
 			const double x = mine[i];
 			int grank = i;
 			for (int r = 0; r < W; r++) {
@@ -1038,13 +1049,32 @@ void k_shard_decide(AstarDev d, const double *gathered, double time_limit, doubl
 				}
 				grank += lo;
 			}
-			if (grank < N) atomicAdd(&s_mine, 1);
+			in = grank < N;
 		}
+		const int cnt = __popcll(__ballot(in));
+		if ((tid & 63) == 0 && cnt) atomicAdd(&s_mine, cnt);
 	}
 	__syncthreads();
 	if (tid == 0) {
-		d.ctr[C_NPOP] = s_stop == STOP_NO ? s_mine : 0;
-		decision[D_NPOP] = d.ctr[C_NPOP];
+		if (s_mine) atomicAdd(&d.ctr[C_DECIDE_ACC], s_mine);
+		__threadfence();
+		s_last = atomicAdd(&d.ctr[C_DECIDE_TICKET], 1) == (int)gridDim.x - 1;
+	}
+	__syncthreads();
+	if (s_last && tid == 0) {                                          // every workgroup's count is in: publish
+		__threadfence();
+		const int pops = s_stop == STOP_NO ? __hip_atomic_load(&d.ctr[C_DECIDE_ACC], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+		d.ctr[C_DECIDE_ACC] = 0; d.ctr[C_DECIDE_TICKET] = 0;
+		d.ctr[C_NPOP] = pops;
+		decision[D_STOP] = s_stop;
+		decision[D_WINNER_RANK] = s_winner;
+		decision[D_WINNER_IDX] = s_winner >= 0 ? (long long)gathered[(size_t)s_winner * stride + 2] : 0;
+		decision[D_TOTAL] = (long long)s_total;
+		decision[D_NPOP] = pops;
+		decision[D_ITERS] = d.ctr[C_ITERS];
+		decision[D_NSTATES] = d.ctr[C_NSTATES];
+		decision[D_ERROR] = (long long)s_maxerr;                         // the largest error code any rank reported (ERR_*)
+		if (s_stop != STOP_NO) d.ctr[C_DONE] = 1;
 	}
 }
 
@@ -1202,7 +1232,7 @@ int dev_alloc(rk_astar *h, T **p, size_t count)
 }
 
 inline unsigned blocks(size_t n, unsigned per = 256) { return (unsigned)((n + per - 1) / per); }
-inline bool pop_is_wide_host(const AstarDev &d) { return d.world == 1 && d.q.levels * d.N > POP_LDS; }
+inline bool pop_is_wide_host(const AstarDev &d) { return d.q.levels * d.N > POP_LDS; }
 
 constexpr int WALK_MAX = 1 << 16;
 
@@ -1213,6 +1243,15 @@ int read_ctr(rk_astar *h, int32_t *out, hipStream_t st)
 	RK_HIP(hipStreamSynchronize(st));
 	if (dst != out) memcpy(out, dst, C_COUNT * sizeof(int32_t));
 	return RK_OK;
+}
+
+// sharded engines whose levels * N candidates do not fit one workgroup's LDS: the selection as a grid, then the candidate costs of the
+// next all-gather (k_end<true> has written the eight header doubles)
+static void launch_shard_wide_selection(const AstarDev &d, hipStream_t st)
+{
+	if (!pop_is_wide_host(d)) return;
+	hipLaunchKernelGGL(k_pop_wide, dim3(blocks((size_t)d.q.levels * d.N)), dim3(256), 0, st, d);
+	hipLaunchKernelGGL(k_shard_heads, dim3(blocks((size_t)d.N)), dim3(256), 0, st, d);
 }
 
 template <bool SHARDED>
@@ -1726,6 +1765,7 @@ int rk_astar_shard_reset(rk_astar_t *h, const int8_t *h_start_state, double lamb
 	hipLaunchKernelGGL(k_shard_clear_send, dim3(1), dim3(64), 0, st, h->d, (uint8_t *)d_send, 3);
 	// the first all-gather contribution: as k_end<true> would write it
 	hipLaunchKernelGGL((k_end<true>), dim3(1), dim3(1024), 0, st, h->d, 0, 0, 0);
+	launch_shard_wide_selection(h->d, st);
 	RK_HIP(hipGetLastError());
 	RK_HIP(hipStreamSynchronize(st));
 	return RK_OK;
@@ -1748,7 +1788,7 @@ int rk_astar_shard_select(rk_astar_t *h, const void *d_gathered, double time_lim
 	if (h->pending) return fail(RK_ESTATE, "rk_astar_shard_select: previous iteration not finished");
 	hipStream_t st = (hipStream_t)stream;
 	const AstarDev &d = h->d;
-	hipLaunchKernelGGL(k_shard_decide, dim3(1), dim3(1024), 0, st, d, (const double *)d_gathered, time_limit, max_states, h->decision);
+	hipLaunchKernelGGL(k_shard_decide, dim3(blocks((size_t)d.N)), dim3(256), 0, st, d, (const double *)d_gathered, time_limit, max_states, h->decision);
 	hipLaunchKernelGGL(k_shard_expand, dim3(blocks((size_t)d.K, ASCAN)), dim3(ASCAN), 0, st, d, (uint8_t *)d_send);
 	RK_HIP(hipGetLastError());
 	return RK_OK;
@@ -1812,6 +1852,7 @@ static int shard_push_impl(rk_astar_t *h, const float *d_values, int rows, const
 	const int from = launch_commit<true>(h, d_values, (const uint8_t *)d_recv, st, &d);
 	hipLaunchKernelGGL(k_shard_offers, dim3(blocks((size_t)d.KI, ASCAN)), dim3(ASCAN), 0, st, d, (const uint8_t *)d_recv, (uint8_t *)d_send);
 	hipLaunchKernelGGL((k_end<true>), dim3(1), dim3(1024), 0, st, d, from, 1, rows == d.K ? 0 : rows);
+	launch_shard_wide_selection(d, st);
 	RK_HIP(hipGetLastError());
 	h->pending = false;
 	return RK_OK;
