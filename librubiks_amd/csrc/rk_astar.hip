@@ -1245,6 +1245,9 @@ int read_ctr(rk_astar *h, int32_t *out, hipStream_t st)
 	return RK_OK;
 }
 
+// records an iteration is expected to push: what the open queue's level capacities are multiples of
+static inline int queue_inflow(const AstarDev &d) { return d.world == 1 ? d.K : (d.K + d.world - 1) / d.world; }
+
 // sharded engines whose levels * N candidates do not fit one workgroup's LDS: the selection as a grid, then the candidate costs of the
 // next all-gather (k_end<true> has written the eight header doubles)
 static void launch_shard_wide_selection(const AstarDev &d, hipStream_t st)
@@ -1341,9 +1344,13 @@ static int astar_create_impl(rk_astar_t **out, size_t capacity, int max_expansio
 	A(chain0, n_scan_blocks); A(chain1, n_scan_blocks * (size_t)world); A(chain2, n_scan_blocks * (size_t)world);
 	A(hit, KS); A(gather_in, (size_t)d.N + 16);
 	#undef A
-	// queue levels: 4 K, 16 K, 64 K, ... records, the top level holds the whole pool
+	// queue levels: 4 K, 16 K, 64 K, ... records, the top level holds the whole pool.  K here is what an iteration is expected to PUSH:
+	// 12 N on one GPU, 12 N / world on a rank of a sharded search (owner = hash).  Rounds 2-4 sized a rank's levels by its incoming
+	// SLOTS, world * 12 N: at 8 ranks level 0 held 64 iterations' worth of records and every push rewrote all of it -- 183 us of a
+	// rank's iteration in the weak-scaling run (benchmarks/sharded_sim8.py).  The sizes are tuning, not correctness: a push that does
+	// not fit level 0 goes to the first level that holds it (make_plan).
 	if (!e) e = dev_alloc(h, &d.q.meta, 4 * QL);
-	uint64_t c = std::max<uint64_t>(4ull * (uint64_t)kin, 4096ull);
+	uint64_t c = std::max<uint64_t>(4ull * (uint64_t)queue_inflow(d), 4096ull);
 	int levels = 0;
 	for (; levels < QL && !e; levels++) {
 		const bool top = c >= C1 || levels == QL - 1;
@@ -1458,8 +1465,7 @@ int rk_astar_grow(rk_astar_t *h, size_t new_capacity, void *stream)
 	RK_GROW(table, uint32_t, (size_t)t); RK_GROW(mark, uint32_t, C1);
 	#undef RK_GROW
 	// queue levels: capacities 4 K, 16 K, ... as at creation; a level whose capacity is unchanged keeps its buffers
-	const int kin = d.world == 1 ? d.K : d.KI;
-	uint64_t c = std::max<uint64_t>(4ull * (uint64_t)kin, 4096ull);
+	uint64_t c = std::max<uint64_t>(4ull * (uint64_t)queue_inflow(d), 4096ull);
 	int levels = 0;
 	for (; levels < QL && ok; levels++) {
 		const bool top = c >= C1 || levels == QL - 1;
