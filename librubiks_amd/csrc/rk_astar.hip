@@ -309,22 +309,44 @@ void kb_expand_lookup(const AstarDev *__restrict__ devs)
 
 
 // Sharded mode: incoming child slots.  The receive buffer is `world` blocks of {32-byte header, K records of 32 B,
-// K shortcut offers of 16 B}; batch position c = src * K + pos keeps arrival order (grouped by sending rank, each group
-// in the sender's order) without compaction.  Record: {state[5], parent_idx, g | action<<16 | parent_rank<<24, pad}.
+// K shortcut offers of 16 B}.  Batch position c counts the records in ARRIVAL ORDER -- grouped by sending rank, each group in the
+// sender's order -- over the records that are there: c = (records of the peers before `src`) + pos.  All ranks together pop N nodes,
+// so a rank receives at most K = 12 N records (and K offers) whatever the world size: every receive-side kernel is a grid over K
+// positions.  (Rounds 2-4 used c = src * K + pos over world * K slots, 98 % of them empty at 8 ranks: the receive side's five
+// kernels and their ticketed look-back chains ran over 2 100 workgroups where 263 carry records -- benchmarks/sharded_sim8.py.)
+// Record: {state[5], parent_idx, g | action<<16 | parent_rank<<24, pad}.
 __device__ __forceinline__ size_t shard_block_bytes(int K) { return 32 + (size_t)K * 48; }
 __device__ __forceinline__ const uint32_t *shard_hdr(const uint8_t *buf, int K, int peer)
 {
 	return reinterpret_cast<const uint32_t *>(buf + (size_t)peer * shard_block_bytes(K));
 }
-__device__ __forceinline__ const uint32_t *shard_rec(const uint8_t *buf, int K, int c)
+constexpr int SHARD_MAX_WORLD = 64;
+// Per workgroup, once: s_pref[p] = records (which = 0) or offers (which = 1) of the peers before p, s_pref[world] = their total.
+// Contains a barrier: call from ALL threads, before any early exit.
+__device__ __forceinline__ void shard_stage_prefix(int *s_pref /* world + 1 */, const uint8_t *buf, int K, int world, int which)
 {
-	const int peer = c / K, pos = c - peer * K;
-	return reinterpret_cast<const uint32_t *>(buf + (size_t)peer * shard_block_bytes(K) + 32 + (size_t)pos * 32);
+	if ((int)threadIdx.x < world) s_pref[threadIdx.x + 1] = (int)shard_hdr(buf, K, (int)threadIdx.x)[which];
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		int sum = 0;
+		s_pref[0] = 0;
+		for (int p = 0; p < world; p++) { sum += s_pref[p + 1]; s_pref[p + 1] = sum; }
+	}
+	__syncthreads();
 }
-__device__ __forceinline__ bool shard_valid(const uint8_t *buf, int K, int c)
+__device__ __forceinline__ bool shard_valid(const int *s_pref, int world, int c) { return c < s_pref[world]; }
+// (peer, pos) of batch position c < s_pref[world]
+__device__ __forceinline__ void shard_locate(const int *s_pref, int world, int c, int &peer, int &pos)
 {
-	const int peer = c / K, pos = c - peer * K;
-	return pos < (int)shard_hdr(buf, K, peer)[0];
+	int p = 0;
+	while (p + 1 < world && c >= s_pref[p + 1]) p++;
+	peer = p; pos = c - s_pref[p];
+}
+__device__ __forceinline__ const uint32_t *shard_rec(const uint8_t *buf, int K, const int *s_pref, int world, int c)
+{
+	int peer, pos;
+	shard_locate(s_pref, world, c, peer, pos);
+	return reinterpret_cast<const uint32_t *>(buf + (size_t)peer * shard_block_bytes(K) + 32 + (size_t)pos * 32);
 }
 
 // The net's input rows for the new states of this iteration, (n_new, 480) one-hot or (n_new, 20) raw states, written by a
@@ -337,14 +359,16 @@ __device__ __forceinline__ void new_rows_body(const AstarDev &d, u32x4 *out, uin
 	// relaxation case 1, write half (agents.py:357-359): first-seen children that found a shorter way to an old node.
 	// It only needs the append kernel's results and touches old nodes, so it rides here, off the critical path after the
 	// net.  The reference returns before relaxing once it has won (agents.py:321-323).
+	__shared__ int s_pref[SHARDED ? SHARD_MAX_WORLD + 1 : 1];
+	if (SHARDED) shard_stage_prefix(s_pref, recv, d.K, d.world, 0);
 	if (!d.ctr[C_WON]) {
-		const int K = SHARDED ? d.KI : 12 * d.ctr[C_NPOP];
+		const int K = SHARDED ? s_pref[d.world] : 12 * d.ctr[C_NPOP];
 		for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < K; c += gridDim.x * blockDim.x) {
 			if (!(d.flags[c] & 2) || !d.newway[c]) continue;
 			const int32_t t = d.seen[c];
 			d.G[t] = d.val1[c];
 			if (SHARDED) {
-				const uint32_t *r = shard_rec(recv, d.K, c);
+				const uint32_t *r = shard_rec(recv, d.K, s_pref, d.world, c);
 				d.pact[t] = (uint8_t)((r[6] >> 16) & 0xFFu);
 				d.parents[t] = (int32_t)r[5];
 				d.prank[t] = (uint8_t)(r[6] >> 24);
@@ -433,11 +457,13 @@ void kb_new_rows(const AstarDev *__restrict__ devs, u32x4 *out, uint32_t one_bit
 __global__ __launch_bounds__(256)
 void k_shard_lookup(AstarDev d, const uint8_t *recv)
 {
+	__shared__ int s_pref[SHARD_MAX_WORLD + 1];
+	shard_stage_prefix(s_pref, recv, d.K, d.world, 0);
 	const int c = blockIdx.x * blockDim.x + threadIdx.x;
-	if (c >= d.KI || d.ctr[C_DONE] || !shard_valid(recv, d.K, c)) return;
+	if (d.ctr[C_DONE] || !shard_valid(s_pref, d.world, c)) return;
 	uint32_t s[5];
-	load5(shard_rec(recv, d.K, c), s);
-	lookup_elect(d, s, c, [&](int c2, uint32_t o[5]) { load5(shard_rec(recv, d.K, c2), o); });
+	load5(shard_rec(recv, d.K, s_pref, d.world, c), s);
+	lookup_elect(d, s, c, [&](int c2, uint32_t o[5]) { load5(shard_rec(recv, d.K, s_pref, d.world, c2), o); });
 }
 
 // flags + order-preserving compaction (tickets + look-back) + append + goal test + relaxation case 1 (read half).
@@ -447,11 +473,13 @@ __device__ __forceinline__ void append_body(const AstarDev &d, const uint8_t *re
 {
 	__shared__ int s_wave[4];
 	__shared__ int s_ticket, s_base;
+	__shared__ int s_pref[SHARDED ? SHARD_MAX_WORLD + 1 : 1];
+	if (SHARDED) shard_stage_prefix(s_pref, recv, d.K, d.world, 0);
 	const int b = scan_ticket(&d.ctr[C_TICKET0], &s_ticket);
-	const int K = SHARDED ? d.KI : 12 * d.ctr[C_NPOP];
+	const int K = SHARDED ? s_pref[d.world] : 12 * d.ctr[C_NPOP];
 	const bool live = !d.ctr[C_DONE] || !SHARDED;                       // (single mode: K is 0 once done)
 	const int c = b * ASCAN + threadIdx.x;
-	const bool valid = live && c < K && (!SHARDED || shard_valid(recv, d.K, c));
+	const bool valid = live && c < K;
 	int fu = 0, fs = 0;
 	int32_t sidx = 0;
 	if (valid) {
@@ -459,7 +487,7 @@ __device__ __forceinline__ void append_body(const AstarDev &d, const uint8_t *re
 		if (sidx == 0) fu = __hip_atomic_load(&d.table[d.child_slot[c]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (TENT | (uint32_t)c);
 		else fs = __hip_atomic_load(&d.mark[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)c;
 	}
-	if (c < (SHARDED ? d.KI : d.K)) d.flags[c] = (uint8_t)(fu | (fs << 1));
+	if (c < d.K) d.flags[c] = (uint8_t)(fu | (fs << 1));
 	int total;
 	const int r = block_rank256(fu != 0, s_wave, &total);
 	const uint32_t epoch = (uint32_t)d.ctr[C_EPOCH] + 1u;
@@ -470,7 +498,7 @@ __device__ __forceinline__ void append_body(const AstarDev &d, const uint8_t *re
 		d.ctr[C_NSTATES] = (int32_t)n_before + base + total;
 	}
 	if (valid) {
-		const uint32_t *cs = SHARDED ? shard_rec(recv, d.K, c) : d.children + (size_t)c * 5;
+		const uint32_t *cs = SHARDED ? shard_rec(recv, d.K, s_pref, d.world, c) : d.children + (size_t)c * 5;
 		int32_t p, g;
 		uint8_t act, pr = (uint8_t)d.rank;
 		if (SHARDED) {
@@ -1122,23 +1150,21 @@ void k_shard_expand(AstarDev d, uint8_t *send)
 }
 
 // Shortcut offer (16 B): {parent_idx, new G for the parent, index of the child on this rank, this rank | rev(action) << 8}
-__device__ __forceinline__ const u32x4 *shard_offer(const uint8_t *buf, int K, int o)
+__device__ __forceinline__ const u32x4 *shard_offer(const uint8_t *buf, int K, const int *s_pref, int world, int o)
 {
-	const int peer = o / K, pos = o - peer * K;
+	int peer, pos;
+	shard_locate(s_pref, world, o, peer, pos);
 	return reinterpret_cast<const u32x4 *>(buf + (size_t)peer * shard_block_bytes(K) + 32 + (size_t)K * 32 + (size_t)pos * 16);
-}
-__device__ __forceinline__ bool shard_offer_valid(const uint8_t *buf, int K, int o)
-{
-	const int peer = o / K, pos = o - peer * K;
-	return pos < (int)shard_hdr(buf, K, peer)[1];
 }
 
 // phase 0: evaluate (read all of G first) and elect the last hit per parent; phase 1: apply; phase 2: clear the marks
 __global__ void k_shard_offers_in(AstarDev d, const uint8_t *recv, int phase)
 {
+	__shared__ int s_pref[SHARD_MAX_WORLD + 1];
+	shard_stage_prefix(s_pref, recv, d.K, d.world, 1);                  // offers: header word 1
 	const int o = blockIdx.x * blockDim.x + threadIdx.x;
-	if (o >= d.KI || !shard_offer_valid(recv, d.K, o)) return;
-	const u32x4 r = *shard_offer(recv, d.K, o);
+	if (!shard_valid(s_pref, d.world, o)) return;
+	const u32x4 r = *shard_offer(recv, d.K, s_pref, d.world, o);
 	if (phase == 0) {
 		const bool h = (int32_t)r.y < d.G[r.x];
 		d.hit[o] = h;
@@ -1161,13 +1187,15 @@ void k_shard_offers(AstarDev d, const uint8_t *recv, uint8_t *send)
 {
 	__shared__ int s_wave[4];
 	__shared__ int s_ticket, s_base;
+	__shared__ int s_pref[SHARD_MAX_WORLD + 1];
+	shard_stage_prefix(s_pref, recv, d.K, d.world, 0);
 	const int b = scan_ticket(&d.ctr[C_TICKET2], &s_ticket);
 	const int c = b * ASCAN + threadIdx.x;
 	const bool live = !d.ctr[C_DONE] && !d.ctr[C_WON];
 	uint32_t dst_rank = 0xFFFFFFFFu;
 	u32x4 rec = {0u, 0u, 0u, 0u};
-	if (!d.ctr[C_DONE] && c < d.KI && shard_valid(recv, d.K, c) && (d.flags[c] & 2)) {
-		const uint32_t *r = shard_rec(recv, d.K, c);
+	if (!d.ctr[C_DONE] && shard_valid(s_pref, d.world, c) && (d.flags[c] & 2)) {
+		const uint32_t *r = shard_rec(recv, d.K, s_pref, d.world, c);
 		const int32_t t = d.seen[c];
 		d.mark[t] = NO_MARK;
 		const int32_t g_parent = (int32_t)(r[6] & 0xFFFFu) - 1;
@@ -1261,7 +1289,7 @@ template <bool SHARDED>
 void launch_append(rk_astar *h, const uint8_t *recv, void *d_onehot, int out_dtype, hipStream_t st)
 {
 	const AstarDev &d = h->d;
-	const size_t kin = SHARDED ? (size_t)d.KI : (size_t)d.K;
+	const size_t kin = (size_t)d.K;                                    // (sharded too: at most K records arrive, see shard_stage_prefix)
 	hipLaunchKernelGGL((k_append<SHARDED>), dim3(blocks(kin, ASCAN)), dim3(ASCAN), 0, st, d, recv);
 	// the net's input rows (about one 16-byte store per thread: the grid covers the largest possible batch) + relaxation 1
 	const size_t chunks = d_onehot == nullptr ? kin : kin * (out_dtype == RK_OH_F32 ? 120 : out_dtype == RK_OH_STATES ? 2 : 60);
@@ -1818,7 +1846,7 @@ int rk_astar_shard_insert(rk_astar_t *h, const void *d_recv, void *d_send, void 
 	hipStream_t st = (hipStream_t)stream;
 	const AstarDev &d = h->d;
 	const uint8_t *recv = (const uint8_t *)d_recv;
-	const unsigned gK = blocks((size_t)d.KI);
+	const unsigned gK = blocks((size_t)d.K);
 	for (int phase = 0; phase < 3; phase++)
 		hipLaunchKernelGGL(k_shard_offers_in, dim3(gK), dim3(256), 0, st, d, recv, phase);
 	hipLaunchKernelGGL(k_shard_lookup, dim3(gK), dim3(256), 0, st, d, recv);
@@ -1856,7 +1884,7 @@ static int shard_push_impl(rk_astar_t *h, const float *d_values, int rows, const
 		d.Kpad = std::min(d.Kpad, ((rows + d.chunk - 1) / d.chunk) * d.chunk);
 	}
 	const int from = launch_commit<true>(h, d_values, (const uint8_t *)d_recv, st, &d);
-	hipLaunchKernelGGL(k_shard_offers, dim3(blocks((size_t)d.KI, ASCAN)), dim3(ASCAN), 0, st, d, (const uint8_t *)d_recv, (uint8_t *)d_send);
+	hipLaunchKernelGGL(k_shard_offers, dim3(blocks((size_t)d.K, ASCAN)), dim3(ASCAN), 0, st, d, (const uint8_t *)d_recv, (uint8_t *)d_send);
 	hipLaunchKernelGGL((k_end<true>), dim3(1), dim3(1024), 0, st, d, from, 1, rows == d.K ? 0 : rows);
 	launch_shard_wide_selection(d, st);
 	RK_HIP(hipGetLastError());
@@ -1879,7 +1907,7 @@ int rk_astar_shard_flush(rk_astar_t *h, const void *d_recv, void *stream)
 {
 	if (!h || !h->ready || !d_recv) return fail(RK_EINVAL, "rk_astar_shard_flush: bad argument");
 	hipStream_t st = (hipStream_t)stream;
-	const unsigned gK = blocks((size_t)h->d.KI);
+	const unsigned gK = blocks((size_t)h->d.K);
 	for (int phase = 0; phase < 3; phase++)
 		hipLaunchKernelGGL(k_shard_offers_in, dim3(gK), dim3(256), 0, st, h->d, (const uint8_t *)d_recv, phase);
 	RK_HIP(hipGetLastError());
