@@ -476,10 +476,14 @@ __device__ __forceinline__ void append_body(const AstarDev &d, const uint8_t *re
 	__shared__ int s_pref[SHARDED ? SHARD_MAX_WORLD + 1 : 1];
 	if (SHARDED) shard_stage_prefix(s_pref, recv, d.K, d.world, 0);
 	const int b = scan_ticket(&d.ctr[C_TICKET0], &s_ticket);
-	const int K = SHARDED ? s_pref[d.world] : 12 * d.ctr[C_NPOP];
 	const bool live = !d.ctr[C_DONE] || !SHARDED;                       // (single mode: K is 0 once done)
+	const int K = !live ? 0 : SHARDED ? s_pref[d.world] : 12 * d.ctr[C_NPOP];
+	// the grid covers the largest batch; the tickets past the batch's last workgroup have nothing to add to the scan and leave
+	// (a rank of a sharded search receives about 1 / world of it: seven workgroups in eight)
+	const int last = K > 0 ? (K - 1) / ASCAN : 0;
+	if (b > last) return;
 	const int c = b * ASCAN + threadIdx.x;
-	const bool valid = live && c < K;
+	const bool valid = c < K;
 	int fu = 0, fs = 0;
 	int32_t sidx = 0;
 	if (valid) {
@@ -493,7 +497,7 @@ __device__ __forceinline__ void append_body(const AstarDev &d, const uint8_t *re
 	const uint32_t epoch = (uint32_t)d.ctr[C_EPOCH] + 1u;
 	const int base = scan_lookback(d.chain0, b, total, epoch, &s_base);
 	const uint32_t n_before = (uint32_t)d.ctr[C_NBEFORE];
-	if (b == (int)gridDim.x - 1 && threadIdx.x == 0) {                  // the last ticket holds the grand total
+	if (b == last && threadIdx.x == 0) {                                // the batch's last ticket holds the grand total
 		d.ctr[C_NNEW] = base + total;
 		d.ctr[C_NSTATES] = (int32_t)n_before + base + total;
 	}
@@ -1118,6 +1122,8 @@ void k_shard_expand(AstarDev d, uint8_t *send)
 	if (threadIdx.x < QL) s_take[threadIdx.x] = 0;
 	const int b = scan_ticket(&d.ctr[C_TICKET1], &s_ticket);                // (contains the barrier that publishes s_take)
 	const int n_pop = d.ctr[C_NPOP], K = 12 * n_pop;
+	const int last = K > 0 ? (K - 1) / ASCAN : 0;                        // tickets past the last workgroup with children leave (see append_body)
+	if (b > last) return;
 	const int c = b * ASCAN + threadIdx.x;
 	const bool valid = c < K;
 	uint32_t s[5] = {0, 0, 0, 0, 0}, meta6 = 0, p = 0, owner = 0xFFFFFFFFu;
@@ -1143,7 +1149,7 @@ void k_shard_expand(AstarDev d, uint8_t *send)
 			dst[0] = u32x4{s[0], s[1], s[2], s[3]};
 			dst[1] = u32x4{s[4], p, meta6, (uint32_t)c};
 		}
-		if (b == (int)gridDim.x - 1 && threadIdx.x == 0) reinterpret_cast<uint32_t *>(blk)[0] = (uint32_t)(base + total);
+		if (b == last && threadIdx.x == 0) reinterpret_cast<uint32_t *>(blk)[0] = (uint32_t)(base + total);
 		__syncthreads();                                                 // s_base is reused by the next owner
 	}
 	if (threadIdx.x < QL && s_take[threadIdx.x] > 0) atomicAdd(&qmeta(d.q, Q_TAKE)[threadIdx.x], s_take[threadIdx.x]);
@@ -1190,6 +1196,9 @@ void k_shard_offers(AstarDev d, const uint8_t *recv, uint8_t *send)
 	__shared__ int s_pref[SHARD_MAX_WORLD + 1];
 	shard_stage_prefix(s_pref, recv, d.K, d.world, 0);
 	const int b = scan_ticket(&d.ctr[C_TICKET2], &s_ticket);
+	const int n_in = d.ctr[C_DONE] ? 0 : s_pref[d.world];
+	const int last = n_in > 0 ? (n_in - 1) / ASCAN : 0;                  // tickets past the last workgroup with records leave (see append_body)
+	if (b > last) return;
 	const int c = b * ASCAN + threadIdx.x;
 	const bool live = !d.ctr[C_DONE] && !d.ctr[C_WON];
 	uint32_t dst_rank = 0xFFFFFFFFu;
@@ -1213,7 +1222,7 @@ void k_shard_offers(AstarDev d, const uint8_t *recv, uint8_t *send)
 		uint8_t *blk = send + (size_t)w * shard_block_bytes(d.K);
 		if (dst_rank == (uint32_t)w)
 			*reinterpret_cast<u32x4 *>(blk + 32 + (size_t)d.K * 32 + (size_t)(base + r) * 16) = rec;
-		if (b == (int)gridDim.x - 1 && threadIdx.x == 0) reinterpret_cast<uint32_t *>(blk)[1] = (uint32_t)(base + total);
+		if (b == last && threadIdx.x == 0) reinterpret_cast<uint32_t *>(blk)[1] = (uint32_t)(base + total);
 		__syncthreads();
 	}
 }
