@@ -1116,7 +1116,7 @@ void k_shard_expand(AstarDev d, uint8_t *send)
 {
 	__shared__ u32x4 s_act[36];
 	__shared__ int s_wave[4];
-	__shared__ int s_ticket, s_base;
+	__shared__ int s_ticket;
 	__shared__ int s_take[QL];
 	stage_action_tables(s_act, threadIdx.x);
 	if (threadIdx.x < QL) s_take[threadIdx.x] = 0;
@@ -1139,19 +1139,15 @@ void k_shard_expand(AstarDev d, uint8_t *send)
 		owner = owner_of(s, (uint32_t)d.world);
 	}
 	const uint32_t epoch = (uint32_t)d.ctr[C_EPOCH] + 1u;
-	for (int w = 0; w < d.world; w++) {                                  // world <= 8 on a node: one ballot round per owner
-		int total;
-		const int r = block_rank256(owner == (uint32_t)w, s_wave, &total);
-		const int base = scan_lookback(d.chain1 + (size_t)w * gridDim.x, b, total, epoch, &s_base);
-		uint8_t *blk = send + (size_t)w * shard_block_bytes(d.K);
-		if (owner == (uint32_t)w) {
-			u32x4 *dst = reinterpret_cast<u32x4 *>(blk + 32 + (size_t)(base + r) * 32);
-			dst[0] = u32x4{s[0], s[1], s[2], s[3]};
-			dst[1] = u32x4{s[4], p, meta6, (uint32_t)c};
-		}
-		if (b == last && threadIdx.x == 0) reinterpret_cast<uint32_t *>(blk)[0] = (uint32_t)(base + total);
-		__syncthreads();                                                 // s_base is reused by the next owner
+	__shared__ int s_tot[SHARD_MAX_WORLD], s_bases[SHARD_MAX_WORLD];
+	const int at = scan_lookback_classes(d.chain1, (int)gridDim.x, b, d.world, owner, epoch, s_wave, s_tot, s_bases);
+	if (valid) {
+		u32x4 *dst = reinterpret_cast<u32x4 *>(send + (size_t)owner * shard_block_bytes(d.K) + 32 + (size_t)at * 32);
+		dst[0] = u32x4{s[0], s[1], s[2], s[3]};
+		dst[1] = u32x4{s[4], p, meta6, (uint32_t)c};
 	}
+	if (b == last && (int)threadIdx.x < d.world)                          // the batch's last ticket holds every owner's grand total
+		reinterpret_cast<uint32_t *>(send + (size_t)threadIdx.x * shard_block_bytes(d.K))[0] = (uint32_t)(s_bases[threadIdx.x] + s_tot[threadIdx.x]);
 	if (threadIdx.x < QL && s_take[threadIdx.x] > 0) atomicAdd(&qmeta(d.q, Q_TAKE)[threadIdx.x], s_take[threadIdx.x]);
 }
 
@@ -1192,7 +1188,7 @@ __global__ __launch_bounds__(ASCAN)
 void k_shard_offers(AstarDev d, const uint8_t *recv, uint8_t *send)
 {
 	__shared__ int s_wave[4];
-	__shared__ int s_ticket, s_base;
+	__shared__ int s_ticket;
 	__shared__ int s_pref[SHARD_MAX_WORLD + 1];
 	shard_stage_prefix(s_pref, recv, d.K, d.world, 0);
 	const int b = scan_ticket(&d.ctr[C_TICKET2], &s_ticket);
@@ -1215,16 +1211,12 @@ void k_shard_offers(AstarDev d, const uint8_t *recv, uint8_t *send)
 		}
 	}
 	const uint32_t epoch = (uint32_t)d.ctr[C_EPOCH] + 1u;
-	for (int w = 0; w < d.world; w++) {
-		int total;
-		const int r = block_rank256(dst_rank == (uint32_t)w, s_wave, &total);
-		const int base = scan_lookback(d.chain2 + (size_t)w * gridDim.x, b, total, epoch, &s_base);
-		uint8_t *blk = send + (size_t)w * shard_block_bytes(d.K);
-		if (dst_rank == (uint32_t)w)
-			*reinterpret_cast<u32x4 *>(blk + 32 + (size_t)d.K * 32 + (size_t)(base + r) * 16) = rec;
-		if (b == last && threadIdx.x == 0) reinterpret_cast<uint32_t *>(blk)[1] = (uint32_t)(base + total);
-		__syncthreads();
-	}
+	__shared__ int s_tot[SHARD_MAX_WORLD], s_bases[SHARD_MAX_WORLD];
+	const int at = scan_lookback_classes(d.chain2, (int)gridDim.x, b, d.world, dst_rank, epoch, s_wave, s_tot, s_bases);
+	if (dst_rank < (uint32_t)d.world)
+		*reinterpret_cast<u32x4 *>(send + (size_t)dst_rank * shard_block_bytes(d.K) + 32 + (size_t)d.K * 32 + (size_t)at * 16) = rec;
+	if (b == last && (int)threadIdx.x < d.world)
+		reinterpret_cast<uint32_t *>(send + (size_t)threadIdx.x * shard_block_bytes(d.K))[1] = (uint32_t)(s_bases[threadIdx.x] + s_tot[threadIdx.x]);
 }
 
 // zero the counts of every send block (after a flush, or before the first iteration)

@@ -130,6 +130,50 @@ __device__ __forceinline__ int scan_lookback(unsigned long long *words, int b, i
 	return *s_base;
 }
 
+// The same for W classes at once (the sharded engine buckets records by owner rank): every thread belongs to class `cls` (none: cls >= W).
+// Returns the thread's position in its class's output -- the class's total over all workgroups with smaller tickets plus the thread's rank
+// inside this workgroup; afterwards s_tot[w] / s_base[w] (W ints each, LDS) hold this workgroup's total and its predecessors' sum per class.
+// ALL totals are published before anybody waits, so the chain costs ONE wait on the predecessors instead of W of them back to back
+// (W = 8: the sharded expand kernel spent 41 us of a 14-us job in eight dependent look-backs, benchmarks/sharded_sim8.py).
+// words: W rows of `nblocks` look-back words.  Call from ALL threads of a 256-thread workgroup.
+__device__ __forceinline__ int scan_lookback_classes(unsigned long long *words, int nblocks, int b, int W, uint32_t cls, uint32_t epoch,
+                                                    int *s_wave /* [4] */, int *s_tot, int *s_base)
+{
+	int my = 0;
+	for (int w = 0; w < W; w++) {
+		int total;
+		const int r = block_rank256(cls == (uint32_t)w, s_wave, &total);
+		if (cls == (uint32_t)w) my = r;
+		if (threadIdx.x == 0) s_tot[w] = total;
+	}
+	__syncthreads();
+	if ((int)threadIdx.x < W)
+		__hip_atomic_store(&words[(size_t)threadIdx.x * nblocks + b], ((unsigned long long)epoch << 32) | (uint32_t)s_tot[threadIdx.x],
+		                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+	for (int w = wv; w < W; w += nw) {                // a wave per class, 64 predecessors per round
+		const unsigned long long *row = words + (size_t)w * nblocks;
+		int sum = 0;
+		for (int j0 = 0; j0 < b; j0 += 64) {
+			const int j = j0 + lane;
+			if (j < b) {
+				unsigned long long x;
+				for (;;) {
+					x = __hip_atomic_load(&row[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if ((uint32_t)(x >> 32) == epoch) break;
+					__builtin_amdgcn_s_sleep(1);
+				}
+				sum += (int)(uint32_t)x;
+			}
+		}
+		#pragma unroll
+		for (int m = 32; m > 0; m >>= 1) sum += __shfl_xor(sum, m, 64);
+		if (lane == 0) s_base[w] = sum;
+	}
+	__syncthreads();
+	return (cls < (uint32_t)W ? s_base[cls] : 0) + my;
+}
+
 __device__ __forceinline__ int lower_bound_rec(const Rec *a, int n, const Rec &x)
 {
 	int lo = 0, hi = n;
