@@ -102,37 +102,47 @@ def sharded_astar_leg(dist, backend: str, world: int, rank: int, *, weak: bool, 
 	for g in seeds:
 		np.random.seed(g)
 		starts.append(cube.scramble(depth, True)[0])
-	secs = states = iters = solved = rows = launches = 0
-	stops, game_secs, game_iters = [], [], []
-	for st in starts:
+	def play(st):
 		barrier()
 		t0 = time.perf_counter()
 		ok = agent.search(st, time_limit=time_limit, max_states=total_budget)
 		torch.cuda.synchronize()
-		game_secs.append(_max_over_ranks(time.perf_counter() - t0, dist, backend))
+		return ok, _max_over_ranks(time.perf_counter() - t0, dist, backend)      # the same number on every rank
+
+	# Game 0 both ways first -- the captured iteration replayed (one launch per iteration) and the same iteration issued eagerly (about
+	# thirty launches) -- then the timed games in the faster form: which one wins depends on whether the host's launch bill or the
+	# GPU bounds the iteration at THIS world size (world 1, N = 700: the GPU, and the replay is 5-9 % slower; 1 344-row nets at world 8:
+	# unknown until a node runs it).  The times are max-over-ranks, so every rank takes the same decision.
+	graph_ms = eager_ms = None
+	can_graph = False
+	if want_graph:
+		_, t = play(starts[0])
+		can_graph = agent.use_hipgraph and agent.graph_error is None
+		if can_graph:
+			graph_ms = t / max(agent.iterations, 1) * 1e3
+	graph_error = agent.graph_error
+	agent.use_hipgraph = False
+	_, t = play(starts[0])
+	eager_ms = t / max(agent.iterations, 1) * 1e3
+	use_graph = can_graph and graph_ms < eager_ms
+	agent.use_hipgraph = use_graph
+	secs = states = iters = solved = rows = launches = 0
+	stops, game_secs, game_iters = [], [], []
+	for st in starts:
+		ok, t = play(st)
+		game_secs.append(t)
 		game_iters.append(agent.iterations)
-		secs += game_secs[-1]
+		secs += t
 		states += agent.total_states
 		iters += agent.iterations
 		solved += bool(ok)
 		rows += agent.net_rows_total
 		launches += agent.host_launches
 		stops.append(agent.stop_reason)
-	# the phase split: a second pass over the first game with HIP events between the phases of every iteration (device time on the
-	# search stream; the events themselves cost a few microseconds per phase, so the timed pass above runs without them)
-	graph_state = "replayed" if (agent.use_hipgraph and agent.graph_error is None) else ("eager: " + (agent.graph_error or "not requested"))
+	graph_state = ("replayed" if use_graph else "eager (faster on game 0)" if can_graph else "eager: " + (graph_error or "not requested"))
 	repeated, rows_fixed = agent.repeated, agent.net_rows_max
-	# the other way of driving the same iteration, on game 0 (eager launches if the timed games replayed the graph): says on THIS box and
-	# world size whether the host's launch bill or the GPU bounds the iteration
-	eager_ms = None
-	if graph_state == "replayed":
-		agent.use_hipgraph = False
-		barrier()
-		t0 = time.perf_counter()
-		agent.search(starts[0], time_limit=time_limit, max_states=total_budget)
-		torch.cuda.synchronize()
-		eager_ms = _max_over_ranks(time.perf_counter() - t0, dist, backend) / max(agent.iterations, 1) * 1e3
-		agent.use_hipgraph = True
+	# the phase split: one more pass over the first game with HIP events between the phases of every iteration (device time on the
+	# search stream; the events themselves cost a few microseconds per phase, so the timed passes above run without them)
 	agent.profile = True
 	barrier()
 	agent.search(starts[0], time_limit=time_limit, max_states=total_budget)
@@ -147,8 +157,8 @@ def sharded_astar_leg(dist, backend: str, world: int, rank: int, *, weak: bool, 
 		pre + "total_states": states, pre + "games": len(starts), pre + "solved": solved, pre + "stop_reasons": ",".join(stops),
 		pre + "expansions_per_iteration": N, pre + "budget": total_budget,
 		pre + "net_rows_per_rank": rows_fixed, pre + "net_rows_bound_12N": 12 * N, pre + "row_shortfall_repeats": repeated,
-		pre + "hipgraph": graph_state, pre + "graph_launches_per_iteration": launches / max(iters, 1) if graph_state == "replayed" else None,
-		pre + "ms_per_iteration_game0": game_secs[0] / max(game_iters[0], 1) * 1e3, pre + "ms_per_iteration_game0_eager": eager_ms,
+		pre + "hipgraph": graph_state, pre + "graph_launches_per_iteration": launches / max(iters, 1) if use_graph else None,
+		pre + "ms_per_iteration_game0_replayed": graph_ms, pre + "ms_per_iteration_game0_eager": eager_ms,
 		pre + "allgather_us": ph.get("all_gather", 0.0) * 1e3, pre + "select_us": ph.get("select+expand", 0.0) * 1e3,
 		pre + "alltoall_us": ph.get("all_to_all", 0.0) * 1e3, pre + "insert_us": ph.get("insert", 0.0) * 1e3,
 		pre + "net_us": ph.get("net", 0.0) * 1e3, pre + "push_us": ph.get("push", 0.0) * 1e3,
