@@ -1159,7 +1159,9 @@ __device__ __forceinline__ const u32x4 *shard_offer(const uint8_t *buf, int K, c
 	return reinterpret_cast<const u32x4 *>(buf + (size_t)peer * shard_block_bytes(K) + 32 + (size_t)K * 32 + (size_t)pos * 16);
 }
 
-// phase 0: evaluate (read all of G first) and elect the last hit per parent; phase 1: apply; phase 2: clear the marks
+// phase 0: evaluate (read all of G first) and elect the last hit per parent; phase 1: the elected offer applies itself and clears the
+// parent's mark (every marked parent has exactly one elected offer, and a mark is only ever set by a hit: nothing else needs clearing --
+// rounds 2-4 cleared in a third launch)
 __global__ void k_shard_offers_in(AstarDev d, const uint8_t *recv, int phase)
 {
 	__shared__ int s_pref[SHARD_MAX_WORLD + 1];
@@ -1171,13 +1173,12 @@ __global__ void k_shard_offers_in(AstarDev d, const uint8_t *recv, int phase)
 		const bool h = (int32_t)r.y < d.G[r.x];
 		d.hit[o] = h;
 		if (h) atomicMin(&d.mark[r.x], ~(uint32_t)o);
-	} else if (phase == 1) {
-		if (!d.hit[o] || d.mark[r.x] != ~(uint32_t)o) return;
+	} else {
+		if (!d.hit[o] || __hip_atomic_load(&d.mark[r.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ~(uint32_t)o) return;
 		d.G[r.x] = (int32_t)r.y;
 		d.parents[r.x] = (int32_t)r.z;
 		d.prank[r.x] = (uint8_t)(r.w & 0xFFu);
 		d.pact[r.x] = (uint8_t)((r.w >> 8) & 0xFFu);
-	} else {
 		d.mark[r.x] = NO_MARK;
 	}
 }
@@ -1848,7 +1849,7 @@ int rk_astar_shard_insert(rk_astar_t *h, const void *d_recv, void *d_send, void 
 	const AstarDev &d = h->d;
 	const uint8_t *recv = (const uint8_t *)d_recv;
 	const unsigned gK = blocks((size_t)d.K);
-	for (int phase = 0; phase < 3; phase++)
+	for (int phase = 0; phase < 2; phase++)
 		hipLaunchKernelGGL(k_shard_offers_in, dim3(gK), dim3(256), 0, st, d, recv, phase);
 	hipLaunchKernelGGL(k_shard_lookup, dim3(gK), dim3(256), 0, st, d, recv);
 	launch_append<true>(h, recv, d_onehot, out_dtype, st);
@@ -1909,7 +1910,7 @@ int rk_astar_shard_flush(rk_astar_t *h, const void *d_recv, void *stream)
 	if (!h || !h->ready || !d_recv) return fail(RK_EINVAL, "rk_astar_shard_flush: bad argument");
 	hipStream_t st = (hipStream_t)stream;
 	const unsigned gK = blocks((size_t)h->d.K);
-	for (int phase = 0; phase < 3; phase++)
+	for (int phase = 0; phase < 2; phase++)
 		hipLaunchKernelGGL(k_shard_offers_in, dim3(gK), dim3(256), 0, st, h->d, (const uint8_t *)d_recv, phase);
 	RK_HIP(hipGetLastError());
 	return RK_OK;
