@@ -879,6 +879,78 @@ void k_apply_sequences(const uint8_t *__restrict__ actions, int moves, int games
 	if (worst >= 12u) atomicOr(&g_bad_actions, 1u);                      // never taken on valid input
 }
 
+// A move is a permutation of the 24 corner codes and of the 24 edge codes: a 48-byte table, twelve dwords.  Moves COMPOSE --
+// (B after A)[v] = B[A[v]], four codes per lut4 -- so the composition of consecutive moves is an inclusive prefix scan over lanes that hold
+// one move each: after the scan lane l holds the composition of the moves of lanes l0 ... l, l0 = the first lane of its segment (`seg` =
+// the lane's position inside its segment of length `len`: a game's rows, or a 64-move chunk of one long game).  log2(len) steps of twelve
+// cross-lane dwords and twelve lut4 each, all in registers.  All 64 lanes call it (ds_bpermute).
+__device__ __forceinline__ void scan_moves(uint32_t (&X)[12], int lane, int seg, int len)
+{
+	for (int off = 1; off < len; off <<= 1) {
+		uint32_t Y[12];
+		const int src = (lane - off) & 63;
+		#pragma unroll
+		for (int j = 0; j < 12; j++) Y[j] = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)X[j]);
+		if (seg >= off) {                                                // the lane `off` back belongs to the SAME segment
+			uint32_t Z[12];
+			#pragma unroll
+			for (int j = 0; j < 6; j++) { Z[j] = lut4(Y[j], X); Z[6 + j] = lut4(Y[6 + j], X + 6); }   // the earlier moves first, then mine
+			#pragma unroll
+			for (int j = 0; j < 12; j++) X[j] = Z[j];
+		}
+	}
+}
+__device__ __forceinline__ void identity_moves(uint32_t (&X)[12])
+{
+	#pragma unroll
+	for (int j = 0; j < 6; j++) X[j] = X[6 + j] = 0x03020100u + 0x04040404u * (uint32_t)j;
+}
+
+// The scramblers for FEW games (one `scramble(depth)` of the evaluation loop, depth 100-999; `sequence_scrambler` of a few thousand
+// games): a WAVE per game, lane l holds move d0 + l of a 64-move chunk, the chunk's states come out of one scan_moves, the last one
+// carries into the next chunk.  A game of 999 moves is 16 chunks of six scan steps instead of 999 dependent moves of one lane
+// (k_apply_sequences: that loop is right when there are enough games to fill the chip with lanes -- bench.py's 1 M walks).
+__global__ __launch_bounds__(256)
+void k_apply_sequences_scan(const uint8_t *__restrict__ actions, int moves, int games, int with_solved, int only_last, uint32_t *__restrict__ out)
+{
+	__shared__ u32x4 s_act[36];
+	stage_action_tables(s_act, threadIdx.x);
+	__syncthreads();
+	const int lane = threadIdx.x & 63, g = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (g >= games) return;                                                 // (whole waves)
+	uint32_t s[5] = {SOLVED_DW[0], SOLVED_DW[1], SOLVED_DW[2], SOLVED_DW[3], SOLVED_DW[4]};
+	const int rows = moves + (with_solved ? 1 : 0);
+	uint32_t *o = out + (size_t)g * (only_last ? 1 : rows) * STATE_DWORDS;
+	if (!only_last && with_solved) {
+		if (lane < 5) o[lane] = SOLVED_DW[lane];
+		o += STATE_DWORDS;
+	}
+	uint32_t worst = 0;
+	for (int d0 = 0; d0 < moves; d0 += 64) {
+		const int n = moves - d0 < 64 ? moves - d0 : 64;                     // moves of this chunk
+		uint32_t X[12];
+		if (lane < n) {
+			uint32_t a = actions[(size_t)(d0 + lane) * games + g];
+			worst = a > worst ? a : worst;
+			a = a < 12u ? a : 0u;
+			load_action_table(s_act, a, X);
+		} else {
+			identity_moves(X);
+		}
+		scan_moves(X, lane, lane, n);
+		uint32_t st[5] = {s[0], s[1], s[2], s[3], s[4]};
+		move5(st, X);                                                        // the state after move d0 + lane
+		if (!only_last && lane < n) {
+			#pragma unroll
+			for (int j = 0; j < 5; j++) o[(size_t)(d0 + lane) * STATE_DWORDS + j] = st[j];
+		}
+		#pragma unroll
+		for (int j = 0; j < 5; j++) s[j] = (uint32_t)__builtin_amdgcn_readlane((int)st[j], n - 1);   // carries into the next chunk
+	}
+	if (only_last && lane < 5) o[lane] = s[lane];
+	if (worst >= 12u) atomicOr(&g_bad_actions, 1u);                          // never taken on valid input
+}
+
 // ================================================================================================================
 // rollout_fanout: the cube part of one ADI rollout in ONE launch                                   train.py:277-292
 //   states of `games` random walks along their `rows` steps (cube.py:218-232, game-major)  +  is each of them solved (train.py:281)
@@ -918,11 +990,9 @@ void k_rollout_fanout(const uint8_t *__restrict__ actions, int moves, int games,
 	uint32_t par[5] = {SOLVED_DW[0], SOLVED_DW[1], SOLVED_DW[2], SOLVED_DW[3], SOLVED_DW[4]};
 	uint32_t worst = 0;
 	if (scan) {
-		// A move is a permutation of the 24 corner codes and of the 24 edge codes: a 48-byte table, twelve dwords.  Moves COMPOSE --
-		// (B after A)[v] = B[A[v]], four codes per lut4 -- so the state of row r is the composition of the game's first moves applied
-		// to the solved state, and the compositions of all rows of a game are an inclusive prefix scan over its lanes: log2(rows)
-		// steps of twelve cross-lane dwords and twelve lut4 each, in registers, instead of up to `rows` dependent moves per wave
-		// (thirty LDS round trips + v_perm chains: the walk was most of this kernel's 28 us; rocprofv3, profiles/r05_adi_cube_kernels.csv).
+		// The state of row r is the composition of the game's first moves applied to the solved state, and the compositions of all rows
+		// of a game are ONE scan_moves over its lanes, instead of up to `rows` dependent moves per wave (thirty LDS round trips + v_perm
+		// chains: the walk was most of this kernel's 28 us; rocprofv3, profiles/r05_adi_cube_kernels.csv).
 		uint32_t X[12];
 		const int mv = with_solved ? r - 1 : r;                                // the move that leads to row r (none for the solved row)
 		if (mv >= 0) {
@@ -931,22 +1001,9 @@ void k_rollout_fanout(const uint8_t *__restrict__ actions, int moves, int games,
 			a = a < 12u ? a : 0u;
 			load_action_table(s_act, a, X);
 		} else {
-			#pragma unroll
-			for (int j = 0; j < 6; j++) X[j] = X[6 + j] = 0x03020100u + 0x04040404u * (uint32_t)j;   // the identity table
+			identity_moves(X);
 		}
-		for (int off = 1; off < rows; off <<= 1) {
-			uint32_t Y[12];
-			const int src = (lane - off) & 63;
-			#pragma unroll
-			for (int j = 0; j < 12; j++) Y[j] = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)X[j]);
-			if (r >= off) {                                                  // the lane `off` rows back is a row of the SAME game
-				uint32_t Z[12];
-				#pragma unroll
-				for (int j = 0; j < 6; j++) { Z[j] = lut4(Y[j], X); Z[6 + j] = lut4(Y[6 + j], X + 6); }   // the earlier moves first, then mine
-				#pragma unroll
-				for (int j = 0; j < 12; j++) X[j] = Z[j];
-			}
-		}
+		scan_moves(X, lane, r, rows);
 		move5(par, X);
 	} else {
 		const int todo = with_solved ? r : r + 1;
@@ -1791,6 +1848,11 @@ void launch_rollout_fanout(const uint8_t *actions, int moves, int games, int wit
 
 void launch_apply_sequences(const uint8_t *actions, int moves, int games, int with_solved, int only_last, int8_t *out, hipStream_t st)
 {
+	// few games: a wave per game and a scan over its moves; many games (enough lanes to fill the chip): a lane per game walking its moves
+	if (games <= 16384 && moves > 1) {
+		hipLaunchKernelGGL(k_apply_sequences_scan, dim3(grid_for((size_t)games, 4, 1u << 22)), dim3(256), 0, st, actions, moves, games, with_solved, only_last, (uint32_t *)out);
+		return;
+	}
 	const unsigned grid = grid_for((size_t)games, 256, 1u << 22);
 	hipLaunchKernelGGL(k_apply_sequences, dim3(grid), dim3(256), 0, st, actions, moves, games, with_solved, only_last, (uint32_t *)out);
 }

@@ -953,3 +953,30 @@ def test_rollout_fanout_is_walk_plus_goal_test_plus_fanout(games, depth, with_so
 	s3 = cube.device.apply_sequences(acts, with_solved, False)
 	ch3, fl3 = cube.device.expand12(s3)
 	assert torch.equal(s3, states) and torch.equal(ch3, children) and torch.equal(fl3, cfl) and torch.equal(cube.device.multi_is_solved(s3), sfl)
+
+
+@pytest.mark.parametrize("games,depth,with_solved,only_last", [(1, 999, False, True), (1, 100, False, False), (3, 64, True, False), (5, 65, True, False),
+                                                               (7, 129, False, False), (300, 2, True, False), (16384, 3, False, True), (16385, 3, False, True),
+                                                               (2, 64, False, True), (1, 2, True, True)])
+def test_scramblers_as_scans_over_moves(games, depth, with_solved, only_last):
+	"""Few games: a wave per game, the moves of a 64-move chunk composed by a prefix scan over their permutation tables, the last state
+	carried into the next chunk (k_apply_sequences_scan) -- deep single scrambles (the evaluation loop's depth 100-999), chunk boundaries
+	(64, 65, 129 moves), the solved row in front, both sides of the switch to the lane-per-game walk (16 384 / 16 385 games): every
+	row equals the oracle's walk on the same draws."""
+	rng = np.random.RandomState(31 * games + depth)
+	faces, dirs = rng.randint(0, 6, (depth, games)), rng.randint(0, 2, (depth, games))
+	acts = dev((2 * faces + (1 - dirs)).astype(np.uint8))
+	got = cube.device.apply_sequences(acts, with_solved, only_last).cpu().numpy()
+	cur = orc.repeat_state(orc.SOLVED, games)
+	seq = [cur] if with_solved else []
+	for d in range(depth - int(with_solved)):
+		cur = c_oracle.multi_rotate(cur, (2 * faces[d] + (1 - dirs[d])).astype(np.uint8), threads=4)
+		seq.append(cur)
+	want = seq[-1] if only_last else np.stack(seq, axis=1).reshape(games * depth, 20)
+	assert np.array_equal(got, want)
+	if games == 1 and only_last:                                             # ... and through the drop-in: scramble(depth) on the reference's draws
+		np.random.seed(depth)
+		s, f, dr = cube.scramble(depth)
+		np.random.seed(depth)
+		s_ref, _, _ = orc.scramble(depth)
+		assert np.array_equal(s, s_ref)
