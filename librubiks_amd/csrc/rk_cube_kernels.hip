@@ -926,11 +926,14 @@ void k_apply_sequences_scan(const uint8_t *__restrict__ actions, int moves, int 
 		o += STATE_DWORDS;
 	}
 	uint32_t worst = 0;
+	uint32_t a_next = lane < moves ? (uint32_t)actions[(size_t)lane * games + g] : 0xFFu;
 	for (int d0 = 0; d0 < moves; d0 += 64) {
 		const int n = moves - d0 < 64 ? moves - d0 : 64;                     // moves of this chunk
+		uint32_t a = a_next;
+		// the next chunk's action byte is requested before this chunk is scanned: its latency hides behind six scan steps
+		a_next = d0 + 64 + lane < moves ? (uint32_t)actions[(size_t)(d0 + 64 + lane) * games + g] : 0xFFu;
 		uint32_t X[12];
 		if (lane < n) {
-			uint32_t a = actions[(size_t)(d0 + lane) * games + g];
 			worst = a > worst ? a : worst;
 			a = a < 12u ? a : 0u;
 			load_action_table(s_act, a, X);
@@ -1848,8 +1851,11 @@ void launch_rollout_fanout(const uint8_t *actions, int moves, int games, int wit
 
 void launch_apply_sequences(const uint8_t *actions, int moves, int games, int with_solved, int only_last, int8_t *out, hipStream_t st)
 {
-	// few games: a wave per game and a scan over its moves; many games (enough lanes to fill the chip): a lane per game walking its moves
-	if (games <= 16384 && moves > 1) {
+	// FEW games and more than a handful of moves: a wave per game and a scan over its moves -- the scan does more arithmetic (log2(64) x
+	// twelve lut4 per move where a walking lane does five) to shorten the dependent chain from `moves` steps to six per 64 moves, which
+	// pays while the waves do not compete for the SIMDs: 1 x 999 moves 44 us against about 450, 96 x 100 12 us against 45; at 7 500 x 30
+	// the walk's 14 us beat the scan's 41 (rocprofv3, round 5).  Many games: a lane per game walking its moves.
+	if (games <= 1024 && moves >= 8) {
 		hipLaunchKernelGGL(k_apply_sequences_scan, dim3(grid_for((size_t)games, 4, 1u << 22)), dim3(256), 0, st, actions, moves, games, with_solved, only_last, (uint32_t *)out);
 		return;
 	}

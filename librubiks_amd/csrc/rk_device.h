@@ -50,8 +50,12 @@ __device__ __forceinline__ uint32_t lut4(uint32_t x, const uint32_t t[6])
 	const uint32_t r0 = bperm(t[1], t[0], sel);
 	const uint32_t r1 = bperm(t[3], t[2], sel);
 	const uint32_t r2 = bperm(t[5], t[4], sel);
-	const uint32_t m1 = ((x >> 3) & 0x01010101u) * 0xFFu;
-	const uint32_t m2 = ((x >> 4) & 0x01010101u) * 0xFFu;
+	// per-byte masks 0x00 / 0xFF from bit 3 / bit 4 of every code, by v_perm_b32's constant selectors (a selector byte of 12 yields 0x00,
+	// 13 yields 0xFF): one full-rate instruction.  As `b * 0xFF` they were v_mul_lo_u32, a quarter-rate instruction, and the two of them
+	// a third of lut4's cycles (seen in the ISA of the round-5 scan kernels, where lut4 is the whole inner loop; the compiler turns
+	// `(b << 8) - b` back into the multiply).
+	const uint32_t m1 = bperm(0u, 0u, ((x >> 3) & 0x01010101u) | 0x0C0C0C0Cu);
+	const uint32_t m2 = bperm(0u, 0u, ((x >> 4) & 0x01010101u) | 0x0C0C0C0Cu);
 	const uint32_t r = (r1 & m1) | (r0 & ~m1);
 	return (r2 & m2) | (r & ~m2);
 }

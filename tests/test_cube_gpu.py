@@ -956,12 +956,12 @@ def test_rollout_fanout_is_walk_plus_goal_test_plus_fanout(games, depth, with_so
 
 
 @pytest.mark.parametrize("games,depth,with_solved,only_last", [(1, 999, False, True), (1, 100, False, False), (3, 64, True, False), (5, 65, True, False),
-                                                               (7, 129, False, False), (300, 2, True, False), (16384, 3, False, True), (16385, 3, False, True),
-                                                               (2, 64, False, True), (1, 2, True, True)])
+                                                               (7, 129, False, False), (300, 2, True, False), (1024, 9, False, True), (1025, 9, False, True), (1024, 8, True, False),
+                                                               (2, 64, False, True), (1, 2, True, True), (16, 7, False, False), (4, 200, True, True)])
 def test_scramblers_as_scans_over_moves(games, depth, with_solved, only_last):
 	"""Few games: a wave per game, the moves of a 64-move chunk composed by a prefix scan over their permutation tables, the last state
 	carried into the next chunk (k_apply_sequences_scan) -- deep single scrambles (the evaluation loop's depth 100-999), chunk boundaries
-	(64, 65, 129 moves), the solved row in front, both sides of the switch to the lane-per-game walk (16 384 / 16 385 games): every
+	(64, 65, 129 moves), the solved row in front, both sides of the switch to the lane-per-game walk (1 024 / 1 025 games, 7 / 8 moves): every
 	row equals the oracle's walk on the same draws."""
 	rng = np.random.RandomState(31 * games + depth)
 	faces, dirs = rng.randint(0, 6, (depth, games)), rng.randint(0, 2, (depth, games))
