@@ -68,6 +68,24 @@ def case_cube20(rng):
 		for dt in (torch.float32, torch.bfloat16):
 			got = cube.device.as_oh(view, dtype=dt)
 			assert (got.float().cpu().numpy() == c_oracle.as_oh(host)).all(), ("as_oh", str(dt), what)
+	# round 5: the walks (lane per game / wave per game with a scan over the moves) and the rollout's walks + goal tests + fan-out in one launch
+	games, rows = int(rng.choice([1, 2, 5, 63, 700, 1024, 1025, 3000])), int(rng.choice([1, 2, 7, 8, 30, 31, 64, 65, 130]))
+	with_solved = bool(rng.rand() < 0.5)
+	if games * rows <= 200_000:
+		acts = rng.randint(0, 12, (rows, games)).astype(np.uint8)
+		cur = orc.repeat_state(orc.SOLVED, games)
+		seq = [cur] if with_solved else []
+		for d in range(rows - int(with_solved)):
+			cur = c_oracle.multi_rotate(cur, acts[d], threads=4)
+			seq.append(cur)
+		want = np.stack(seq, axis=1).reshape(games * rows, 20)
+		w2 = dict(what, games=games, rows=rows, with_solved=with_solved)
+		assert (cube.device.apply_sequences(dev(acts), with_solved, False).cpu().numpy() == want).all(), ("apply_sequences", w2)
+		assert (cube.device.apply_sequences(dev(acts), with_solved, True).cpu().numpy() == seq[-1]).all(), ("apply_sequences last", w2)
+		st2, sfl, ch2, cfl = cube.device.rollout_fanout(dev(acts), with_solved)
+		rch, rfl = c_oracle.expand12(want, threads=8)
+		assert (st2.cpu().numpy() == want).all() and (sfl.cpu().numpy().astype(bool) == orc.multi_is_solved(want)).all(), ("rollout states", w2)
+		assert (ch2.cpu().numpy() == rch).all() and (cfl.cpu().numpy() == rfl).all(), ("rollout children", w2)
 	return what
 
 
