@@ -139,13 +139,20 @@ __device__ __forceinline__ int scan_lookback(unsigned long long *words, int b, i
 __device__ __forceinline__ int scan_lookback_classes(unsigned long long *words, int nblocks, int b, int W, uint32_t cls, uint32_t epoch,
                                                     int *s_wave /* [4] */, int *s_tot, int *s_base)
 {
+	// ranks inside this workgroup for all classes with ONE barrier: per wave a ballot per class (no barrier), the waves' counts in LDS
+	__shared__ int s_cnt[4 * 64];
+	const int lane0 = threadIdx.x & 63, wv0 = threadIdx.x >> 6;
 	int my = 0;
 	for (int w = 0; w < W; w++) {
-		int total;
-		const int r = block_rank256(cls == (uint32_t)w, s_wave, &total);
-		if (cls == (uint32_t)w) my = r;
-		if (threadIdx.x == 0) s_tot[w] = total;
+		const unsigned long long bal = __ballot(cls == (uint32_t)w);
+		if (lane0 == 0) s_cnt[wv0 * 64 + w] = __popcll(bal);
+		if (cls == (uint32_t)w) my = __popcll(bal & ((1ull << lane0) - 1ull));
 	}
+	__syncthreads();
+	if (cls < (uint32_t)W)
+		for (int v = 0; v < wv0; v++) my += s_cnt[v * 64 + cls];
+	if ((int)threadIdx.x < W) s_tot[threadIdx.x] = s_cnt[threadIdx.x] + s_cnt[64 + threadIdx.x] + s_cnt[128 + threadIdx.x] + s_cnt[192 + threadIdx.x];
+	(void)s_wave;
 	__syncthreads();
 	if ((int)threadIdx.x < W)
 		__hip_atomic_store(&words[(size_t)threadIdx.x * nblocks + b], ((unsigned long long)epoch << 32) | (uint32_t)s_tot[threadIdx.x],
