@@ -1035,6 +1035,7 @@ __global__ __launch_bounds__(256)
 void k_shard_decide(AstarDev d, const double *gathered, double time_limit, double max_states, long long *decision)
 {
 	__shared__ int s_mine, s_stop, s_winner, s_last;
+	__shared__ int s_grank[256];
 	__shared__ double s_total, s_maxerr;
 	const int tid = threadIdx.x, W = d.world, N = d.N, stride = 8 + N;
 	if (tid == 0) {
@@ -1063,26 +1064,28 @@ void k_shard_decide(AstarDev d, const double *gathered, double time_limit, doubl
 	}
 	__syncthreads();
 	if (s_stop == STOP_NO) {
-		// my candidates' global ranks by (cost, rank, position); the n globally cheapest are popped
+		// my candidates' global ranks by (cost, rank, position); the n globally cheapest are popped.  One thread per (candidate, rank)
+		// pair: the W - 1 binary searches of a candidate run side by side and meet in an LDS counter, so the dependent chain is ONE
+		// search (ten loads), not W - 1 of them back to back (seven searches in a row were 20 us of the select phase at world 8).
 		const double *mine = gathered + (size_t)d.rank * stride + 8;
 		const int n_mine = (int)gathered[(size_t)d.rank * stride + 4];
-		const int i = blockIdx.x * blockDim.x + tid;
-		bool in = false;
-		if (i < n_mine) {
+		const int cpb = (int)blockDim.x / W;                                // candidates per workgroup
+		const int li = tid / W, r = tid - li * W;                            // local candidate, the rank whose list this thread searches
+		const int i = blockIdx.x * cpb + li;
+		if (tid < cpb) s_grank[tid] = 0;
+		__syncthreads();
+		if (li < cpb && i < n_mine && r != d.rank) {
 			const double x = mine[i];
-			int grank = i;
-			for (int r = 0; r < W; r++) {
-				if (r == d.rank) continue;
-				const double *o = gathered + (size_t)r * stride + 8;
-				int lo = 0, hi = (int)gathered[(size_t)r * stride + 4];
-				while (lo < hi) {                                           // ranks below mine win ties, ranks above lose them
-					const int mid = (lo + hi) >> 1;
-					if (r < d.rank ? o[mid] <= x : o[mid] < x) lo = mid + 1; else hi = mid;
-				}
-				grank += lo;
+			const double *o = gathered + (size_t)r * stride + 8;
+			int lo = 0, hi = (int)gathered[(size_t)r * stride + 4];
+			while (lo < hi) {                                               // ranks below mine win ties, ranks above lose them
+				const int mid = (lo + hi) >> 1;
+				if (r < d.rank ? o[mid] <= x : o[mid] < x) lo = mid + 1; else hi = mid;
 			}
-			in = grank < N;
+			if (lo) atomicAdd(&s_grank[li], lo);
 		}
+		__syncthreads();
+		const bool in = tid < cpb && blockIdx.x * cpb + tid < n_mine && blockIdx.x * cpb + tid + s_grank[tid] < N;
 		const int cnt = __popcll(__ballot(in));
 		if ((tid & 63) == 0 && cnt) atomicAdd(&s_mine, cnt);
 	}
@@ -1824,7 +1827,7 @@ int rk_astar_shard_select(rk_astar_t *h, const void *d_gathered, double time_lim
 	if (h->pending) return fail(RK_ESTATE, "rk_astar_shard_select: previous iteration not finished");
 	hipStream_t st = (hipStream_t)stream;
 	const AstarDev &d = h->d;
-	hipLaunchKernelGGL(k_shard_decide, dim3(blocks((size_t)d.N)), dim3(256), 0, st, d, (const double *)d_gathered, time_limit, max_states, h->decision);
+	hipLaunchKernelGGL(k_shard_decide, dim3(blocks((size_t)d.N, 256 / d.world)), dim3(256), 0, st, d, (const double *)d_gathered, time_limit, max_states, h->decision);
 	hipLaunchKernelGGL(k_shard_expand, dim3(blocks((size_t)d.K, ASCAN)), dim3(ASCAN), 0, st, d, (uint8_t *)d_send);
 	RK_HIP(hipGetLastError());
 	return RK_OK;
