@@ -414,9 +414,9 @@ def _nccl_world1(rank, port, out_path, case):
 	"""One rank, nccl backend, collectives forced: the RCCL transport (device tensors, variable-size all_to_all_single,
 	all_gather_into_tensor, broadcast) carries a whole search."""
 	import torch.distributed as dist
-	os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
 	torch.cuda.set_device(0)
-	dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+	# one rank: a file store needs no port (a port found free by the parent can be taken again before the child binds it)
+	dist.init_process_group("nccl", init_method=f"file://{out_path}.rendezvous", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 	try:
 		seed, depth, lam, n, budget = case
 		np.random.seed(seed)
@@ -584,8 +584,7 @@ def _captured_collectives_world1(rank, port, out_path, tags, how):
 	torch.cuda.set_device(0)
 	t = dict(np.load(os.path.join(GOLDEN, "astar_trace.npz")))
 	if how == "nccl":
-		os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-		dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+		dist.init_process_group("nccl", init_method=f"file://{out_path}.rendezvous", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 	out = {}
 	try:
 		for tag in tags:
