@@ -76,7 +76,7 @@ def _max_over_ranks(seconds: float, dist, backend) -> float:
 
 
 def sharded_astar_leg(dist, backend: str, world: int, rank: int, *, weak: bool, games: int = 3, depth: int = DEPTH, lam: float = LAMBDA,
-                      expansions: int = STRONG_N, budget: int = STRONG_BUDGET, poll: int = 4, time_limit: float = 30.0, net_kind: str = None,
+                      expansions: int = STRONG_N, budget: int = STRONG_BUDGET, poll: int = 8, time_limit: float = 30.0, net_kind: str = None,
                       prefix: str = None, seeds=None) -> dict:
 	"""One scaling mode of configs[4].  `expansions` / `budget` are the world-1 figures; weak scaling multiplies both by `world`."""
 	from librubiks_amd import cube
