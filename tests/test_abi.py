@@ -120,6 +120,15 @@ def test_error_reporting_without_fallback():
 	assert lib.rk_expand12(0, None, None, None, None, 5, None) == -1
 	assert lib.rk_expand12(0, 4, 8, None, None, 5, None) == -1 and b"16-byte" in lib.rk_last_error()
 	assert lib.rk_as_oh(0, 4, 16, 9, 1, None) == -1
+	# round-5 entries: arguments are validated before anything touches a device
+	assert lib.rk_rollout_fanout(0, None, 30, 10, 1, None, None, None, None, None, None) == -1 and b"null pointer" in lib.rk_last_error()
+	assert lib.rk_rollout_fanout(1, None, 30, 10, 1, None, None, None, None, None, None) == -1 and b"20-byte" in lib.rk_last_error()
+	assert lib.rk_rollout_fanout(0, None, 30, 0, 1, None, None, None, None, None, None) == 0                 # no games: nothing to do
+	assert lib.rk_rollout_fanout(0, 16, 30, 10, 1, 4, None, 8, 4, None, None) == -1 and b"aligned" in lib.rk_last_error()
+	assert lib.rk_astar_shard_push_rows(None, None, 5, None, None, None) < 0
+	assert lib.rk_mcts_backup_select_logits_range(None, 0, 1, None, 12, None, 1, 0, None) < 0
+	assert lib.rk_face_definitions(None) == -1
+	assert lib.rk_stream_register(None) == 0 and lib.rk_stream_forget(None) == 0 and lib.rk_get_pacing(None, None, None) == 0
 	if not torch.cuda.is_available():
 		assert lib.rk_init(0) == -2          # no device: an error, never a CPU path
 		with pytest.raises(_ffi.RubiksHipError):
