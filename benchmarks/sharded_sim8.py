@@ -82,6 +82,7 @@ def main():
 	ap.add_argument("--expansions", type=int, default=700)
 	ap.add_argument("--budget", type=int, default=2_000_000)
 	ap.add_argument("--weak", action="store_true")
+	ap.add_argument("--skip-world1", action="store_true", help="only the world-W run (for a kernel profile of it)")
 	a = ap.parse_args()
 	_ffi.check(_ffi.lib().rk_init(0))
 	empty = []
@@ -92,7 +93,7 @@ def main():
 	torch.cuda.synchronize()
 	pair_us = float(np.median([x.elapsed_time(y) for x, y in empty])) * 1e3
 	rows = []
-	for world in sorted({1, a.world}):
+	for world in ([a.world] if a.skip_world1 else sorted({1, a.world})):
 		N = a.expansions * (world if a.weak else 1)
 		rows.append(run(world, N, a.budget * (world if a.weak else 1), 20, 0.16, 0))
 	print(json.dumps({"bench": "sharded_sim", "mode": "weak" if a.weak else "strong", "net": "exact stub (one kernel)", "event_pair_overhead_us": pair_us,
