@@ -350,10 +350,20 @@ def main():
 	backend = os.environ.get("RK_BENCH_BACKEND", "nccl")
 	device_index = local_rank % max(1, torch.cuda.device_count())
 	torch.cuda.set_device(device_index)
+	# RK_BENCH_FORCE_MULTI=1 with --gpus 1: a process group of ONE rank over RCCL, and the multi-GPU legs with their collectives forced --
+	# the N > 1 code path of this file (device-buffer collectives, the captured sharded iteration, the final all-gather of the
+	# partitioned MCTS) rehearsed on a one-GPU box, where two nccl ranks cannot share the GPU.  n_gpus stays 1.
+	force_multi = world == 1 and os.environ.get("RK_BENCH_FORCE_MULTI", "") == "1"
+	if force_multi:
+		backend = "nccl"
 	dist = None
-	if world > 1:
+	if world > 1 or force_multi:
 		import torch.distributed as dist
-		if backend == "nccl":
+		if force_multi:
+			import tempfile
+			store = os.path.join(tempfile.mkdtemp(prefix="rk_bench_"), "rendezvous")
+			dist.init_process_group("nccl", init_method=f"file://{store}", rank=0, world_size=1, device_id=torch.device("cuda", device_index))
+		elif backend == "nccl":
 			dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
 		else:
 			dist.init_process_group(backend)
@@ -455,7 +465,7 @@ def main():
 	paced = PACED and tau_c.value > 0
 	kernel = KERNEL_PACED if paced else KERNEL_RING
 
-	if world > 1:
+	if world > 1 or force_multi:
 		del ins, outs
 		torch.cuda.empty_cache()
 
@@ -500,7 +510,7 @@ def main():
 			# flat copies: the driver's parser keeps flat extra keys
 			line["frac_ring_same_box"] = line["roofline"]["frac_ring_same_box"]
 			line["paced_over_ring_same_box"] = kernel_ms_ring / kernel_ms
-		if world == 1 and not args.no_search_legs:
+		if world == 1 and not force_multi and not args.no_search_legs:
 			del ins, outs                                     # 1.6 GB back to the allocator before the pools of the search legs
 			torch.cuda.empty_cache()
 			try:
@@ -519,7 +529,7 @@ def main():
 	# headline's line, under a watchdog: should a leg hang (a collective that never completes on hardware the build never saw), every
 	# rank leaves after RK_BENCH_LEGS_TIMEOUT seconds and rank 0 still prints the line with what was finished -- the fan-out number of
 	# the scaling run is never lost to a leg.
-	if world > 1:
+	if world > 1 or force_multi:
 		import threading
 		from benchmarks import multi_gpu
 		multi, finished = {}, threading.Event()
@@ -544,7 +554,7 @@ def main():
 		if not args.no_search_legs:
 			multi_gpu.legs(dist, backend, world, rank, games=args.search_games, sims=args.mcts_sims or 4096, mcts=args.mcts_sims > 0,
 			               budget=args.search_budget or multi_gpu.STRONG_BUDGET, expansions=args.search_expansions or multi_gpu.STRONG_N,
-			               depth=args.search_depth or multi_gpu.DEPTH, out=multi)
+			               depth=args.search_depth or multi_gpu.DEPTH, out=multi, force_collectives=force_multi)
 		finished.set()
 		watchdog.cancel()
 		if rank == 0:

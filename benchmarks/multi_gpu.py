@@ -77,7 +77,7 @@ def _max_over_ranks(seconds: float, dist, backend) -> float:
 
 def sharded_astar_leg(dist, backend: str, world: int, rank: int, *, weak: bool, games: int = 3, depth: int = DEPTH, lam: float = LAMBDA,
                       expansions: int = STRONG_N, budget: int = STRONG_BUDGET, poll: int = 8, time_limit: float = 30.0, net_kind: str = None,
-                      prefix: str = None, seeds=None) -> dict:
+                      prefix: str = None, seeds=None, force_collectives: bool = False) -> dict:
 	"""One scaling mode of configs[4].  `expansions` / `budget` are the world-1 figures; weak scaling multiplies both by `world`."""
 	from librubiks_amd import cube
 	from librubiks_amd.solving.sharded import ShardedAStar
@@ -95,7 +95,8 @@ def sharded_astar_leg(dist, backend: str, world: int, rank: int, *, weak: bool, 
 
 	# the iteration replayed as one hipGraph wherever its collectives are on the device (RCCL) or short-circuit (world 1); RK_SHARD_GRAPH=0/1 overrides
 	want_graph = os.environ.get("RK_SHARD_GRAPH", "1" if (world == 1 or backend == "nccl") else "0") != "0"
-	agent = ShardedAStar(net, lam, N, capacity=cap, poll=poll, fused_first_layer=fused, use_hipgraph=want_graph)
+	want_graph = want_graph and (backend == "nccl" or not force_collectives)            # (host-staged collectives cannot be captured)
+	agent = ShardedAStar(net, lam, N, capacity=cap, poll=poll, fused_first_layer=fused, use_hipgraph=want_graph, force_collectives=force_collectives)
 	np.random.seed(12345)
 	agent.search(cube.scramble(depth, True)[0], time_limit=time_limit, max_states=min(total_budget, 30 * 12 * N))      # pools, GEMM selection, group warm-up
 	starts = []
@@ -171,7 +172,7 @@ def sharded_astar_leg(dist, backend: str, world: int, rank: int, *, weak: bool, 
 
 
 def partitioned_mcts_leg(dist, backend: str, world: int, rank: int, *, trees_per_rank: int = 256, sims: int = 4096, depth: int = 14, c: float = 0.6,
-                         net_kind: str = None) -> dict:
+                         net_kind: str = None, force_collectives: bool = False) -> dict:
 	"""configs[3], weak: every rank runs its own `trees_per_rank` trees (hipGraph-replayed step); one all-gather of results at the end."""
 	from librubiks_amd import cube
 	from librubiks_amd.solving.sharded import PartitionedMCTS
@@ -183,7 +184,7 @@ def partitioned_mcts_leg(dist, backend: str, world: int, rank: int, *, trees_per
 		starts.append(cube.scramble(depth, True)[0])
 	starts = np.array(starts)
 	kw = {"fused_first_layer": fused} if fused else {}
-	agent = PartitionedMCTS(net, c, trees, capacity=12 * sims + 64, max_path=4096, **kw)
+	agent = PartitionedMCTS(net, c, trees, capacity=12 * sims + 64, max_path=4096, force_collectives=force_collectives, **kw)
 	agent.search(starts, max_sims=16, use_graph=True, poll=8)                                       # pools, GEMM selection, first capture
 	torch.cuda.synchronize()
 	if dist is not None:
@@ -202,14 +203,14 @@ def partitioned_mcts_leg(dist, backend: str, world: int, rank: int, *, trees_per
 
 
 def legs(dist, backend: str, world: int, rank: int, *, games: int = 3, sims: int = 4096, trees_per_rank: int = 256, budget: int = STRONG_BUDGET,
-         expansions: int = STRONG_N, depth: int = DEPTH, mcts: bool = True, out: dict = None) -> dict:
+         expansions: int = STRONG_N, depth: int = DEPTH, mcts: bool = True, out: dict = None, force_collectives: bool = False) -> dict:
 	"""Everything `bench.py --gpus N` adds for N > 1.  A leg that fails says so in `<leg>_error` and the others still run -- but a rank
 	that raises inside a collective leaves its peers waiting, so errors are caught per leg on EVERY rank alike (the legs are
 	deterministic: what fails on one rank fails on all).  `out` is filled leg by leg, so a caller with a watchdog can report what was finished."""
 	out = {} if out is None else out
-	for name, fn in (("sharded", lambda: sharded_astar_leg(dist, backend, world, rank, weak=False, games=games, budget=budget, expansions=expansions, depth=depth)),
-	                 ("sharded_weak", lambda: sharded_astar_leg(dist, backend, world, rank, weak=True, games=games, budget=budget, expansions=expansions, depth=depth)),
-	                 ("pmcts", (lambda: partitioned_mcts_leg(dist, backend, world, rank, trees_per_rank=trees_per_rank, sims=sims)) if mcts else None)):
+	for name, fn in (("sharded", lambda: sharded_astar_leg(dist, backend, world, rank, weak=False, games=games, budget=budget, expansions=expansions, depth=depth, force_collectives=force_collectives)),
+	                 ("sharded_weak", lambda: sharded_astar_leg(dist, backend, world, rank, weak=True, games=games, budget=budget, expansions=expansions, depth=depth, force_collectives=force_collectives)),
+	                 ("pmcts", (lambda: partitioned_mcts_leg(dist, backend, world, rank, trees_per_rank=trees_per_rank, sims=sims, force_collectives=force_collectives)) if mcts else None)):
 		if fn is None:
 			continue
 		try:

@@ -438,9 +438,9 @@ class PartitionedMCTS:
 	start state alone (agents.py:415-645), whichever rank ran it.
 	"""
 
-	def __init__(self, net, c: float, n_trees: int, capacity: int = 50_000, max_path: int = None, group=None, **kw):
+	def __init__(self, net, c: float, n_trees: int, capacity: int = 50_000, max_path: int = None, group=None, force_collectives: bool = False, **kw):
 		from librubiks_amd.solving.agents import MCTSBatch
-		self.tr = Transport(group)
+		self.tr = Transport(group, force_collectives)       # force_collectives: run the final all-gather also with one rank (rehearsals on one GPU)
 		self.n_trees = int(n_trees)
 		self.mine = np.arange(self.tr.rank, self.n_trees, self.tr.world)
 		self.max_path = int(max_path or 4096)

@@ -102,3 +102,38 @@ def test_a_hanging_leg_does_not_lose_the_headline():
 	r = json.loads(lines[0])
 	assert r["n_gpus"] == 2 and r["value"] > 0 and r["verified_children"] == 48_000_000 and "roofline" in r
 	assert "did not finish within" in r["multi_gpu_legs_error"] and "sharded_weak_states_per_s" not in r
+
+
+def test_the_multi_gpu_code_path_over_rccl_with_one_rank():
+	"""Two nccl ranks cannot share the one GPU of the test box, so the N > 1 code path of bench.py -- device-buffer collectives, the
+	sharded iteration with its RCCL collectives inside the captured graph, the partitioned MCTS's final all-gather -- is rehearsed with
+	a process group of ONE rank and the collectives forced (RK_BENCH_FORCE_MULTI=1).  With the exact stub net the sharded leg's searches
+	are the single-engine oracle's: same iteration and state counts."""
+	import numpy as np
+	from oracle import cube_oracle as orc
+	from oracle.search_oracle import AStarOracle, StubNet
+	env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "RK_BENCH_BACKEND")}
+	env.update(RK_BENCH_FORCE_MULTI="1", RK_BENCH_SEARCH_NET="stub")
+	games, budget, N, depth = 2, 60_000, 100, 12
+	out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--search-games", str(games),
+	                      "--search-budget", str(budget), "--search-expansions", str(N), "--search-depth", str(depth), "--mcts-sims", "64"],
+	                     capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+	assert out.returncode == 0, out.stderr[-3000:]
+	lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+	assert len(lines) == 1
+	r = json.loads(lines[0])
+	assert r["n_gpus"] == 1 and r["verified_children"] == 48_000_000 and "astar_states_per_s" not in r       # the N = 1 legs give way to the multi-GPU ones
+	assert r["collective_backend"] == "nccl" and r["collective_world"] == 1 and r["rank_checksum"] == 1 and r["alltoall_verified_on_every_rank"] is True
+	assert r["collective_buffers"] == "device"
+	assert not [k for k in r if k.endswith("_error")], {k: r[k] for k in r if k.endswith("_error")}
+	assert r["sharded_hipgraph"] in ("replayed", "eager (faster on game 0)") and r["sharded_ms_per_iteration_game0_replayed"] > 0   # RCCL captured
+	assert r["sharded_collectives_seen"] > 0 and r["pmcts_tree_sims"] == 256 * 64
+	states = iters = 0
+	for g in range(games):
+		np.random.seed(g)
+		start, _, _ = orc.scramble(depth, True)
+		o = AStarOracle(StubNet(), 0.16, N)
+		o.search(start, budget)
+		states += len(o)
+		iters += o.iterations
+	assert (r["sharded_total_states"], r["sharded_iterations"]) == (states, iters) == (r["sharded_weak_total_states"], r["sharded_weak_iterations"])
