@@ -108,10 +108,11 @@ def test_the_multi_gpu_code_path_over_rccl_with_one_rank():
 	"""Two nccl ranks cannot share the one GPU of the test box, so the N > 1 code path of bench.py -- device-buffer collectives, the
 	sharded iteration with its RCCL collectives inside the captured graph, the partitioned MCTS's final all-gather -- is rehearsed with
 	a process group of ONE rank and the collectives forced (RK_BENCH_FORCE_MULTI=1).  With the exact stub net the sharded leg's searches
-	are the single-engine oracle's: same iteration and state counts."""
+	are the protocol oracle's at world 1 (= the reference's A*): same iteration and state counts."""
 	import numpy as np
 	from oracle import cube_oracle as orc
-	from oracle.search_oracle import AStarOracle, StubNet
+	from oracle.search_oracle import StubNet
+	from oracle.sharded_oracle import ShardedAStarOracle
 	env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "RK_BENCH_BACKEND")}
 	env.update(RK_BENCH_FORCE_MULTI="1", RK_BENCH_SEARCH_NET="stub")
 	games, budget, N, depth = 2, 60_000, 100, 12
@@ -132,8 +133,8 @@ def test_the_multi_gpu_code_path_over_rccl_with_one_rank():
 	for g in range(games):
 		np.random.seed(g)
 		start, _, _ = orc.scramble(depth, True)
-		o = AStarOracle(StubNet(), 0.16, N)
+		o = ShardedAStarOracle(StubNet(), 0.16, N, 1)                     # (= the reference's A* at world 1: tests/test_sharded_oracle_cpu.py)
 		o.search(start, budget)
-		states += len(o)
+		states += o.total_states
 		iters += o.iterations
 	assert (r["sharded_total_states"], r["sharded_iterations"]) == (states, iters) == (r["sharded_weak_total_states"], r["sharded_weak_iterations"])
