@@ -76,6 +76,10 @@ int rk_set_pacing(int mode);
  * microseconds per 1 Mi-parent launch of {ring form, 2.0, 2.1, 2.2, 2.4 ns}, zeros if nothing was measured.  Any pointer may be null. */
 int rk_calibrate_pacing(int force);
 int rk_get_pacing(unsigned int *tau_ps, int *source, float *h_us);
+/* Everything the paced forms keep is PER DEVICE (time-base cells, the measured schedule, the turn gate): this is the slot of `device` in
+ * those tables -- the device's own index, or -1 for a device the tables have no room for (it runs the unpaced forms).  Pure host
+ * arithmetic, no HIP call: a diagnostic, and what the CPU test pins ("two devices never share a slot"). */
+int rk_pace_slot_of_device(int device);
 /* Stream lifetime.  Paced launches on different streams take turns: the library remembers, per device, the
  * stream of the last paced launch and, when the next one arrives on another stream, makes it wait (event record + stream wait)
  * for that stream.  It only ever remembers a stream it may rely on: the null stream, and streams REGISTERED with

@@ -31,6 +31,7 @@ SIGNATURES = {
 	"rk_set_pacing": (_i, [_i]),
 	"rk_calibrate_pacing": (_i, [_i]),
 	"rk_get_pacing": (_i, [C.POINTER(C.c_uint), C.POINTER(C.c_int), C.POINTER(C.c_float)]),
+	"rk_pace_slot_of_device": (_i, [_i]),
 	"rk_stream_register": (_i, [_vp]),
 	"rk_stream_forget": (_i, [_vp]),
 	"rk_tables": (_i, [_i, _vp]),

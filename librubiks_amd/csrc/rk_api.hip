@@ -231,6 +231,8 @@ int rk_get_pacing(unsigned int *tau_ps, int *source, float *h_us)
 	return RK_OK;
 }
 
+int rk_pace_slot_of_device(int device) { return pace_slot_of_device(device); }
+
 int rk_stream_register(void *stream)
 {
 	register_stream((hipStream_t)stream);

@@ -1474,12 +1474,17 @@ struct PaceDevice {
 	std::atomic<unsigned> tau_ps{PACE_TAU_PS};     // schedule of the fan-out on this device; 0 = the ring form won the calibration
 	float us[PACE_CANDIDATES] = {0, 0, 0, 0, 0};
 };
+// slot of a device in the per-device tables below (time-base cells + calibration, turn gates): its own index, or -1 for a device the tables
+// have no room for -- such a device runs the unpaced forms.  ONE function decides it for every table (rk_pace_slot_of_device exposes it to
+// the CPU test that pins "two devices never share a slot": the round-4 advisor's finding was one cached pointer for all devices).
+int pace_slot_of_device(int dev) { return dev >= 0 && dev < PACE_MAX_DEVICES ? dev : -1; }
 static PaceDevice *pace_device()
 {
 	static PaceDevice devices[PACE_MAX_DEVICES];
 	int dev = -1;
 	if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-	return dev >= 0 && dev < PACE_MAX_DEVICES ? &devices[dev] : nullptr;
+	const int slot = pace_slot_of_device(dev);
+	return slot >= 0 ? &devices[slot] : nullptr;
 }
 static unsigned long long *pace_cells(PaceDevice *d)
 {
@@ -1542,7 +1547,8 @@ struct PacedTurn {
 	{
 		int dev = 0;
 		if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
-		return gates()[dev >= 0 && dev < PACE_MAX_DEVICES ? dev : 0];
+		const int slot = pace_slot_of_device(dev);
+		return gates()[slot >= 0 ? slot : 0];                          // (a device without a slot never launches a paced form: pace_on() is false there)
 	}
 	// Streams the library may REMEMBER: the null stream, and the streams a caller has registered (rk_stream_register) -- a promise
 	// that the stream stays alive until rk_stream_forget.  Nothing else is ever kept across two calls.  Round 4 remembered whatever

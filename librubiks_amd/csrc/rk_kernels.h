@@ -27,6 +27,7 @@ void launch_multi_is_solved(const int8_t *states, uint8_t *flags, long long *sta
 int read_bad_actions(hipStream_t st);
 void set_pace_override(int mode);
 int calibrate_pacing(bool force);
+int pace_slot_of_device(int device);
 void get_pacing(unsigned *tau_ps, int *source, float *us5);
 void register_stream(hipStream_t st);
 void forget_stream(hipStream_t st);

@@ -114,6 +114,16 @@ def test_host_rows_are_whole_rows():
 	assert cube.cube._host_rows(np.zeros((2, 6, 8, 6), np.int8)).shape == (2, 6, 8, 6)
 
 
+def test_pacing_state_is_per_device():
+	"""Advisor, round 4 (medium): the paced launches' time-base cells were looked up once per PROCESS, so a launch on a second device
+	did its atomics at the first device's address.  All per-device state now sits in tables indexed by one function of the device id:
+	distinct devices get distinct slots, a device beyond the tables gets none (and runs unpaced)."""
+	lib = _ffi.lib()
+	slots = [lib.rk_pace_slot_of_device(d) for d in range(32)]
+	assert slots == list(range(32)) and len(set(slots)) == 32
+	assert lib.rk_pace_slot_of_device(32) == -1 and lib.rk_pace_slot_of_device(-1) == -1 and lib.rk_pace_slot_of_device(1 << 20) == -1
+
+
 def test_error_reporting_without_fallback():
 	lib = _ffi.lib()
 	assert lib.rk_tables(7, None) == -1 and b"representation" in lib.rk_last_error()
