@@ -687,3 +687,28 @@ def test_device_clock_ends_a_search_on_time():
 			assert agent.total_states < 4_000_000 - 12 * 20
 			break
 		assert found
+
+
+@pytest.mark.parametrize("fused", [False, "folded"])
+def test_captured_iteration_with_a_real_net_equals_the_eager_one(fused):
+	"""The replayed graph holds the net's GEMMs as well as the engine's kernels: with a random-init fc_small (float32, and bfloat16 with
+	the first layer fused + folded) the captured search visits the very states of the eager one -- same fixed batch shape, so the same
+	net numbers -- and the second search on the kept graph does too."""
+	from benchmarks.nets import FcSmall
+	net = FcSmall(seed=4).cuda().eval()
+	if fused:
+		net = net.to(torch.bfloat16)
+	np.random.seed(77)
+	start, _, _ = orc.scramble(11, True)
+	eager = ShardedAStar(net, 0.2, 60, capacity=40_000, fused_first_layer=fused, poll=2)
+	graph = ShardedAStar(net, 0.2, 60, capacity=40_000, fused_first_layer=fused, poll=5, use_hipgraph=True)
+	a = eager.search(start, None, 25_000)
+	es, eG, ep, ea = eager.local_arrays()
+	for again in range(2):
+		b = graph.search(start, None, 25_000)
+		assert graph.graph_error is None and graph.captures == 1
+		assert a == b and len(eager) == len(graph) and eager.iterations == graph.iterations
+		gs, gG, gp, ga = graph.local_arrays()
+		assert (es == gs).all() and (eG == gG).all() and (ep == gp).all() and (ea == ga).all()
+		if a:
+			assert list(eager.action_queue) == list(graph.action_queue)
