@@ -573,10 +573,29 @@ __device__ __forceinline__ Rec cost_record(const AstarDev &d, const float *value
 // was VALU-bound with 16 waves on the CU: 17.9 us per 2048-record chunk.)
 // A bitonic network over the same chunk needs 66 barrier steps (36 for 256 records), each moving every record through
 // LDS twice: 27.2 us per 2048-record chunk against 16.6 us for this one (9.6 against 8.6 us for 256 records).
+// Round 5: the records are sorted by KEY ALONE, as a stable merge.  A new record's index is n_before + 1 + its batch position
+// (cost_record; the padding's likewise), so "ties by index" is "ties by position", and a merge of two neighbouring runs is stable
+// when a record of the left run counts the right run's keys BELOW its own and a record of the right run the left run's keys
+// up to and including its own.  LDS then holds 8-byte keys and 4-byte positions apart: a search step reads 8 bytes instead of a
+// 16-byte record (the sort was bound by LDS cycles: 2048 x 66 record reads), the searches have a fixed trip count (runs are
+// powers of two), and a thread's two searches advance together.  17.1 -> see profiles/r05_search_legs.json.
+__device__ __forceinline__ void rank_pow2_x2(const uint64_t *a0, const uint64_t *a1, int L, const uint64_t x[2], bool incl0, bool incl1, int pos[2])
+{
+	pos[0] = pos[1] = 0;
+	for (int step = L >> 1; step > 0; step >>= 1) {
+		const uint64_t k0 = a0[pos[0] + step - 1], k1 = a1[pos[1] + step - 1];
+		pos[0] += (incl0 ? k0 <= x[0] : k0 < x[0]) ? step : 0;
+		pos[1] += (incl1 ? k1 <= x[1] : k1 < x[1]) ? step : 0;
+	}
+	const uint64_t k0 = a0[pos[0]], k1 = a1[pos[1]];
+	pos[0] += (incl0 ? k0 <= x[0] : k0 < x[0]) ? 1 : 0;
+	pos[1] += (incl1 ? k1 <= x[1] : k1 < x[1]) ? 1 : 0;
+}
 template <int CHUNK>
 __device__ __forceinline__ void records_sort_body(const AstarDev &d, const float *values)
 {
-	__shared__ Rec s[CHUNK];
+	__shared__ uint64_t sk[CHUNK];
+	__shared__ uint32_t sp[CHUNK];
 	constexpr int T = CHUNK / 2;
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int n_new = min(d.ctr[C_NNEW], d.Kpad);                       // (never more than the launches were sized for: see shard_push_impl)
@@ -586,45 +605,56 @@ __device__ __forceinline__ void records_sort_body(const AstarDev &d, const float
 	const int cnt = n_new - base < CHUNK ? n_new - base : CHUNK;
 	int P = 128;                                                        // merge only the power of two that holds the chunk's records
 	while (P < cnt) P <<= 1;                                            // (records past it are padding and already in place)
-	Rec x[2];
-	int dst[2];
-	Rec *w = s + wv * 128;                                              // this wave's 128 records
+	uint64_t x[2];
+	uint32_t xp[2];
+	int dst[2], rk[2];
+	uint64_t *wk = sk + wv * 128;                                       // this wave's 128 records
+	uint32_t *wp = sp + wv * 128;
 	#pragma unroll
-	for (int t = 0; t < 2; t++) w[t * 64 + lane] = cost_record(d, values, base + wv * 128 + t * 64 + lane, n_new, n_before);
+	for (int t = 0; t < 2; t++) {
+		const int e = wv * 128 + t * 64 + lane;
+		wk[t * 64 + lane] = cost_record(d, values, base + e, n_new, n_before).key;
+		wp[t * 64 + lane] = (uint32_t)e;
+	}
 	wave_lds_fence();
+	#pragma unroll
 	for (int lg = 0; lg <= 6; lg++) {                                   // runs of 1, 2, ... 64 -> 128 sorted records per wave, no barrier
 		const int L = 1 << lg;
-		#pragma unroll
-		for (int t = 0; t < 2; t++) {
-			const int e = t * 64 + lane, r = e >> lg, i = e & (L - 1);
-			x[t] = w[e];
-			dst[t] = ((r & ~1) << lg) + i + lower_bound_rec(w + ((r ^ 1) << lg), L, x[t]);
-		}
+		const int e0 = lane, e1 = 64 + lane;
+		const int r0 = e0 >> lg, r1 = e1 >> lg;
+		x[0] = wk[e0]; x[1] = wk[e1];
+		xp[0] = wp[e0]; xp[1] = wp[e1];
+		rank_pow2_x2(wk + ((r0 ^ 1) << lg), wk + ((r1 ^ 1) << lg), L, x, r0 & 1, r1 & 1, rk);
+		dst[0] = ((r0 & ~1) << lg) + (e0 & (L - 1)) + rk[0];
+		dst[1] = ((r1 & ~1) << lg) + (e1 & (L - 1)) + rk[1];
 		wave_lds_fence();                                               // every lane has read before any lane writes
-		w[dst[0]] = x[0];
-		w[dst[1]] = x[1];
+		wk[dst[0]] = x[0]; wp[dst[0]] = xp[0];
+		wk[dst[1]] = x[1]; wp[dst[1]] = xp[1];
 		wave_lds_fence();
 	}
 	__syncthreads();
 	for (int lg = 7; (1 << lg) < P; lg++) {
 		const int L = 1 << lg;
-		#pragma unroll
-		for (int t = 0; t < 2; t++) {
-			const int e = tid + t * T;
-			if (e < P) {
-				const int r = e >> lg, i = e & (L - 1);
-				x[t] = s[e];
-				dst[t] = ((r & ~1) << lg) + i + lower_bound_rec(s + ((r ^ 1) << lg), L, x[t]);
-			}
-		}
+		const int e0 = tid, e1 = tid + T;
+		const bool on0 = e0 < P, on1 = e1 < P;                          // (P >= 128 is a multiple of the run length: an active record's sibling run is whole)
+		const int r0 = on0 ? e0 >> lg : 0, r1 = on1 ? e1 >> lg : 0;     // idle threads search run 1 from run 0's side: in bounds, result unused
+		x[0] = sk[on0 ? e0 : 0]; x[1] = sk[on1 ? e1 : 0];
+		xp[0] = sp[on0 ? e0 : 0]; xp[1] = sp[on1 ? e1 : 0];
+		rank_pow2_x2(sk + ((r0 ^ 1) << lg), sk + ((r1 ^ 1) << lg), L, x, r0 & 1, r1 & 1, rk);
+		dst[0] = ((r0 & ~1) << lg) + (e0 & (L - 1)) + rk[0];
+		dst[1] = ((r1 & ~1) << lg) + (e1 & (L - 1)) + rk[1];
 		__syncthreads();
-		#pragma unroll
-		for (int t = 0; t < 2; t++)
-			if (tid + t * T < P) s[dst[t]] = x[t];
+		if (on0) { sk[dst[0]] = x[0]; sp[dst[0]] = xp[0]; }
+		if (on1) { sk[dst[1]] = x[1]; sp[dst[1]] = xp[1]; }
 		__syncthreads();
 	}
-	d.rec0[base + tid] = s[tid];
-	d.rec0[base + tid + T] = s[tid + T];
+	#pragma unroll
+	for (int t = 0; t < 2; t++) {
+		const int e = tid + t * T;
+		const int j = base + (int)sp[e];
+		const uint64_t idx = j < n_new ? (uint64_t)(n_before + 1u + (uint32_t)j) : 0xFFFFFFFF00000000ull + (uint64_t)j;   // = cost_record's
+		d.rec0[base + e] = Rec{sk[e], idx};
+	}
 }
 template <int CHUNK>
 __global__ __launch_bounds__(CHUNK / 2)
