@@ -123,6 +123,22 @@ __device__ __host__ __forceinline__ int new_chunk_of(int chunk, int Kpad)
 	return chunk == SMALL_CHUNK ? SMALL_CHUNK : (Kpad <= MAX_NEW_RUNS * SORT_CHUNK ? SORT_CHUNK : 0);
 }
 
+// The plan's target level and size alone (the end-of-iteration kernel needs nothing else of it; a whole MergePlan as a local
+// of one thread is 272 bytes of SCRATCH memory, written and read back through the memory system: 2 us of that kernel).
+// t = -1: nothing to merge.
+__device__ __forceinline__ void plan_target(const QueueDev &q, const int32_t *meta, int n_new, int &t_out, int &total)
+{
+	t_out = -1; total = 0;
+	if (n_new <= 0) return;
+	int sum = n_new, t = 0;
+	for (; t < q.levels; t++) {
+		sum += meta[Q_LEN * QL + t] - meta[Q_HEAD * QL + t] - meta[Q_TAKE * QL + t];
+		if ((uint32_t)sum <= q.cap[t]) break;
+	}
+	if (t >= q.levels) t = q.levels - 1;       // cannot happen: the top level holds the whole pool
+	t_out = t; total = sum;
+}
+
 // meta = pointer to [4][QL] ints (global or LDS copy).  live range of level j after the pending pop: [head+take, len)
 // new_chunk: the new records are sorted runs of this length (SMALL_CHUNK), or one run (0)
 __device__ __forceinline__ void make_plan(const QueueDev &q, const int32_t *meta, const Rec *newrun, int n_new, int new_chunk, MergePlan &p)
@@ -157,6 +173,51 @@ __device__ __forceinline__ void make_plan(const QueueDev &q, const int32_t *meta
 	}
 	p.total = sum;
 	p.dst = q.buf[t][meta[Q_CUR * QL + t] ^ 1];
+}
+
+// The same plan written by ONE WAVE (all 64 lanes of it call this): lane j looks at queue level j, lane i at new run i; the
+// prefix sums, the target level and the run list come out of a few cross-lane steps instead of one thread's loops over LDS
+// and kernel-argument memory (2.1 us at the head of every workgroup of k_queue_insert, measured with the device clock).
+__device__ __forceinline__ void make_plan_wave(const QueueDev &q, const int32_t *meta, const Rec *newrun, int n_new, int new_chunk, MergePlan &p, int lane)
+{
+	if (n_new <= 0) {
+		if (lane == 0) { p.t = -1; p.n_runs = 0; p.total = 0; p.dst = nullptr; p.n_new_runs = 0; }
+		return;
+	}
+	const int levels = q.levels;
+	const bool is_level = lane < levels;
+	const int lv = is_level ? lane : 0;
+	const int start = meta[Q_HEAD * QL + lv] + meta[Q_TAKE * QL + lv];
+	const int live = is_level ? meta[Q_LEN * QL + lv] - start : 0;
+	const int cur = meta[Q_CUR * QL + lv];
+	int incl = live;                                                    // inclusive prefix sum over the levels (QL <= 16 lanes)
+	#pragma unroll
+	for (int off = 1; off < 16; off <<= 1) {
+		const int v = __shfl_up(incl, off);
+		if (lane >= off) incl += v;
+	}
+	const int sum = n_new + incl;
+	const unsigned long long fits = __ballot(is_level && (uint32_t)sum <= q.cap[lv]);
+	const int t = fits ? __ffsll((long long)fits) - 1 : levels - 1;     // (no level fits: cannot happen, the top level holds the whole pool)
+	const int total = __shfl(sum, t);
+	const int cur_t = __shfl(cur, t);
+	const int n_chunks = new_chunk > 0 ? (n_new + new_chunk - 1) / new_chunk : 1;
+	if (lane < n_chunks) {
+		const int at = lane * new_chunk;
+		p.run[lane] = newrun + at;
+		p.len[lane] = new_chunk > 0 ? (n_new - at < new_chunk ? n_new - at : new_chunk) : n_new;
+	}
+	const bool has = is_level && lane <= t && live > 0;
+	const unsigned long long m = __ballot(has);
+	if (has) {
+		const int at = n_chunks + __popcll(m & ((1ull << lane) - 1ull));
+		p.run[at] = q.buf[lv][cur] + start;
+		p.len[at] = live;
+	}
+	if (lane == 0) {
+		p.t = t; p.n_new_runs = n_chunks; p.n_runs = n_chunks + __popcll(m); p.total = total;
+		p.dst = q.buf[t][cur_t ^ 1];
+	}
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -717,20 +778,43 @@ __device__ __forceinline__ void queue_insert_body(const AstarDev &d, int new_in_
 	__shared__ MergePlan s_plan;
 	__shared__ Rec s_pool[POOL_RECS];
 	__shared__ int32_t s_qmeta[4 * QL];
+	__shared__ int s_nnew;
 	const int nc = new_chunk_of(d.chunk, d.Kpad);
 	const bool small = nc == SMALL_CHUNK;
 	Rec *const s_newrecs = s_pool;
+	const int stride = gridDim.x * blockDim.x;
+	if (!SHARDED) {
+		// Read half of relaxation case 2 and the marks this batch set: independent of the merge, so it comes first and in the
+		// LAST workgroups of the grid, which have no records to merge most of the time (behind the merge in the first workgroups it
+		// was 1.7 us at the end of the kernel).  Sharded engines: case 2 travels as offers (k_shard_offers).
+		const int K = 12 * d.ctr[C_NPOP];
+		const bool won = d.ctr[C_WON] != 0;
+		for (int c = (gridDim.x - 1 - blockIdx.x) * blockDim.x + threadIdx.x; c < K; c += stride) {
+			uint8_t sc = 0;
+			if (d.flags[c] & 2) {
+				const int32_t t = d.seen[c];
+				d.mark[t] = NO_MARK;
+				if (!won) {
+					const int32_t g = d.G[t] + 1;
+					sc = g < d.G[d.exp_idx[c / 12]];
+					d.val2[c] = g;
+				}
+			}
+			d.shortcut[c] = sc;
+		}
+	}
 	if (threadIdx.x < 4 * QL) s_qmeta[threadIdx.x] = d.q.meta[threadIdx.x];     // one parallel load instead of a dependent chain
+	else if (threadIdx.x == 64) s_nnew = min(d.ctr[C_NNEW], d.Kpad);            // (in the same round trip)
 	__syncthreads();
-	if (threadIdx.x == 0) {
-		const int n_new = min(d.ctr[C_NNEW], d.Kpad);
+	if (threadIdx.x < 64) {
+		const int n_new = s_nnew;
 		// after merge passes (one run out of more than eight chunks) the result ping-pongs; otherwise the sorted run(s) are in rec0
-		make_plan(d.q, s_qmeta, (nc == 0 && n_new > SORT_CHUNK && new_in_rec1) ? d.rec1 : d.rec0, n_new, nc, s_plan);
+		make_plan_wave(d.q, s_qmeta, (nc == 0 && n_new > SORT_CHUNK && new_in_rec1) ? d.rec1 : d.rec0, n_new, nc, s_plan, threadIdx.x);
 	}
 	__syncthreads();
 	if (small && s_plan.total > 0) {
 		// K <= 2048: the sorted runs of new records (16-32 KB) are staged in LDS, so the merge searches them on the CU
-		const int n_new = min(d.ctr[C_NNEW], d.Kpad);
+		const int n_new = s_nnew;
 		for (int i = threadIdx.x; i < n_new; i += blockDim.x) s_newrecs[i] = d.rec0[i];
 		__syncthreads();
 		if ((int)threadIdx.x < s_plan.n_new_runs) s_plan.run[threadIdx.x] = s_newrecs + threadIdx.x * SMALL_CHUNK;
@@ -744,17 +828,33 @@ __device__ __forceinline__ void queue_insert_body(const AstarDev &d, int new_in_
 	const int sampled_runs = small ? 3 : MAX_SAMPLED;
 	const int first_global = small ? p.n_new_runs : 0;
 	if (p.total > 0) {
-		for (int k = 0; k < sampled_runs; k++) {
+		// The samples of all runs are loaded TOGETHER, then stored (as a loop of load-and-store per run every run's load waited for
+		// the one before: 4.2 us in front of every workgroup's merge, measured with the device clock).  Two things make that happen
+		// on this compiler: the loaded records are named values (an array of them indexed by the unrolled loop lands in scratch
+		// memory), and the loads are GLOBAL loads -- the sampled runs always are global memory, and a flat load counts on the LDS
+		// counter too, so the LDS reads of the next run's length would wait for it.  A thread without a sample in run k reads
+		// the first new record (always there, always global memory) and drops it.
+		static_assert(MAX_SAMPLED == 11, "one SAMPLE_LOAD / SAMPLE_STORE per sampled run");
+		auto sample_load = [&](int k, int &ns) -> u32x4 {
 			const int r = first_global + k;
-			if (r >= p.n_runs) break;
-			const int len = p.len[r], step = (len + SAMPLES - 1) / SAMPLES;
-			const int ns = step > 1 ? (len + step - 1) / step : 0;             // short runs are searched directly
-			if ((int)threadIdx.x < ns) s_samples[k * SAMPLES + threadIdx.x] = p.run[r][(size_t)threadIdx.x * step];
-			if (threadIdx.x == 0) { s_step[k] = step; s_nsamp[k] = ns; }
-		}
+			const bool have = k < sampled_runs && r < p.n_runs;
+			const int len = have ? p.len[r] : 0, step = (len + SAMPLES - 1) / SAMPLES;
+			ns = step > 1 ? (len + step - 1) / step : 0;                      // short runs are searched directly
+			if (threadIdx.x == 0 && have) { s_step[k] = step; s_nsamp[k] = ns; }
+			const bool mine = (int)threadIdx.x < ns;
+			const Rec *src = mine ? p.run[r] + (size_t)threadIdx.x * step : d.rec0;
+			return *(const __attribute__((address_space(1))) u32x4 *)(uintptr_t)src;
+		};
+		#define SAMPLE_LOAD(k) int n##k; const u32x4 v##k = sample_load(k, n##k);
+		#define SAMPLE_STORE(k) if ((int)threadIdx.x < n##k) reinterpret_cast<u32x4 *>(s_samples)[k * SAMPLES + threadIdx.x] = v##k;
+		SAMPLE_LOAD(0) SAMPLE_LOAD(1) SAMPLE_LOAD(2) SAMPLE_LOAD(3) SAMPLE_LOAD(4) SAMPLE_LOAD(5)
+		SAMPLE_LOAD(6) SAMPLE_LOAD(7) SAMPLE_LOAD(8) SAMPLE_LOAD(9) SAMPLE_LOAD(10)
+		SAMPLE_STORE(0) SAMPLE_STORE(1) SAMPLE_STORE(2) SAMPLE_STORE(3) SAMPLE_STORE(4) SAMPLE_STORE(5)
+		SAMPLE_STORE(6) SAMPLE_STORE(7) SAMPLE_STORE(8) SAMPLE_STORE(9) SAMPLE_STORE(10)
+		#undef SAMPLE_LOAD
+		#undef SAMPLE_STORE
 		__syncthreads();
 	}
-	const int stride = gridDim.x * blockDim.x;
 	for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < p.total; e += stride) {
 		int r = 0, off = e;
 		while (off >= p.len[r]) { off -= p.len[r]; r++; }
@@ -773,22 +873,6 @@ __device__ __forceinline__ void queue_insert_body(const AstarDev &d, int new_in_
 			}
 		}
 		p.dst[pos] = x;
-	}
-	if (SHARDED) return;                                                // sharded: case 2 travels as offers (k_shard_offers)
-	const int K = 12 * d.ctr[C_NPOP];
-	const bool won = d.ctr[C_WON] != 0;
-	for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < K; c += stride) {
-		uint8_t sc = 0;
-		if (d.flags[c] & 2) {
-			const int32_t t = d.seen[c];
-			d.mark[t] = NO_MARK;
-			if (!won) {
-				const int32_t g = d.G[t] + 1;
-				sc = g < d.G[d.exp_idx[c / 12]];
-				d.val2[c] = g;
-			}
-		}
-		d.shortcut[c] = sc;
 	}
 }
 template <bool SHARDED>
@@ -859,9 +943,8 @@ __device__ __forceinline__ void end_body(const AstarDev &d, int new_in_rec1, int
 			if (t0 == 0) { t0 = now ? now : 1; s_ctr[C_CLOCK0] = (int32_t)(uint32_t)t0; s_ctr[C_CLOCK0 + 1] = (int32_t)(uint32_t)(t0 >> 32); }
 			s_elapsed = (double)(now - t0) * 1e-8;
 		}
-		MergePlan p;
-		const int nc = new_chunk_of(d.chunk, d.Kpad);
-		make_plan(d.q, s_old, (nc == 0 && n_new > SORT_CHUNK && new_in_rec1) ? d.rec1 : d.rec0, n_new, nc, p);
+		struct { int t, total; } p;                                      // (what k_queue_insert's plan of this iteration said: same inputs)
+		plan_target(d.q, s_old, n_new, p.t, p.total);
 		int open = 0;
 		for (int j = 0; j < d.q.levels; j++) {
 			int head = s_old[Q_HEAD * QL + j] + s_old[Q_TAKE * QL + j], len = s_old[Q_LEN * QL + j], cur = s_old[Q_CUR * QL + j];
