@@ -771,6 +771,7 @@ __global__ void kb_merge_pass(const AstarDev *__restrict__ devs, int L, int from
 constexpr int SAMPLES = 256;
 constexpr int POOL_RECS = SORT_CHUNK + 3 * SAMPLES;                     // 45 056 B: staged new records + 3 indexed runs, or 11 indexed runs
 constexpr int MAX_SAMPLED = POOL_RECS / SAMPLES;
+constexpr int MERGE_SLOTS = 8;                                        // lanes per record in the insert's merge (a power of two <= 64)
 
 template <bool SHARDED>
 __device__ __forceinline__ void queue_insert_body(const AstarDev &d, int new_in_rec1)
@@ -806,10 +807,21 @@ __device__ __forceinline__ void queue_insert_body(const AstarDev &d, int new_in_
 	if (threadIdx.x < 4 * QL) s_qmeta[threadIdx.x] = d.q.meta[threadIdx.x];     // one parallel load instead of a dependent chain
 	else if (threadIdx.x == 64) s_nnew = min(d.ctr[C_NNEW], d.Kpad);            // (in the same round trip)
 	__syncthreads();
+	__shared__ int s_step[MAX_SAMPLED], s_nsamp[MAX_SAMPLED];
 	if (threadIdx.x < 64) {
 		const int n_new = s_nnew;
 		// after merge passes (one run out of more than eight chunks) the result ping-pongs; otherwise the sorted run(s) are in rec0
 		make_plan_wave(d.q, s_qmeta, (nc == 0 && n_new > SORT_CHUNK && new_in_rec1) ? d.rec1 : d.rec0, n_new, nc, s_plan, threadIdx.x);
+		wave_lds_fence();
+		// the coarse index's geometry (below), one sampled run per lane: the two divisions per run cost every thread of the
+		// workgroup 2 us of instructions when each of them worked them out for all eleven runs
+		if (threadIdx.x < MAX_SAMPLED) {
+			const int k = threadIdx.x, r = (small ? s_plan.n_new_runs : 0) + k;
+			const bool have = s_plan.total > 0 && k < (small ? 3 : MAX_SAMPLED) && r < s_plan.n_runs;
+			const int len = have ? s_plan.len[r] : 0, step = (len + SAMPLES - 1) / SAMPLES;
+			s_step[k] = step;
+			s_nsamp[k] = step > 1 ? (len + step - 1) / step : 0;              // short runs are searched directly
+		}
 	}
 	__syncthreads();
 	if (small && s_plan.total > 0) {
@@ -823,7 +835,6 @@ __device__ __forceinline__ void queue_insert_body(const AstarDev &d, int new_in_
 	const MergePlan &p = s_plan;
 	// Long runs that stay in global memory (the queue levels) get a coarse index in LDS: every `step`-th record, at most
 	// SAMPLES per run, so that a binary search spends its first steps on the CU and only log2(step) of them in memory.
-	__shared__ int s_step[MAX_SAMPLED], s_nsamp[MAX_SAMPLED];
 	Rec *const s_samples = small ? s_pool + SORT_CHUNK : s_pool;          // [sampled runs][SAMPLES]
 	const int sampled_runs = small ? 3 : MAX_SAMPLED;
 	const int first_global = small ? p.n_new_runs : 0;
@@ -836,13 +847,9 @@ __device__ __forceinline__ void queue_insert_body(const AstarDev &d, int new_in_
 		// the first new record (always there, always global memory) and drops it.
 		static_assert(MAX_SAMPLED == 11, "one SAMPLE_LOAD / SAMPLE_STORE per sampled run");
 		auto sample_load = [&](int k, int &ns) -> u32x4 {
-			const int r = first_global + k;
-			const bool have = k < sampled_runs && r < p.n_runs;
-			const int len = have ? p.len[r] : 0, step = (len + SAMPLES - 1) / SAMPLES;
-			ns = step > 1 ? (len + step - 1) / step : 0;                      // short runs are searched directly
-			if (threadIdx.x == 0 && have) { s_step[k] = step; s_nsamp[k] = ns; }
+			ns = s_nsamp[k];                                                  // (0 for a run that is not there or not sampled)
 			const bool mine = (int)threadIdx.x < ns;
-			const Rec *src = mine ? p.run[r] + (size_t)threadIdx.x * step : d.rec0;
+			const Rec *src = mine ? p.run[first_global + k] + (size_t)threadIdx.x * s_step[k] : d.rec0;
 			return *(const __attribute__((address_space(1))) u32x4 *)(uintptr_t)src;
 		};
 		#define SAMPLE_LOAD(k) int n##k; const u32x4 v##k = sample_load(k, n##k);
@@ -855,24 +862,36 @@ __device__ __forceinline__ void queue_insert_body(const AstarDev &d, int new_in_
 		#undef SAMPLE_STORE
 		__syncthreads();
 	}
-	for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < p.total; e += stride) {
-		int r = 0, off = e;
+	// A record's searches in the other runs are independent: MERGE_SLOTS neighbouring lanes share one record, lane `slot` searches
+	// runs slot, slot + MERGE_SLOTS, ..., and the partial ranks are added across the lanes.  One thread per record walked through
+	// all the other runs -- 7 to 9 dependent binary searches, 7.9 us of this kernel with one wave per SIMD on half the CUs
+	// (device clock) -- where now every lane does one or two and eight times as many waves hide each other's latencies.
+	const int slot = threadIdx.x & (MERGE_SLOTS - 1);
+	const int per_pass = blockDim.x / MERGE_SLOTS;
+	for (int e0 = blockIdx.x * per_pass; e0 < p.total; e0 += gridDim.x * per_pass) {      // (uniform for the workgroup)
+		const int e = e0 + (int)(threadIdx.x / MERGE_SLOTS);
+		const bool on = e < p.total;
+		int r = 0, off = on ? e : 0;
 		while (off >= p.len[r]) { off -= p.len[r]; r++; }
 		const Rec x = p.run[r][off];
-		int pos = off;
-		for (int r2 = 0; r2 < p.n_runs; r2++) {
-			if (r2 == r) continue;
-			const int k = r2 - first_global;
-			if (k >= 0 && k < sampled_runs && s_nsamp[k] > 0) {
-				const int sp = lower_bound_rec(s_samples + k * SAMPLES, s_nsamp[k], x);   // first sample >= x
-				const int lo = sp > 0 ? (sp - 1) * s_step[k] : 0;
-				const int hi = sp < s_nsamp[k] ? sp * s_step[k] : p.len[r2];
-				pos += lo + lower_bound_rec(p.run[r2] + lo, hi - lo, x);
-			} else {
-				pos += lower_bound_rec(p.run[r2], p.len[r2], x);
+		int pos = 0;
+		if (on) {
+			for (int r2 = slot; r2 < p.n_runs; r2 += MERGE_SLOTS) {
+				if (r2 == r) continue;
+				const int k = r2 - first_global;
+				if (k >= 0 && k < sampled_runs && s_nsamp[k] > 0) {
+					const int sp = lower_bound_rec(s_samples + k * SAMPLES, s_nsamp[k], x);   // first sample >= x
+					const int lo = sp > 0 ? (sp - 1) * s_step[k] : 0;
+					const int hi = sp < s_nsamp[k] ? sp * s_step[k] : p.len[r2];
+					pos += lo + lower_bound_rec(p.run[r2] + lo, hi - lo, x);
+				} else {
+					pos += lower_bound_rec(p.run[r2], p.len[r2], x);
+				}
 			}
 		}
-		p.dst[pos] = x;
+		#pragma unroll
+		for (int m = 1; m < MERGE_SLOTS; m <<= 1) pos += __shfl_xor(pos, m);
+		if (on && slot == 0) p.dst[off + pos] = x;
 	}
 }
 template <bool SHARDED>
@@ -1440,7 +1459,10 @@ int launch_commit(rk_astar *h, const float *d_values, const uint8_t *recv, hipSt
 	// then); workgroups beyond it leave after the plan.  With 32 workgroups at N = 100 the occasional level merge (up to
 	// the whole open set) ran 32 records per thread, each a chain of dependent binary searches: 310 us spikes in round 2.
 	static const unsigned min_grid = [] { const char *e = std::getenv("RK_INSERT_MIN_GRID"); return e ? (unsigned)std::atoi(e) : 512u; }();
-	const unsigned grid = std::min<unsigned>(1024u, std::max<unsigned>(blocks((size_t)d.Kpad * 4), min_grid));
+	// (a workgroup merges 256 / MERGE_SLOTS records per pass: the usual merge -- the new records and a level or two, about 2.5 x Kpad
+	//  records -- in one pass; not more workgroups than the chip holds at once with this kernel's LDS, three per CU)
+	static const unsigned max_grid = [] { const char *e = std::getenv("RK_INSERT_MAX_GRID"); return e ? (unsigned)std::atoi(e) : 768u; }();
+	const unsigned grid = std::min<unsigned>(max_grid, std::max<unsigned>(blocks((size_t)d.Kpad * 5 * MERGE_SLOTS / 2), min_grid));
 	hipLaunchKernelGGL((k_queue_insert<SHARDED>), dim3(grid), dim3(256), 0, st, d, from);
 	if (!SHARDED) {
 		hipLaunchKernelGGL((k_end<false>), dim3(1), dim3(1024), 0, st, d, from, 1, 0);
