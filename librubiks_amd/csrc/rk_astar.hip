@@ -306,11 +306,10 @@ __device__ __forceinline__ void lookup_elect(const AstarDev &d, const uint32_t s
 {
 	uint32_t slot = hash_state(s) & d.mask;
 	for (;;) {
-		uint32_t e = __hip_atomic_load(&d.table[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if (e == 0u) {
-			e = atomicCAS(&d.table[slot], 0u, TENT | (uint32_t)c);
-			if (e == 0u) { d.seen[c] = 0; d.child_slot[c] = slot; return; }
-		}
+		// (the claim IS the probe: an empty slot -- two children in three at N = 1000 are new states -- costs one round trip to the
+		//  table instead of a load and then the compare-and-swap; an occupied slot answers with its occupant either way)
+		const uint32_t e = atomicCAS(&d.table[slot], 0u, TENT | (uint32_t)c);
+		if (e == 0u) { d.seen[c] = 0; d.child_slot[c] = slot; return; }
 		if (e & TENT) {
 			uint32_t o[5];
 			other((int)(e & ~TENT), o);
@@ -844,12 +843,12 @@ __device__ __forceinline__ void queue_insert_body(const AstarDev &d, int new_in_
 		// on this compiler: the loaded records are named values (an array of them indexed by the unrolled loop lands in scratch
 		// memory), and the loads are GLOBAL loads -- the sampled runs always are global memory, and a flat load counts on the LDS
 		// counter too, so the LDS reads of the next run's length would wait for it.  A thread without a sample in run k reads
-		// the first new record (always there, always global memory) and drops it.
+		// one of the new records' slots (always there, always global memory; another one in every workgroup) and drops it.
 		static_assert(MAX_SAMPLED == 11, "one SAMPLE_LOAD / SAMPLE_STORE per sampled run");
 		auto sample_load = [&](int k, int &ns) -> u32x4 {
 			ns = s_nsamp[k];                                                  // (0 for a run that is not there or not sampled)
 			const bool mine = (int)threadIdx.x < ns;
-			const Rec *src = mine ? p.run[first_global + k] + (size_t)threadIdx.x * s_step[k] : d.rec0;
+			const Rec *src = mine ? p.run[first_global + k] + (size_t)threadIdx.x * s_step[k] : d.rec0 + (blockIdx.x * 16 + k) % d.Kpad;
 			return *(const __attribute__((address_space(1))) u32x4 *)(uintptr_t)src;
 		};
 		#define SAMPLE_LOAD(k) int n##k; const u32x4 v##k = sample_load(k, n##k);
@@ -862,21 +861,24 @@ __device__ __forceinline__ void queue_insert_body(const AstarDev &d, int new_in_
 		#undef SAMPLE_STORE
 		__syncthreads();
 	}
-	// A record's searches in the other runs are independent: MERGE_SLOTS neighbouring lanes share one record, lane `slot` searches
-	// runs slot, slot + MERGE_SLOTS, ..., and the partial ranks are added across the lanes.  One thread per record walked through
+	// A record's searches in the other runs are independent: `slots` (up to MERGE_SLOTS) neighbouring lanes share one record, lane `slot`
+	// searches runs slot, slot + slots, ..., and the partial ranks are added across the lanes.  One thread per record walked through
 	// all the other runs -- 7 to 9 dependent binary searches, 7.9 us of this kernel with one wave per SIMD on half the CUs
 	// (device clock) -- where now every lane does one or two and eight times as many waves hide each other's latencies.
-	const int slot = threadIdx.x & (MERGE_SLOTS - 1);
-	const int per_pass = blockDim.x / MERGE_SLOTS;
+	// As many lanes per record as leave the grid ONE pass over the merge (a second pass in some workgroups is the kernel's tail).
+	int slots = MERGE_SLOTS;
+	while (slots > 1 && (long long)p.total * slots > (long long)gridDim.x * blockDim.x) slots >>= 1;
+	const int slot = threadIdx.x & (slots - 1);
+	const int per_pass = blockDim.x / slots;
 	for (int e0 = blockIdx.x * per_pass; e0 < p.total; e0 += gridDim.x * per_pass) {      // (uniform for the workgroup)
-		const int e = e0 + (int)(threadIdx.x / MERGE_SLOTS);
+		const int e = e0 + (int)(threadIdx.x / slots);
 		const bool on = e < p.total;
 		int r = 0, off = on ? e : 0;
 		while (off >= p.len[r]) { off -= p.len[r]; r++; }
 		const Rec x = p.run[r][off];
 		int pos = 0;
 		if (on) {
-			for (int r2 = slot; r2 < p.n_runs; r2 += MERGE_SLOTS) {
+			for (int r2 = slot; r2 < p.n_runs; r2 += slots) {
 				if (r2 == r) continue;
 				const int k = r2 - first_global;
 				if (k >= 0 && k < sampled_runs && s_nsamp[k] > 0) {
@@ -889,8 +891,7 @@ __device__ __forceinline__ void queue_insert_body(const AstarDev &d, int new_in_
 				}
 			}
 		}
-		#pragma unroll
-		for (int m = 1; m < MERGE_SLOTS; m <<= 1) pos += __shfl_xor(pos, m);
+		for (int m = 1; m < slots; m <<= 1) pos += __shfl_xor(pos, m);
 		if (on && slot == 0) p.dst[off + pos] = x;
 	}
 }
@@ -1459,10 +1460,9 @@ int launch_commit(rk_astar *h, const float *d_values, const uint8_t *recv, hipSt
 	// then); workgroups beyond it leave after the plan.  With 32 workgroups at N = 100 the occasional level merge (up to
 	// the whole open set) ran 32 records per thread, each a chain of dependent binary searches: 310 us spikes in round 2.
 	static const unsigned min_grid = [] { const char *e = std::getenv("RK_INSERT_MIN_GRID"); return e ? (unsigned)std::atoi(e) : 512u; }();
-	// (a workgroup merges 256 / MERGE_SLOTS records per pass: the usual merge -- the new records and a level or two, about 2.5 x Kpad
-	//  records -- in one pass; not more workgroups than the chip holds at once with this kernel's LDS, three per CU)
-	static const unsigned max_grid = [] { const char *e = std::getenv("RK_INSERT_MAX_GRID"); return e ? (unsigned)std::atoi(e) : 768u; }();
-	const unsigned grid = std::min<unsigned>(max_grid, std::max<unsigned>(blocks((size_t)d.Kpad * 5 * MERGE_SLOTS / 2), min_grid));
+	// (512 workgroups, two per CU, also are what the usual merge at N = 1000 -- 30 000 records -- runs fastest on: 256 / 384 / 512 / 768 /
+	//  1024 workgroups: 14.3 / 13.5 / 12.2 / 12.8 / 16.8 us, every workgroup pays the plan and the coarse index before it merges)
+	const unsigned grid = std::min<unsigned>(1024u, std::max<unsigned>(blocks((size_t)d.Kpad * 4), min_grid));
 	hipLaunchKernelGGL((k_queue_insert<SHARDED>), dim3(grid), dim3(256), 0, st, d, from);
 	if (!SHARDED) {
 		hipLaunchKernelGGL((k_end<false>), dim3(1), dim3(1024), 0, st, d, from, 1, 0);
