@@ -178,13 +178,15 @@ __device__ __forceinline__ void make_plan(const QueueDev &q, const int32_t *meta
 // The same plan written by ONE WAVE (all 64 lanes of it call this): lane j looks at queue level j, lane i at new run i; the
 // prefix sums, the target level and the run list come out of a few cross-lane steps instead of one thread's loops over LDS
 // and kernel-argument memory (2.1 us at the head of every workgroup of k_queue_insert, measured with the device clock).
-__device__ __forceinline__ void make_plan_wave(const QueueDev &q, const int32_t *meta, const Rec *newrun, int n_new, int new_chunk, MergePlan &p, int lane)
+// cap[j], buf[2 j + b]: the queue's q.cap[j] and q.buf[j][b] (LDS copies: as kernel-argument memory indexed by the lane they are two
+// more round trips inside the plan)
+__device__ __forceinline__ void make_plan_wave(int levels, const uint32_t *cap, Rec *const *buf, const int32_t *meta, const Rec *newrun, int n_new, int new_chunk, MergePlan &p, int lane)
 {
+	static_assert(QL <= 16, "the levels' prefix sums run over 16 lanes");
 	if (n_new <= 0) {
 		if (lane == 0) { p.t = -1; p.n_runs = 0; p.total = 0; p.dst = nullptr; p.n_new_runs = 0; }
 		return;
 	}
-	const int levels = q.levels;
 	const bool is_level = lane < levels;
 	const int lv = is_level ? lane : 0;
 	const int start = meta[Q_HEAD * QL + lv] + meta[Q_TAKE * QL + lv];
@@ -197,7 +199,7 @@ __device__ __forceinline__ void make_plan_wave(const QueueDev &q, const int32_t 
 		if (lane >= off) incl += v;
 	}
 	const int sum = n_new + incl;
-	const unsigned long long fits = __ballot(is_level && (uint32_t)sum <= q.cap[lv]);
+	const unsigned long long fits = __ballot(is_level && (uint32_t)sum <= cap[lv]);
 	const int t = fits ? __ffsll((long long)fits) - 1 : levels - 1;     // (no level fits: cannot happen, the top level holds the whole pool)
 	const int total = __shfl(sum, t);
 	const int cur_t = __shfl(cur, t);
@@ -211,12 +213,12 @@ __device__ __forceinline__ void make_plan_wave(const QueueDev &q, const int32_t 
 	const unsigned long long m = __ballot(has);
 	if (has) {
 		const int at = n_chunks + __popcll(m & ((1ull << lane) - 1ull));
-		p.run[at] = q.buf[lv][cur] + start;
+		p.run[at] = buf[2 * lv + cur] + start;
 		p.len[at] = live;
 	}
 	if (lane == 0) {
 		p.t = t; p.n_new_runs = n_chunks; p.n_runs = n_chunks + __popcll(m); p.total = total;
-		p.dst = q.buf[t][cur_t ^ 1];
+		p.dst = buf[2 * t + (cur_t ^ 1)];
 	}
 }
 
@@ -256,20 +258,29 @@ constexpr int POP_LDS = 6144;                   // 96 KB of 16-byte records
 //  and one workgroup walking levels * N candidates through global memory was 130 us of a rank's iteration, benchmarks/sharded_sim8.py)
 __device__ __forceinline__ bool pop_is_wide(const AstarDev &d) { return d.q.levels * d.N > POP_LDS; }
 
+// cand / n for 0 <= cand < 2^23: a float multiply and a fix-up instead of the 30-instruction integer division (twice per candidate)
+__device__ __forceinline__ int div_small(int cand, int n, float inv_n)
+{
+	int j = (int)((float)cand * inv_n);
+	if ((j + 1) * n <= cand) j++;
+	else if (j * n > cand) j--;
+	return j;
+}
 __device__ __forceinline__ void pop_select(const AstarDev &d, const int32_t *meta, int n_cand, int n_exp, Rec *s_heads, int first, int stride)
 {
 	const QueueDev &q = d.q;
+	const float inv_n = 1.0f / (float)(n_exp > 0 ? n_exp : 1);
 	const bool staged = s_heads != nullptr && q.levels * n_exp <= POP_LDS;
 	if (staged) {
 		for (int cand = threadIdx.x; cand < q.levels * n_exp; cand += blockDim.x) {
-			const int j = cand / n_exp, i = cand - j * n_exp;
+			const int j = div_small(cand, n_exp, inv_n), i = cand - j * n_exp;
 			const int head = meta[Q_HEAD * QL + j];
 			if (i < meta[Q_LEN * QL + j] - head) s_heads[cand] = q.buf[j][meta[Q_CUR * QL + j]][head + i];
 		}
 		__syncthreads();
 	}
 	for (int cand = first; cand < q.levels * n_exp; cand += stride) {
-		const int j = cand / n_exp, i = cand - j * n_exp;
+		const int j = div_small(cand, n_exp, inv_n), i = cand - j * n_exp;
 		const int head = meta[Q_HEAD * QL + j], live = meta[Q_LEN * QL + j] - head;
 		if (i >= live) continue;
 		const Rec x = staged ? s_heads[cand] : q.buf[j][meta[Q_CUR * QL + j]][head + i];
@@ -778,6 +789,8 @@ __device__ __forceinline__ void queue_insert_body(const AstarDev &d, int new_in_
 	__shared__ MergePlan s_plan;
 	__shared__ Rec s_pool[POOL_RECS];
 	__shared__ int32_t s_qmeta[4 * QL];
+	__shared__ uint32_t s_cap[QL];
+	__shared__ Rec *s_buf[2 * QL];
 	__shared__ int s_nnew;
 	const int nc = new_chunk_of(d.chunk, d.Kpad);
 	const bool small = nc == SMALL_CHUNK;
@@ -804,13 +817,15 @@ __device__ __forceinline__ void queue_insert_body(const AstarDev &d, int new_in_
 		}
 	}
 	if (threadIdx.x < 4 * QL) s_qmeta[threadIdx.x] = d.q.meta[threadIdx.x];     // one parallel load instead of a dependent chain
-	else if (threadIdx.x == 64) s_nnew = min(d.ctr[C_NNEW], d.Kpad);            // (in the same round trip)
+	else if (threadIdx.x == 64) s_nnew = min(d.ctr[C_NNEW], d.Kpad);            // (in the same round trip, and so are the queue's capacities and buffers)
+	else if (threadIdx.x >= 128 && threadIdx.x < 128 + QL) s_cap[threadIdx.x - 128] = d.q.cap[threadIdx.x - 128];
+	else if (threadIdx.x >= 192 && threadIdx.x < 192 + 2 * QL) s_buf[threadIdx.x - 192] = d.q.buf[(threadIdx.x - 192) >> 1][(threadIdx.x - 192) & 1];
 	__syncthreads();
 	__shared__ int s_step[MAX_SAMPLED], s_nsamp[MAX_SAMPLED];
 	if (threadIdx.x < 64) {
 		const int n_new = s_nnew;
 		// after merge passes (one run out of more than eight chunks) the result ping-pongs; otherwise the sorted run(s) are in rec0
-		make_plan_wave(d.q, s_qmeta, (nc == 0 && n_new > SORT_CHUNK && new_in_rec1) ? d.rec1 : d.rec0, n_new, nc, s_plan, threadIdx.x);
+		make_plan_wave(d.q.levels, s_cap, s_buf, s_qmeta, (nc == 0 && n_new > SORT_CHUNK && new_in_rec1) ? d.rec1 : d.rec0, n_new, nc, s_plan, threadIdx.x);
 		wave_lds_fence();
 		// the coarse index's geometry (below), one sampled run per lane: the two divisions per run cost every thread of the
 		// workgroup 2 us of instructions when each of them worked them out for all eleven runs
@@ -917,6 +932,7 @@ template <bool SHARDED>
 __device__ __forceinline__ void end_body(const AstarDev &d, int new_in_rec1, int count_iteration, int rows_evaluated = 0)
 {
 	__shared__ int32_t s_meta[4 * QL], s_old[4 * QL], s_ctr[C_COUNT];
+	__shared__ uint32_t s_cap[QL];
 	__shared__ int s_ncand, s_nexp;
 	__shared__ double s_elapsed;
 	__shared__ Rec s_heads[POP_LDS];
@@ -925,6 +941,7 @@ __device__ __forceinline__ void end_body(const AstarDev &d, int new_in_rec1, int
 	// works on LDS only (as dependent global round trips it cost more than every other kernel of the iteration)
 	if (tid < C_COUNT) s_ctr[tid] = d.ctr[tid];
 	else if (tid >= 64 && tid < 64 + 4 * QL) s_old[tid - 64] = d.q.meta[tid - 64];
+	else if (tid >= 128 && tid < 128 + QL) s_cap[tid - 128] = d.q.cap[tid - 128];   // (kernel-argument memory, indexed by the lane: in the same round trip)
 	__syncthreads();
 	const int n_pop = s_ctr[C_NPOP];
 	if (!SHARDED && !s_ctr[C_WON]) {
@@ -947,9 +964,40 @@ __device__ __forceinline__ void end_body(const AstarDev &d, int new_in_rec1, int
 			}
 		}
 	}
-	if (tid == 0) {
+	// The queue's new state, one level per lane of the first wave (what k_queue_insert's plan of this iteration said: same inputs), then
+	// the counters by its first lane.  (One thread walking the levels through LDS was 1.9 us of this kernel, and 4 us while it kept a
+	// whole MergePlan -- 272 bytes of scratch memory -- for the two numbers it needs of it.)
+	if (tid < 64) {
+		const int lane = tid, levels = d.q.levels;
 		const int n_new_all = s_ctr[C_NNEW];
 		const int n_new = min(n_new_all, d.Kpad);                          // what the sort / insert launches of this iteration covered
+		const bool is_level = lane < levels;
+		const int lv = is_level ? lane : 0;
+		int head = s_old[Q_HEAD * QL + lv] + s_old[Q_TAKE * QL + lv], len = s_old[Q_LEN * QL + lv], cur = s_old[Q_CUR * QL + lv];
+		int t = -1, total = 0;                                             // the merge's target level and size (make_plan)
+		if (n_new > 0) {
+			int incl = is_level ? len - head : 0;
+			#pragma unroll
+			for (int off = 1; off < 16; off <<= 1) {
+				const int v = __shfl_up(incl, off);
+				if (lane >= off) incl += v;
+			}
+			const int sum = n_new + incl;
+			const unsigned long long fits = __ballot(is_level && (uint32_t)sum <= s_cap[lv]);
+			t = fits ? __ffsll((long long)fits) - 1 : levels - 1;
+			total = __shfl(sum, t);
+		}
+		if (!is_level) { head = 0; len = 0; cur = 0; }
+		else {
+			if (lane < t) { head = 0; len = 0; }
+			else if (lane == t) { head = 0; len = total; cur ^= 1; }
+			if (head >= len) { head = 0; len = 0; }
+		}
+		if (lane < QL) { s_meta[Q_HEAD * QL + lane] = head; s_meta[Q_LEN * QL + lane] = len; s_meta[Q_CUR * QL + lane] = cur; s_meta[Q_TAKE * QL + lane] = 0; }
+		int open = len - head;
+		#pragma unroll
+		for (int m = 1; m < 16; m <<= 1) open += __shfl_xor(open, m);     // (QL <= 16 levels, the other lanes hold 0)
+	  if (lane == 0) {
 		if (SHARDED) {
 			// The driver evaluates the net on a FIXED number of rows (its expected share of the 12 N children plus a margin,
 			// librubiks_amd/solving/sharded.py net_rows) instead of waiting for this count on the host.  More new states than rows:
@@ -963,18 +1011,6 @@ __device__ __forceinline__ void end_body(const AstarDev &d, int new_in_rec1, int
 			if (t0 == 0) { t0 = now ? now : 1; s_ctr[C_CLOCK0] = (int32_t)(uint32_t)t0; s_ctr[C_CLOCK0 + 1] = (int32_t)(uint32_t)(t0 >> 32); }
 			s_elapsed = (double)(now - t0) * 1e-8;
 		}
-		struct { int t, total; } p;                                      // (what k_queue_insert's plan of this iteration said: same inputs)
-		plan_target(d.q, s_old, n_new, p.t, p.total);
-		int open = 0;
-		for (int j = 0; j < d.q.levels; j++) {
-			int head = s_old[Q_HEAD * QL + j] + s_old[Q_TAKE * QL + j], len = s_old[Q_LEN * QL + j], cur = s_old[Q_CUR * QL + j];
-			if (j < p.t) { head = 0; len = 0; }
-			else if (j == p.t) { head = 0; len = p.total; cur ^= 1; }
-			if (head >= len) { head = 0; len = 0; }
-			s_meta[Q_HEAD * QL + j] = head; s_meta[Q_LEN * QL + j] = len; s_meta[Q_CUR * QL + j] = cur; s_meta[Q_TAKE * QL + j] = 0;
-			open += len - head;
-		}
-		for (int j = d.q.levels; j < QL; j++) { s_meta[Q_HEAD * QL + j] = 0; s_meta[Q_LEN * QL + j] = 0; s_meta[Q_CUR * QL + j] = 0; s_meta[Q_TAKE * QL + j] = 0; }
 		const bool ran = SHARDED ? s_ctr[C_DONE] == 0 : n_pop > 0;
 		if (ran && count_iteration) s_ctr[C_ITERS] += 1;
 		s_ctr[C_EPOCH] += 1;                                             // look-back words of this launch sequence expire
@@ -994,6 +1030,7 @@ __device__ __forceinline__ void end_body(const AstarDev &d, int new_in_rec1, int
 		if (!SHARDED) s_ctr[C_NPOP] = done ? 0 : n_cand;
 		else s_ctr[C_NPOP] = 0;                                          // decided after the all-gather (k_shard_decide)
 		s_ncand = n_cand; s_nexp = n_exp;
+	  }
 	}
 	__syncthreads();
 	if (tid < C_COUNT) d.ctr[tid] = s_ctr[tid];
