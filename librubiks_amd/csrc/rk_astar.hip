@@ -374,7 +374,7 @@ void k_expand_lookup(AstarDev d)
 __global__ __launch_bounds__(256)
 void kb_expand_lookup(const AstarDev *__restrict__ devs)
 {
-	const AstarDev d = devs[blockIdx.y];              // search blockIdx.y of the batch (rk_astarb_*)
+	const AstarDev &d = devs[blockIdx.y];              // search blockIdx.y of the batch (rk_astarb_*)
 	expand_lookup_body(d);
 }
 
@@ -517,7 +517,7 @@ template <int ELEM_BYTES, bool SHARDED>
 __global__ __launch_bounds__(256)
 void kb_new_rows(const AstarDev *__restrict__ devs, u32x4 *out, uint32_t one_bits, const uint8_t *recv, const int32_t *__restrict__ row_off)
 {
-	const AstarDev d = devs[blockIdx.y];              // search blockIdx.y of the batch (rk_astarb_*)
+	const AstarDev &d = devs[blockIdx.y];              // search blockIdx.y of the batch (rk_astarb_*)
 	// this search's rows of the shared net batch: 480 elements (30 * ELEM_BYTES 16-byte chunks) or 20 bytes (5/4 chunks) each
 	const size_t first_row = row_off != nullptr ? (size_t)row_off[blockIdx.y] : (size_t)blockIdx.y * d.K;
 	if (out != nullptr) out += ELEM_BYTES == 0 ? first_row * 5 / 4 : first_row * 30 * ELEM_BYTES;
@@ -617,7 +617,7 @@ template <bool SHARDED>
 __global__ __launch_bounds__(ASCAN)
 void kb_append(const AstarDev *__restrict__ devs, const uint8_t *recv)
 {
-	const AstarDev d = devs[blockIdx.y];              // search blockIdx.y of the batch (rk_astarb_*)
+	const AstarDev &d = devs[blockIdx.y];              // search blockIdx.y of the batch (rk_astarb_*)
 	append_body<SHARDED>(d, recv);
 }
 
@@ -737,7 +737,7 @@ template <int CHUNK>
 __global__ __launch_bounds__(CHUNK / 2)
 void kb_records_sort(const AstarDev *__restrict__ devs, const float *values, const int32_t *__restrict__ row_off)
 {
-	const AstarDev d = devs[blockIdx.y];              // search blockIdx.y of the batch (rk_astarb_*)
+	const AstarDev &d = devs[blockIdx.y];              // search blockIdx.y of the batch (rk_astarb_*)
 	const size_t first_row = row_off != nullptr ? (size_t)row_off[blockIdx.y] : (size_t)blockIdx.y * d.K;
 	values = reinterpret_cast<const float *>(reinterpret_cast<const char *>(values) + first_row * (d.values_bf16 ? 2 : 4));
 	records_sort_body<CHUNK>(d, values);
@@ -767,7 +767,7 @@ __global__ void k_merge_pass(AstarDev d, int L, int from)
 }
 __global__ void kb_merge_pass(const AstarDev *__restrict__ devs, int L, int from)
 {
-	const AstarDev d = devs[blockIdx.y];              // search blockIdx.y of the batch (rk_astarb_*)
+	const AstarDev &d = devs[blockIdx.y];              // search blockIdx.y of the batch (rk_astarb_*)
 	merge_pass_body(d, L, from);
 }
 
@@ -920,7 +920,7 @@ template <bool SHARDED>
 __global__ __launch_bounds__(256)
 void kb_queue_insert(const AstarDev *__restrict__ devs, int new_in_rec1)
 {
-	const AstarDev d = devs[blockIdx.y];              // search blockIdx.y of the batch (rk_astarb_*)
+	const AstarDev &d = devs[blockIdx.y];              // search blockIdx.y of the batch (rk_astarb_*)
 	queue_insert_body<SHARDED>(d, new_in_rec1);
 }
 
@@ -1061,7 +1061,7 @@ template <bool SHARDED>
 __global__ __launch_bounds__(1024)
 void kb_end(const AstarDev *__restrict__ devs, int new_in_rec1, int count_iteration)
 {
-	const AstarDev d = devs[blockIdx.y];              // search blockIdx.y of the batch (rk_astarb_*)
+	const AstarDev &d = devs[blockIdx.y];              // search blockIdx.y of the batch (rk_astarb_*)
 	end_body<SHARDED>(d, new_in_rec1, count_iteration);
 }
 
@@ -1112,7 +1112,7 @@ void k_shard_heads(AstarDev d)
 __global__ __launch_bounds__(256)
 void kb_pop_wide(const AstarDev *__restrict__ devs)
 {
-	const AstarDev d = devs[blockIdx.y];              // search blockIdx.y of the batch (rk_astarb_*)
+	const AstarDev &d = devs[blockIdx.y];              // search blockIdx.y of the batch (rk_astarb_*)
 	pop_wide_body(d);
 }
 
