@@ -50,7 +50,9 @@ extern "C" {
 #define RK_OH_STATES 3   /* engines only: hand the net the 20-byte states themselves (first layer fused, rk_ohl_*) */
 
 #define RK_OHL_GATHER 0  /* exact float32 gather-sum through an LDS-resident weight slice */
-#define RK_OHL_MFMA   1  /* bf16 MFMA with the one-hot operand synthesised in registers */
+#define RK_OHL_MFMA   1  /* bf16 MFMA with the one-hot operand synthesised in registers; the form follows the batch size */
+#define RK_OHL_MFMA_DIRECT 2  /* ... always the few-rows form: one 32 x 32 output tile per wave, weights straight from global memory */
+#define RK_OHL_MFMA_TILED  3  /* ... always the many-rows form: a 64-column weight tile resident in LDS (same bits as the direct form) */
 /* epilogue activation of the fused first layer (rk_ohl_set_epilogue) */
 #define RK_OHL_ACT_NONE 0
 #define RK_OHL_ACT_ELU  1  /* x > 0 ? x : alpha (exp(x) - 1)          nn.ELU, the reference's default, model.py:30 */
@@ -193,7 +195,9 @@ int rk_as_oh(int repr, const int8_t *d_states, void *d_out, int out_dtype, size_
  * H must be a multiple of 64.  rk_ohl_forward: d_out (n, H) row-major, 16-byte aligned.
  *   RK_OHL_GATHER  y = ((b + w_0) + w_1) + ... + w_19 with float32 adds in that order (w_i = row 24 i + state[i] of W^T):
  *                  exact and reproducible; out_dtype RK_OH_F32 or RK_OH_BF16 (rounded to nearest even at the end)
- *   RK_OHL_MFMA    bf16 weights, float32 accumulation on the matrix cores, out_dtype RK_OH_BF16 */
+ *   RK_OHL_MFMA    bf16 weights, float32 accumulation on the matrix cores, out_dtype RK_OH_BF16.  Two forms with identical
+ *                  results: up to 1 536 rows (a search step's batch) every wave computes one output tile from weights it
+ *                  reads itself; beyond, workgroups keep a weight tile in LDS.  RK_OHL_MFMA_DIRECT / _TILED force one. */
 typedef struct rk_ohl rk_ohl_t;
 int rk_ohl_create(rk_ohl_t **out, const void *d_weight, int w_dtype, const void *d_bias, int H, void *stream);
 int rk_ohl_destroy(rk_ohl_t *h);

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "librubiks_hip.so")
 
 REPR_2024, REPR_686 = 0, 1
 OH_F32, OH_F16, OH_BF16, OH_STATES = 0, 1, 2, 3
-OHL_GATHER, OHL_MFMA = 0, 1
+OHL_GATHER, OHL_MFMA, OHL_MFMA_DIRECT, OHL_MFMA_TILED = 0, 1, 2, 3
 OHL_ACT_NONE, OHL_ACT_ELU, OHL_ACT_RELU = 0, 1, 2
 INT64_MAX = (1 << 63) - 1
 

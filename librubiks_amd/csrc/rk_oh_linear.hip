@@ -18,7 +18,14 @@
 //                       a ds_read_b128 group hit 16 different bank quads); accumulators start at the bias; the epilogue
 //                       rounds to bf16 (nearest even) and goes through LDS so that a wave stores whole 128-byte rows.
 //
-// Which one is faster where is measured by benchmarks/oh_linear.py (profiles/r02_oh_linear.json).
+//   MFMA, few rows      (round 5) the LDS tile pays when many row tiles reuse it.  A search step's batch is a few hundred rows
+//                       (256 trees of an MCTS step, a sharded rank's 1 344): there 64 workgroups each spend most of their
+//                       time filling 61 KB of LDS for one pass.  k_ohl_mfma_direct gives every WAVE one 32 x 32 output tile
+//                       and loads its thirty B fragments straight from a fragment-major copy of W (one contiguous 1 KB per
+//                       wave instruction, all thirty in flight at once): no W in LDS, no barrier behind a load loop, 4 x as
+//                       many workgroups.  Same MFMA, same k order, same epilogue arithmetic: bit-identical to the tiled form.
+//
+// Which one is faster where is measured by benchmarks/oh_linear.py (profiles/r02_oh_linear.json, r05_oh_linear_small.json).
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <cstring>
@@ -32,6 +39,7 @@ namespace rk {
 
 constexpr int OHL_K = 480;
 constexpr int OHL_TN = 64;                   // output columns per workgroup (both routes)
+constexpr size_t OHL_DIRECT_MAX_ROWS = 1536; // RK_OHL_MFMA: batches up to here take the direct form (one output tile per wave)
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -53,7 +61,9 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float x)
 }
 
 // weight preparation: W (H, 480) in f32 or bf16 -> W^T (480, H) f32 and W (H, 480) bf16
-__global__ void k_ohl_prepare(const void *w, int w_is_bf16, int H, float *wt_f32, uint16_t *w_bf16)
+// w_frag: the same bf16 values in the order the direct kernel's waves read them -- [column tile of 32][k-step][lane = 32 h + r]
+// eight values each: W[32 ct + r][16 ks + 8 h .. + 7], i.e. lane (r, h)'s B operand of v_mfma_f32_32x32x16_bf16 at k-step ks.
+__global__ void k_ohl_prepare(const void *w, int w_is_bf16, int H, float *wt_f32, uint16_t *w_bf16, uint16_t *w_frag)
 {
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= (size_t)H * OHL_K) return;
@@ -62,7 +72,10 @@ __global__ void k_ohl_prepare(const void *w, int w_is_bf16, int H, float *wt_f32
 	if (w_is_bf16) v = __builtin_bit_cast(float, (uint32_t)reinterpret_cast<const uint16_t *>(w)[i] << 16);
 	else v = reinterpret_cast<const float *>(w)[i];
 	wt_f32[k * (size_t)H + h] = v;
-	w_bf16[i] = f32_to_bf16_rne(v);
+	const uint16_t b = f32_to_bf16_rne(v);
+	w_bf16[i] = b;
+	const size_t ct = h >> 5, r = h & 31, ks = k >> 4, hh = (k >> 3) & 1, e = k & 7;
+	w_frag[(((ct * (OHL_K / 16) + ks) * 64) + 32 * hh + r) * 8 + e] = b;
 }
 
 __global__ void k_ohl_bias(const void *b, int b_is_bf16, int H, float *out)
@@ -265,6 +278,82 @@ void k_ohl_mfma(const uint32_t *__restrict__ states, const uint16_t *__restrict_
 	}
 }
 
+// ---- route MFMA, few rows: one 32 x 32 output tile per wave, B fragments straight from global memory -----------------
+constexpr int OHL_SROW = 80;                 // bytes per LDS row of a wave's output staging (32 bf16 + 16 B pad)
+
+// Workgroup L of the 1-D grid: column group cg = L % col_groups (four 32-column tiles, one per wave), row tile L / col_groups.
+// Workgroups go to the XCDs round-robin by L, so with col_groups a multiple of 8 every column group always lands on the same
+// XCD: its 120 KB of fragments come from the fabric once and serve the other row tiles from that XCD's L2.
+template <int ACT, bool AFFINE>
+__global__ __launch_bounds__(256)
+void k_ohl_mfma_direct(const uint32_t *__restrict__ states, const u32x4 *__restrict__ wfrag, const float *__restrict__ bias, uint16_t *__restrict__ out,
+                       size_t n, int H, unsigned col_groups, float alpha, const float *__restrict__ scale, const float *__restrict__ shift)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t s_d[4][32 * OHL_SROW];       // 10 240 B
+	__shared__ u32x4 s_frag[9];          // A fragments, as in k_ohl_mfma
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
+	const unsigned cg = blockIdx.x % col_groups;
+	const size_t m0 = (size_t)(blockIdx.x / col_groups) * 32;
+	const int ct = (int)cg * 4 + wv, c0 = ct * 32;
+	const bool live = c0 < H;                                                     // H is a multiple of 64: the last group may hold two tiles
+	// everything this wave will ever read from memory, requested before anything waits: thirty 16-byte fragments and one state
+	u32x4 B[OHL_K / 16];
+	uint32_t s5[5];
+	{
+		const u32x4 *wf = wfrag + (size_t)(live ? ct : 0) * (OHL_K / 16) * 64 + lane;
+		#pragma unroll
+		for (int ks = 0; ks < OHL_K / 16; ks++) B[ks] = wf[ks * 64];
+		const size_t row = m0 + r < n ? m0 + r : n - 1;                           // tail rows repeat the last row (never stored)
+		#pragma unroll
+		for (int j = 0; j < 5; j++) s5[j] = states[row * 5 + j];
+	}
+	const int col = live ? c0 + r : r;
+	const float bias0 = bias[col];
+	float sc0 = 1.0f, sh0 = 0.0f;
+	if (AFFINE) { sc0 = scale[col]; sh0 = shift[col]; }
+	if (tid < 9) {
+		const uint32_t one = 0x3F80u << (16 * (tid & 1));
+		const int slot = tid >> 1;
+		s_frag[tid] = tid < 8 ? u32x4{slot == 0 ? one : 0u, slot == 1 ? one : 0u, slot == 2 ? one : 0u, slot == 3 ? one : 0u} : u32x4{0u, 0u, 0u, 0u};
+	}
+	__syncthreads();
+	if (!live) return;
+	const uint32_t off3[3] = {h ? 8u : 0u, h ? 0u : 16u, h ? 16u : 8u};
+	f32x16 acc;
+	#pragma unroll
+	for (int v = 0; v < 16; v++) acc[v] = bias0;
+	#pragma unroll
+	for (int ks = 0; ks < OHL_K / 16; ks++) {
+		const int k_lo = 16 * ks, k_hi = 16 * ks + 8;
+		const uint32_t c_lo = (s5[(k_lo / 24) >> 2] >> (8 * ((k_lo / 24) & 3))) & 0xFFu;
+		const uint32_t c_hi = (s5[(k_hi / 24) >> 2] >> (8 * ((k_hi / 24) & 3))) & 0xFFu;
+		uint32_t rel = (h ? c_hi : c_lo) - off3[ks % 3];
+		rel = rel < 8u ? rel : 8u;
+		const bf16x8 A = __builtin_bit_cast(bf16x8, s_frag[rel]);
+		acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(bf16x8, B[ks]), acc, 0, 0, 0);
+	}
+	// epilogue: C/D element v of lane (r, h) is row (v & 3) + 8 (v >> 2) + 4 h, column r; through the wave's staging area so
+	// that the 32 x 64-byte tile leaves as 16-byte stores (two per lane) instead of sixteen 2-byte ones
+	uint8_t *stage = s_d[wv];
+	#pragma unroll
+	for (int v = 0; v < 16; v++) {
+		const int i = (v & 3) + 8 * (v >> 2) + 4 * h;
+		f32x2 pair = {acc[v], 0.0f};
+		if (ACT != 0) pair.x = ohl_act<ACT, true>(pair.x, alpha);
+		if (AFFINE) pair.x = pair.x * sc0 + sh0;
+		const uint32_t packed = __builtin_bit_cast(uint32_t, __builtin_convertvector(pair, bf16x2));
+		reinterpret_cast<uint16_t *>(stage + i * OHL_SROW)[r] = (uint16_t)packed;
+	}
+	wave_lds_fence();
+	#pragma unroll
+	for (int it = 0; it < 2; it++) {                                              // 32 rows x 64 B, 16 B per lane
+		const int idx = it * 64 + lane, i = idx >> 2, ch = idx & 3;
+		const u32x4 val = *reinterpret_cast<const u32x4 *>(stage + i * OHL_SROW + ch * 16);
+		const size_t row = m0 + i;
+		if (row < n) *reinterpret_cast<u32x4 *>(out + row * (size_t)H + c0 + ch * 8) = val;
+	}
+}
+
 }  // namespace rk
 
 using namespace rk;
@@ -288,7 +377,7 @@ static bool ohl_rt4(size_t)
 struct rk_ohl {
 	int H = 0;
 	float *wt_f32 = nullptr, *bias = nullptr;
-	uint16_t *w_bf16 = nullptr;
+	uint16_t *w_bf16 = nullptr, *w_frag = nullptr;    // (H, 480) row-major for the LDS-tiled form; fragment-major for the direct form
 	int act = RK_OHL_ACT_NONE;                    // epilogue (rk_ohl_set_epilogue)
 	float alpha = 1.0f;
 	float *affine = nullptr;                      // scale[H] then shift[H], or null
@@ -306,10 +395,11 @@ int rk_ohl_create(rk_ohl_t **out, const void *d_weight, int w_dtype, const void 
 	hipStream_t st = (hipStream_t)stream;
 	hipError_t e = hipMalloc((void **)&h->wt_f32, (size_t)H * OHL_K * sizeof(float));
 	if (e == hipSuccess) e = hipMalloc((void **)&h->w_bf16, (size_t)H * OHL_K * sizeof(uint16_t));
+	if (e == hipSuccess) e = hipMalloc((void **)&h->w_frag, (size_t)H * OHL_K * sizeof(uint16_t));
 	if (e == hipSuccess) e = hipMalloc((void **)&h->bias, (size_t)H * sizeof(float));
 	if (e != hipSuccess) { rk_ohl_destroy(h); return fail(RK_EHIP, "rk_ohl_create: hipMalloc failed: %s", hipGetErrorString(e)); }
 	const size_t total = (size_t)H * OHL_K;
-	hipLaunchKernelGGL(k_ohl_prepare, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_weight, w_dtype == RK_OH_BF16 ? 1 : 0, H, h->wt_f32, h->w_bf16);
+	hipLaunchKernelGGL(k_ohl_prepare, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_weight, w_dtype == RK_OH_BF16 ? 1 : 0, H, h->wt_f32, h->w_bf16, h->w_frag);
 	hipLaunchKernelGGL(k_ohl_bias, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, st, d_bias, w_dtype == RK_OH_BF16 ? 1 : 0, H, h->bias);
 	RK_HIP(hipGetLastError());
 	RK_HIP(hipStreamSynchronize(st));              // the caller's weight tensor may go away
@@ -320,7 +410,7 @@ int rk_ohl_create(rk_ohl_t **out, const void *d_weight, int w_dtype, const void 
 int rk_ohl_destroy(rk_ohl_t *h)
 {
 	if (!h) return RK_OK;
-	(void)hipFree(h->wt_f32); (void)hipFree(h->w_bf16); (void)hipFree(h->bias); (void)hipFree(h->affine);
+	(void)hipFree(h->wt_f32); (void)hipFree(h->w_bf16); (void)hipFree(h->w_frag); (void)hipFree(h->bias); (void)hipFree(h->affine);
 	delete h;
 	return RK_OK;
 }
@@ -355,10 +445,30 @@ int rk_ohl_forward(rk_ohl_t *h, const int8_t *d_states, void *d_out, int out_dty
 	if (!d_states || !d_out) return fail(RK_EINVAL, "rk_ohl_forward: null pointer");
 	if ((reinterpret_cast<uintptr_t>(d_states) & 3) || (reinterpret_cast<uintptr_t>(d_out) & 15))
 		return fail(RK_EINVAL, "rk_ohl_forward: states must be 4-byte and the output 16-byte aligned");
-	if (route != RK_OHL_GATHER && route != RK_OHL_MFMA) return fail(RK_EINVAL, "rk_ohl_forward: unknown route %d", route);
+	if (route != RK_OHL_GATHER && route != RK_OHL_MFMA && route != RK_OHL_MFMA_DIRECT && route != RK_OHL_MFMA_TILED)
+		return fail(RK_EINVAL, "rk_ohl_forward: unknown route %d", route);
 	if (out_dtype != RK_OH_F32 && out_dtype != RK_OH_BF16) return fail(RK_EINVAL, "rk_ohl_forward: output must be float32 or bfloat16");
-	if (route == RK_OHL_MFMA && out_dtype != RK_OH_BF16) return fail(RK_EINVAL, "rk_ohl_forward: the MFMA route writes bfloat16");
+	if (route != RK_OHL_GATHER && out_dtype != RK_OH_BF16) return fail(RK_EINVAL, "rk_ohl_forward: the MFMA route writes bfloat16");
 	hipStream_t st = (hipStream_t)stream;
+	// RK_OHL_MFMA picks the form by the batch: one output tile per wave straight from global memory while the waves of a batch
+	// do not outnumber what the chip holds at once by much, the LDS-resident W tile (reused by many row tiles) beyond that.
+	// Both give the same bits.  OHL_DIRECT_MAX_ROWS: the forms cross between 1 536 and 2 048 rows at H = 4096 (profiles/r05_oh_linear_small.json).
+	const bool direct = route == RK_OHL_MFMA_DIRECT || (route == RK_OHL_MFMA && n <= OHL_DIRECT_MAX_ROWS);
+	if (route != RK_OHL_GATHER) route = RK_OHL_MFMA;
+	if (direct) {
+		const unsigned col_groups = (unsigned)((h->H + 127) / 128);
+		const size_t row_tiles = (n + 31) / 32;
+		if (row_tiles * col_groups > 0x7FFFFFFFull) return fail(RK_EINVAL, "rk_ohl_forward: %zu rows are too many for the direct form", n);
+		const dim3 grid((unsigned)(row_tiles * col_groups));
+		const float *scale = h->affine, *shift = h->affine ? h->affine + h->H : nullptr;
+		#define RK_OHL_DIRECT_GO(ACT, AFF) hipLaunchKernelGGL((k_ohl_mfma_direct<ACT, AFF>), grid, dim3(256), 0, st, \
+			(const uint32_t *)d_states, (const u32x4 *)h->w_frag, h->bias, (uint16_t *)d_out, n, h->H, col_groups, h->alpha, scale, shift)
+		if (scale) { if (h->act == RK_OHL_ACT_ELU) RK_OHL_DIRECT_GO(1, true); else if (h->act == RK_OHL_ACT_RELU) RK_OHL_DIRECT_GO(2, true); else RK_OHL_DIRECT_GO(0, true); }
+		else       { if (h->act == RK_OHL_ACT_ELU) RK_OHL_DIRECT_GO(1, false); else if (h->act == RK_OHL_ACT_RELU) RK_OHL_DIRECT_GO(2, false); else RK_OHL_DIRECT_GO(0, false); }
+		#undef RK_OHL_DIRECT_GO
+		RK_HIP(hipGetLastError());
+		return RK_OK;
+	}
 	const unsigned col_tiles = (unsigned)(h->H / OHL_TN);
 	// about one workgroup per CU (gather: 120 KB of LDS each) or two (MFMA): the weight slice is loaded once per workgroup
 	const bool wide = route == RK_OHL_MFMA && ohl_rt4(n);

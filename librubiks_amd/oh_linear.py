@@ -6,7 +6,8 @@ first `nn.Linear(480, H)` of `Model`, librubiks/model.py:127 / :150).
     y = first(states)                              # states: (n, 20) int8 on the GPU -> (n, H); no (n, 480) one-hot in HBM
 
 `route="gather"` is the exact float32 path (a fixed-order sum of the 20 selected weight rows + bias); `route="mfma"` runs on
-the matrix cores in bf16 with the one-hot operand synthesised in registers.  `fuse_first_linear(net)` wraps a net of the
+the matrix cores in bf16 with the one-hot operand synthesised in registers (`"mfma_direct"` / `"mfma_tiled"` force one of its two
+forms -- few rows / many rows, same bits -- which `"mfma"` picks by the batch size).  `fuse_first_linear(net)` wraps a net of the
 reference's shape (`shared_net` = Sequential starting with a Linear, `policy_net`, `value_net`) into a callable that takes
 states instead of one-hot rows: `AStar(..., fused_first_layer=True)` and `adi_traindata(..., fused_first_layer=True)` use it.
 
@@ -22,7 +23,7 @@ import torch
 
 from librubiks_amd import _ffi
 
-_ROUTES = {"gather": _ffi.OHL_GATHER, "mfma": _ffi.OHL_MFMA}
+_ROUTES = {"gather": _ffi.OHL_GATHER, "mfma": _ffi.OHL_MFMA, "mfma_direct": _ffi.OHL_MFMA_DIRECT, "mfma_tiled": _ffi.OHL_MFMA_TILED}
 _CODES = {torch.float32: _ffi.OH_F32, torch.bfloat16: _ffi.OH_BF16}
 
 
@@ -79,7 +80,7 @@ class OhLinear:
 	def from_pointer(self, d_states: int, n: int, out: torch.Tensor = None, route: str = None, device=None) -> torch.Tensor:
 		"""The layer on n 20-byte states at a device address (an engine's own buffer: rk_mcts_children), no tensor around them."""
 		route = route or self.route
-		dtype = torch.bfloat16 if route == "mfma" else self.dtype
+		dtype = torch.bfloat16 if route.startswith("mfma") else self.dtype
 		if out is None:
 			out = torch.empty((n, self.out_features), dtype=dtype, device=device or "cuda")
 		_ffi.check(_ffi.lib().rk_ohl_forward(self._h, d_states, out.data_ptr(), _CODES[out.dtype], n, _ROUTES[route], _ffi.stream_ptr()))

@@ -64,6 +64,38 @@ def test_mfma_route_matches_bf16_linear(n, H):
 	assert g.dtype == torch.bfloat16 and torch.allclose(g.float(), ref, rtol=2.0 ** -7, atol=1e-6)
 
 
+@pytest.mark.parametrize("n,H", [(1, 64), (12, 4096), (31, 128), (33, 192), (256, 4096), (1000, 4096), (1536, 4096), (1537, 4096), (3072, 4096), (4099, 512)])
+@pytest.mark.parametrize("act,affine", [(None, False), ("elu", True), ("relu", False)])
+def test_mfma_forms_give_the_same_bits(n, H, act, affine):
+	"""Round 5: the MFMA route has two forms -- a wave per 32 x 32 output tile with its weights straight from global memory (few rows:
+	a search step's batch) and the LDS-resident weight tile (many rows).  Same instruction, same k order, same epilogue: every
+	output equal bit for bit, whatever the batch (ragged row tiles, a last column group of two tiles at H = 192, both sides of the
+	1 536-row switch), and `route="mfma"` is one of the two."""
+	lin = _layer(H, dtype=torch.bfloat16, seed=n + H)
+	states = torch.from_numpy(random_walk(n, 15, seed=n)).cuda()
+	layer = OhLinear(lin, route="mfma")
+	if act or affine:
+		bn = None
+		if affine:
+			bn = torch.nn.BatchNorm1d(H).cuda().eval()
+			with torch.no_grad():
+				bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0); bn.weight.normal_(); bn.bias.normal_()
+		layer.set_epilogue({"elu": torch.nn.ELU(), "relu": torch.nn.ReLU(), None: None}[act], bn)
+	# guard rows behind the outputs: neither form writes past row n
+	outs = {r: torch.full((n + 2, H), 7.0, dtype=torch.bfloat16, device="cuda") for r in ("mfma_direct", "mfma_tiled", "mfma")}
+	for r, o in outs.items():
+		layer(states, out=o[:n], route=r)
+	torch.cuda.synchronize()
+	for r, o in outs.items():
+		assert (o[n:] == 7.0).all(), r
+	assert torch.equal(outs["mfma_direct"][:n].view(torch.int16), outs["mfma_tiled"][:n].view(torch.int16))
+	assert torch.equal(outs["mfma"][:n].view(torch.int16), outs["mfma_tiled"][:n].view(torch.int16))
+	if not act and not affine:                     # and the layer itself, as test_mfma_route_matches_bf16_linear states it
+		ref = torch.nn.functional.linear(cube.device.as_oh(states).to(torch.bfloat16), lin.weight, lin.bias).float()
+		got = outs["mfma_direct"][:n].float()
+		assert ((got - ref).abs() <= 2.0 ** -6 * ref.abs() + 2.0 ** -6).all()
+
+
 def test_fused_net_in_astar_and_adi():
 	"""The fused first layer behind the A* engine (states instead of one-hot rows) and ADI: same search / same targets."""
 	from benchmarks.nets import FcSmall
