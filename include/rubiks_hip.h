@@ -196,7 +196,7 @@ int rk_as_oh(int repr, const int8_t *d_states, void *d_out, int out_dtype, size_
  *   RK_OHL_GATHER  y = ((b + w_0) + w_1) + ... + w_19 with float32 adds in that order (w_i = row 24 i + state[i] of W^T):
  *                  exact and reproducible; out_dtype RK_OH_F32 or RK_OH_BF16 (rounded to nearest even at the end)
  *   RK_OHL_MFMA    bf16 weights, float32 accumulation on the matrix cores, out_dtype RK_OH_BF16.  Two forms with identical
- *                  results: up to 1 536 rows (a search step's batch) every wave computes one output tile from weights it
+ *                  results: up to 768 rows (a search step's batch) every wave computes one output tile from weights it
  *                  reads itself; beyond, workgroups keep a weight tile in LDS.  RK_OHL_MFMA_DIRECT / _TILED force one. */
 typedef struct rk_ohl rk_ohl_t;
 int rk_ohl_create(rk_ohl_t **out, const void *d_weight, int w_dtype, const void *d_bias, int H, void *stream);

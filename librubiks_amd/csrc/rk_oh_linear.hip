@@ -39,7 +39,7 @@ namespace rk {
 
 constexpr int OHL_K = 480;
 constexpr int OHL_TN = 64;                   // output columns per workgroup (both routes)
-constexpr size_t OHL_DIRECT_MAX_ROWS = 1536; // RK_OHL_MFMA: batches up to here take the direct form (one output tile per wave)
+constexpr size_t OHL_DIRECT_MAX_ROWS = 768;  // RK_OHL_MFMA: batches up to here take the direct form (one output tile per wave)
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -120,9 +120,18 @@ void k_ohl_gather(const uint32_t *__restrict__ states, const float *__restrict__
 {
 	__shared__ __attribute__((aligned(16))) float s_w[OHL_K * OHL_TN];       // 122 880 B: this workgroup's 64 columns of W^T
 	const int tid = threadIdx.x, c0 = blockIdx.x * OHL_TN;
-	for (int i = tid; i < OHL_K * (OHL_TN / 4); i += OHL_GATHER_THREADS) {
-		const int k = i >> 4, q = i & 15;
-		reinterpret_cast<f32x4 *>(s_w)[i] = *reinterpret_cast<const f32x4 *>(wt + (size_t)k * H + c0 + 4 * q);
+	{
+		// (all fifteen loads of a thread in flight before the first LDS store, as in k_ohl_mfma)
+		constexpr int W_LOADS = OHL_K * (OHL_TN / 4) / OHL_GATHER_THREADS;
+		static_assert(W_LOADS * OHL_GATHER_THREADS == OHL_K * (OHL_TN / 4), "the W^T slice divides evenly over the workgroup");
+		f32x4 w[W_LOADS];
+		#pragma unroll
+		for (int j = 0; j < W_LOADS; j++) {
+			const int i = tid + OHL_GATHER_THREADS * j, k = i >> 4, q = i & 15;
+			w[j] = *reinterpret_cast<const f32x4 *>(wt + (size_t)k * H + c0 + 4 * q);
+		}
+		#pragma unroll
+		for (int j = 0; j < W_LOADS; j++) reinterpret_cast<f32x4 *>(s_w)[tid + OHL_GATHER_THREADS * j] = w[j];
 	}
 	__syncthreads();
 	const int lane = tid & 63, wv = tid >> 6, sub = lane >> 4, q = lane & 15;
@@ -184,30 +193,14 @@ void k_ohl_mfma(const uint32_t *__restrict__ states, const uint16_t *__restrict_
 	__shared__ __attribute__((aligned(16))) uint8_t s_d[4][32 * OHL_DROW];       // 18 432 B
 	__shared__ u32x4 s_frag[9];          // A fragments: entry p < 8 = eight bf16 zeros with 1.0 at position p, entry 8 = all zeros
 	const int tid = threadIdx.x, c0 = blockIdx.x * OHL_TN;
-	if (tid < 9) {
-		const uint32_t one = 0x3F80u << (16 * (tid & 1));
-		const int slot = tid >> 1;
-		s_frag[tid] = tid < 8 ? u32x4{slot == 0 ? one : 0u, slot == 1 ? one : 0u, slot == 2 ? one : 0u, slot == 3 ? one : 0u} : u32x4{0u, 0u, 0u, 0u};
-	}
-	for (int i = tid; i < OHL_TN * 60; i += 256) {
-		const int row = i / 60, ch = i - row * 60;
-		*reinterpret_cast<u32x4 *>(s_w + row * OHL_WROW + ch * 16) = *reinterpret_cast<const u32x4 *>(wb + (size_t)(c0 + row) * OHL_K + ch * 8);
-	}
-	__syncthreads();
 	const int lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
-	// offset of this lane's eight columns inside their cubie, by k-step mod 3: (16 ks + 8 h) % 24
-	const uint32_t off3[3] = {h ? 8u : 0u, h ? 0u : 16u, h ? 16u : 8u};
-	const float bias0 = bias[c0 + r], bias1 = bias[c0 + 32 + r];
-	float sc0 = 1.0f, sc1 = 1.0f, sh0 = 0.0f, sh1 = 0.0f;
-	if (AFFINE) { sc0 = scale[c0 + r]; sc1 = scale[c0 + 32 + r]; sh0 = shift[c0 + r]; sh1 = shift[c0 + 32 + r]; }
-	const uint8_t *wrow0 = s_w + r * OHL_WROW + 16 * h, *wrow1 = s_w + (32 + r) * OHL_WROW + 16 * h;
-	uint8_t *stage = s_d[wv];
 	const size_t r_begin = (size_t)blockIdx.y * rows_per_group;
 	const size_t r_end = r_begin + rows_per_group < n ? r_begin + rows_per_group : n;
 	// A wave multiplies RT 32-row tiles per pass (rows m0 .. m0 + 32 RT - 1): the B fragments it reads from LDS serve all
 	// of them (per k-step RT + 2 LDS reads feed 2 RT MFMAs; with one tile per pass the LDS pipe was co-limiting with the
 	// matrix pipe) and 2 RT independent accumulator chains keep the MFMAs issuing back to back.  The states of the NEXT pass
-	// are requested as soon as the multiplication is done with the current ones, so they land during the epilogue.
+	// are requested as soon as the multiplication is done with the current ones, so they land during the epilogue; those of the
+	// FIRST pass (and the per-column constants) are requested before the W tile, so that they travel with it.
 	uint32_t s5[RT][5];
 	auto request = [&](size_t m0) {
 		#pragma unroll
@@ -219,6 +212,36 @@ void k_ohl_mfma(const uint32_t *__restrict__ states, const uint16_t *__restrict_
 	};
 	constexpr int WROWS = 32 * RT, PASS = 4 * WROWS;                     // rows per wave and per workgroup pass
 	if (r_begin + (size_t)wv * WROWS < r_end) request(r_begin + (size_t)wv * WROWS);
+	const float bias0 = bias[c0 + r], bias1 = bias[c0 + 32 + r];
+	float sc0 = 1.0f, sc1 = 1.0f, sh0 = 0.0f, sh1 = 0.0f;
+	if (AFFINE) { sc0 = scale[c0 + r]; sc1 = scale[c0 + 32 + r]; sh0 = shift[c0 + r]; sh1 = shift[c0 + 32 + r]; }
+	if (tid < 9) {
+		const uint32_t one = 0x3F80u << (16 * (tid & 1));
+		const int slot = tid >> 1;
+		s_frag[tid] = tid < 8 ? u32x4{slot == 0 ? one : 0u, slot == 1 ? one : 0u, slot == 2 ? one : 0u, slot == 3 ? one : 0u} : u32x4{0u, 0u, 0u, 0u};
+	}
+	{
+		// the W tile: all of a thread's fifteen 16-byte loads in flight before the first LDS store.  As a rolled loop (until round 5) this was
+		// load, wait, store fifteen times over: fifteen dependent round trips in front of every workgroup's first MFMA.
+		constexpr int W_LOADS = OHL_TN * 60 / 256;
+		static_assert(W_LOADS * 256 == OHL_TN * 60, "the W tile divides evenly over the workgroup");
+		u32x4 w[W_LOADS];
+		#pragma unroll
+		for (int j = 0; j < W_LOADS; j++) {
+			const int i = tid + 256 * j, row = i / 60, ch = i - row * 60;
+			w[j] = *reinterpret_cast<const u32x4 *>(wb + (size_t)(c0 + row) * OHL_K + ch * 8);
+		}
+		#pragma unroll
+		for (int j = 0; j < W_LOADS; j++) {
+			const int i = tid + 256 * j, row = i / 60, ch = i - row * 60;
+			*reinterpret_cast<u32x4 *>(s_w + row * OHL_WROW + ch * 16) = w[j];
+		}
+	}
+	__syncthreads();
+	// offset of this lane's eight columns inside their cubie, by k-step mod 3: (16 ks + 8 h) % 24
+	const uint32_t off3[3] = {h ? 8u : 0u, h ? 0u : 16u, h ? 16u : 8u};
+	const uint8_t *wrow0 = s_w + r * OHL_WROW + 16 * h, *wrow1 = s_w + (32 + r) * OHL_WROW + 16 * h;
+	uint8_t *stage = s_d[wv];
 	for (size_t m0 = r_begin + (size_t)wv * WROWS; m0 < r_end; m0 += PASS) {
 		f32x16 acc[RT][2];
 		#pragma unroll
@@ -452,7 +475,7 @@ int rk_ohl_forward(rk_ohl_t *h, const int8_t *d_states, void *d_out, int out_dty
 	hipStream_t st = (hipStream_t)stream;
 	// RK_OHL_MFMA picks the form by the batch: one output tile per wave straight from global memory while the waves of a batch
 	// do not outnumber what the chip holds at once by much, the LDS-resident W tile (reused by many row tiles) beyond that.
-	// Both give the same bits.  OHL_DIRECT_MAX_ROWS: the forms cross between 1 536 and 2 048 rows at H = 4096 (profiles/r05_oh_linear_small.json).
+	// Both give the same bits.  OHL_DIRECT_MAX_ROWS: the forms cross between 768 and 1 024 rows at H = 4096 (profiles/r05_oh_linear_small.json).
 	const bool direct = route == RK_OHL_MFMA_DIRECT || (route == RK_OHL_MFMA && n <= OHL_DIRECT_MAX_ROWS);
 	if (route != RK_OHL_GATHER) route = RK_OHL_MFMA;
 	if (direct) {
@@ -472,18 +495,33 @@ int rk_ohl_forward(rk_ohl_t *h, const int8_t *d_states, void *d_out, int out_dty
 	const unsigned col_tiles = (unsigned)(h->H / OHL_TN);
 	// about one workgroup per CU (gather: 120 KB of LDS each) or two (MFMA): the weight slice is loaded once per workgroup
 	const bool wide = route == RK_OHL_MFMA && ohl_rt4(n);
-	const size_t quantum = route == RK_OHL_MFMA ? (wide ? 512 : 256) : OHL_GATHER_ROWS;
-	size_t groups = (route == RK_OHL_MFMA ? 512u : 256u) / col_tiles;
-	if (groups < 1) groups = 1;
-#ifdef RK_TUNING
-	if (const char *e = getenv("RK_OHL_GROUPS")) { const long g = atol(e); if (g > 0) groups = (size_t)g; }   // benchmarks/tune_ohl.py
-#endif
-	const size_t max_groups = (n + quantum - 1) / quantum;
-	if (groups > max_groups) groups = max_groups;
-	if (groups > 65535) groups = 65535;
-	size_t rows = (n + groups - 1) / groups;
-	rows = (rows + quantum - 1) / quantum * quantum;
-	groups = (n + rows - 1) / rows;
+	// rows of a workgroup: a multiple of what its four waves multiply per pass (`quantum` = 4 waves x RT tiles x 32 rows), in as many
+	// row groups as give the chip's 2 x 256 workgroup slots one workgroup each
+	auto plan = [&](size_t quantum, size_t &groups, size_t &rows) {
+		groups = (route == RK_OHL_MFMA ? 512u : 256u) / col_tiles;
+		if (groups < 1) groups = 1;
+	#ifdef RK_TUNING
+		if (const char *e = getenv("RK_OHL_GROUPS")) { const long g = atol(e); if (g > 0) groups = (size_t)g; }   // benchmarks/tune_ohl.py
+	#endif
+		const size_t max_groups = (n + quantum - 1) / quantum;
+		if (groups > max_groups) groups = max_groups;
+		if (groups > 65535) groups = 65535;
+		rows = (n + groups - 1) / groups;
+		rows = (rows + quantum - 1) / quantum * quantum;
+		groups = (n + rows - 1) / rows;
+		// 32-row tiles the busiest SIMD multiplies: workgroups per CU (256 CUs) x passes x tiles per pass
+		return (groups * col_tiles + 255) / 256 * (rows / quantum) * (quantum / 128);
+	};
+	size_t quantum = route == RK_OHL_MFMA ? (wide ? 512 : 256) : OHL_GATHER_ROWS, groups, rows;
+	const size_t cost2 = plan(quantum, groups, rows);
+	// Three tiles per wave and pass instead of two where that balances the chip: 3 072 rows (an MCTS step of 256 trees) are 6 row groups of
+	// 512 rows with two tiles -- 384 workgroups, half of the CUs with two of them and half with one, 18.3 us -- and 8 groups of 384 rows with
+	// three: one workgroup per slot, one pass each (profiles/r05_oh_linear_small.json).  Same accumulation order per output: same bits.
+	bool three = false;
+	if (route == RK_OHL_MFMA && !wide) {
+		size_t g3, r3;
+		if (plan(384, g3, r3) < cost2) { three = true; quantum = 384; groups = g3; rows = r3; }
+	}
 	const dim3 grid(col_tiles, (unsigned)groups);
 	const float *scale = h->affine, *shift = h->affine ? h->affine + h->H : nullptr;
 	const float alpha = h->alpha;
@@ -496,7 +534,9 @@ int rk_ohl_forward(rk_ohl_t *h, const int8_t *d_states, void *d_out, int out_dty
 #else
 	#define RK_OHL_MFMA_WIDE(ACT, AFF)
 #endif
-	#define RK_OHL_MFMA_GO(ACT, AFF) do { RK_OHL_MFMA_WIDE(ACT, AFF) hipLaunchKernelGGL((k_ohl_mfma<2, ACT, AFF>), grid, dim3(256), 0, st, \
+	#define RK_OHL_MFMA_GO(ACT, AFF) do { RK_OHL_MFMA_WIDE(ACT, AFF) if (three) hipLaunchKernelGGL((k_ohl_mfma<3, ACT, AFF>), grid, dim3(256), 0, st, \
+		(const uint32_t *)d_states, h->w_bf16, h->bias, (uint16_t *)d_out, n, h->H, rows, alpha, scale, shift); \
+		else hipLaunchKernelGGL((k_ohl_mfma<2, ACT, AFF>), grid, dim3(256), 0, st, \
 		(const uint32_t *)d_states, h->w_bf16, h->bias, (uint16_t *)d_out, n, h->H, rows, alpha, scale, shift); } while (0)
 	#define RK_OHL_BY_EPILOGUE(GO, ...) do { \
 		if (scale) { if (h->act == RK_OHL_ACT_ELU) GO(__VA_ARGS__ 1, true); else if (h->act == RK_OHL_ACT_RELU) GO(__VA_ARGS__ 2, true); else GO(__VA_ARGS__ 0, true); } \

@@ -64,13 +64,13 @@ def test_mfma_route_matches_bf16_linear(n, H):
 	assert g.dtype == torch.bfloat16 and torch.allclose(g.float(), ref, rtol=2.0 ** -7, atol=1e-6)
 
 
-@pytest.mark.parametrize("n,H", [(1, 64), (12, 4096), (31, 128), (33, 192), (256, 4096), (1000, 4096), (1536, 4096), (1537, 4096), (3072, 4096), (4099, 512)])
+@pytest.mark.parametrize("n,H", [(1, 64), (12, 4096), (31, 128), (33, 192), (256, 4096), (768, 4096), (769, 4096), (1000, 4096), (1536, 4096), (3072, 4096), (3073, 4096), (6000, 2048), (4099, 512)])
 @pytest.mark.parametrize("act,affine", [(None, False), ("elu", True), ("relu", False)])
 def test_mfma_forms_give_the_same_bits(n, H, act, affine):
 	"""Round 5: the MFMA route has two forms -- a wave per 32 x 32 output tile with its weights straight from global memory (few rows:
 	a search step's batch) and the LDS-resident weight tile (many rows).  Same instruction, same k order, same epilogue: every
 	output equal bit for bit, whatever the batch (ragged row tiles, a last column group of two tiles at H = 192, both sides of the
-	1 536-row switch), and `route="mfma"` is one of the two."""
+	768-row switch; 3 072 rows take three tiles per wave and pass in the tiled form, 1 536 two), and `route="mfma"` is one of the two."""
 	lin = _layer(H, dtype=torch.bfloat16, seed=n + H)
 	states = torch.from_numpy(random_walk(n, 15, seed=n)).cuda()
 	layer = OhLinear(lin, route="mfma")
