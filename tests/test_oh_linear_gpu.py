@@ -96,6 +96,30 @@ def test_mfma_forms_give_the_same_bits(n, H, act, affine):
 		assert ((got - ref).abs() <= 2.0 ** -6 * ref.abs() + 2.0 ** -6).all()
 
 
+def test_mfma_forms_agree_on_random_shapes():
+	"""The tiled form's launcher chooses row groups, rows per group and two or three tiles per wave from (n, H); the direct form has one
+	geometry.  Sixty seeded random shapes -- every output of one form against the other's, the buffers pre-filled with DIFFERENT values so
+	that a row or column neither form wrote cannot compare equal -- plus the float32 statement of the layer on a sample of rows."""
+	rng = np.random.RandomState(20240505)
+	layers = {}
+	for case in range(60):
+		H = int(rng.choice([64, 128, 192, 320, 512, 1024, 2048, 4096]))
+		n = int(rng.choice([rng.randint(1, 400), rng.randint(400, 4000), rng.randint(4000, 20_000)]))
+		if H not in layers:
+			layers[H] = _layer(H, torch.bfloat16, seed=H)
+		lin = layers[H]
+		states = torch.from_numpy(random_walk(n, 12, seed=case)).cuda()
+		layer = OhLinear(lin, route="mfma")
+		a = torch.full((n, H), 1.0, dtype=torch.bfloat16, device="cuda")
+		b = torch.full((n, H), 2.0, dtype=torch.bfloat16, device="cuda")
+		layer(states, out=a, route="mfma_direct")
+		layer(states, out=b, route="mfma_tiled")
+		assert torch.equal(a.view(torch.int16), b.view(torch.int16)), (case, n, H)
+		pick = torch.from_numpy(rng.randint(0, n, size=min(n, 64))).cuda()
+		ref = torch.nn.functional.linear(cube.device.as_oh(states[pick]), lin.weight.float(), lin.bias.float())
+		assert torch.allclose(a[pick].float(), ref, rtol=2.0 ** -7, atol=1e-6), (case, n, H)
+
+
 def test_fused_net_in_astar_and_adi():
 	"""The fused first layer behind the A* engine (states instead of one-hot rows) and ADI: same search / same targets."""
 	from benchmarks.nets import FcSmall
