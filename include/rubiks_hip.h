@@ -208,6 +208,15 @@ int rk_ohl_forward(rk_ohl_t *h, const int8_t *d_states, void *d_out, int out_dty
  * values on the device, copied; both null = no affine part.  act RK_OHL_ACT_NONE and null pointers restore the plain layer. */
 int rk_ohl_set_epilogue(rk_ohl_t *h, int act, float alpha, const float *d_scale, const float *d_shift, void *stream);
 
+/* The net's other end (model.py:124-125,128-129: policy_net / value_net end in activation -> Linear(K, 12) / Linear(K, 1), and the
+ * engines read those 12 + 1 numbers per row): y = act(x) @ W^T + b in ONE pass over x for a last layer of M <= 16 outputs, instead of an
+ * elementwise kernel over (n, K) plus a GEMM with a 12-column output.  d_x (n, K) bfloat16 with row stride ldx elements (a multiple
+ * of 8, rows 16-byte aligned), d_weight (M, K) bfloat16 row-major, d_bias M bfloat16 or NULL, d_out (n, M) bfloat16 row-major.
+ * K is 512, 1024 or 2048; act RK_OHL_ACT_* (alpha for ELU), applied in float32 and rounded to bfloat16 as torch's activation kernel
+ * stores it; float32 accumulation (v_dot2c_f32_bf16), the result rounded to bfloat16 (nearest even). */
+int rk_tail_linear(const void *d_x, size_t n, int K, size_t ldx, const void *d_weight, const void *d_bias, int M, int act, float alpha,
+                   void *d_out, void *stream);
+
 /* as_correct (cube.py:371-380): 686 one-hot int8 (n,288) -> float32 (n,48) of +1/-1. */
 int rk_as_correct686(const int8_t *d_states, float *d_out, size_t n, void *stream);
 

@@ -59,6 +59,7 @@ SIGNATURES = {
 	"rk_ohl_destroy": (_i, [_vp]),
 	"rk_ohl_forward": (_i, [_vp, _vp, _vp, _i, _sz, _i, _vp]),
 	"rk_ohl_set_epilogue": (_i, [_vp, _i, C.c_float, _vp, _vp, _vp]),
+	"rk_tail_linear": (_i, [_vp, _sz, _i, _sz, _vp, _vp, _i, _i, C.c_float, _vp, _vp]),
 	"rk_as_correct686": (_i, [_vp, _vp, _sz, _vp]),
 	"rk_astar_create": (_i, [C.POINTER(_vp), _sz, _i]),
 	"rk_astar_destroy": (_i, [_vp]),

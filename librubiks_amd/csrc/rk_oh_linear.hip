@@ -377,6 +377,80 @@ void k_ohl_mfma_direct(const uint32_t *__restrict__ states, const u32x4 *__restr
 	}
 }
 
+// ---- the net's other end: the heads' last, narrow Linear with the activation in front of it --------------------------
+// model.py:124-125,128-129: policy_net / value_net end in  activation -> [BatchNorm, folded away] -> Linear(K, 12) / Linear(K, 1).  As torch
+// runs them that is an elementwise kernel over (n, K) and a GEMM whose output is 12 (or 1, or 13 for both heads side by side) columns
+// wide: two launches for a layer that reads n K bf16 values once.  Here: y = act(x) W^T + b in one pass over x, M <= 16 outputs.
+// Sixteen lanes share a row (four rows per wave): lane (row, q) owns the 8-element pieces k = (16 c + q) 8 .. + 7 of every 128-element
+// chunk c, applies the activation in float32, rounds to bf16 (the value torch's activation kernel would have stored), and feeds
+// v_dot2c_f32_bf16 with W from LDS (one ds_read_b128 per output and chunk, the four rows of a wave read the same addresses);
+// four DPP row rotations sum the sixteen partial dots.  float32 accumulation, bf16 result.
+template <int N> __device__ __forceinline__ float row_ror_f(float v)       // lane i of a 16-lane row reads lane (i + N) % 16 of its row
+{
+	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xF, 0xF, false));
+}
+
+template <int CHUNKS, int ACT>
+__global__ __launch_bounds__(256)
+void k_tail_linear(const uint16_t *__restrict__ x, size_t n, size_t ldx, const u32x4 *__restrict__ w, const uint16_t *__restrict__ b, int M, float alpha,
+                   uint16_t *__restrict__ out)
+{
+	extern __shared__ u32x4 s_tw[];                                     // 16 x (16 CHUNKS) pieces of eight bf16 (rows M .. 15 zero)
+	constexpr int PER_ROW = 16 * CHUNKS;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, rr = lane >> 4, q = lane & 15;
+	const size_t row = (size_t)blockIdx.x * 16 + (size_t)(wv * 4 + rr);
+	const size_t ld_row = row < n ? row : n - 1;                        // rows past the end repeat the last row (never stored)
+	// everything this thread reads from memory is requested before anything waits: its row's pieces, then the weights for LDS
+	u32x4 xv[CHUNKS];
+	#pragma unroll
+	for (int c = 0; c < CHUNKS; c++) xv[c] = *reinterpret_cast<const u32x4 *>(x + ld_row * ldx + (size_t)(16 * c + q) * 8);
+	// the weights into LDS, padded with zero rows to SIXTEEN outputs: the loops below run over all sixteen without a branch (with `if (m < M)`
+	// around every output the compiler kept one ds_read_b128 and its four dots per basic block -- every LDS latency exposed, one wave per SIMD)
+	const int total = M * PER_ROW;
+	for (int base = 0; base < 16 * PER_ROW; base += 4 * 256) {
+		u32x4 t[4];
+		#pragma unroll
+		for (int j = 0; j < 4; j++) { const int i = base + 256 * j + tid; t[j] = w[i < total ? i : total - 1]; }
+		#pragma unroll
+		for (int j = 0; j < 4; j++) { const int i = base + 256 * j + tid; if (i < 16 * PER_ROW) s_tw[i] = i < total ? t[j] : u32x4{0u, 0u, 0u, 0u}; }
+	}
+	const float bias = (b != nullptr && q < M) ? __builtin_bit_cast(float, (uint32_t)b[q] << 16) : 0.0f;
+	__syncthreads();
+	float acc[16];
+	#pragma unroll
+	for (int m = 0; m < 16; m++) acc[m] = 0.0f;
+	#pragma unroll
+	for (int c = 0; c < CHUNKS; c++) {
+		const uint32_t raw[4] = {xv[c].x, xv[c].y, xv[c].z, xv[c].w};
+		bf16x2 a[4];
+		#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			f32x2 v = {__builtin_bit_cast(float, raw[j] << 16), __builtin_bit_cast(float, raw[j] & 0xFFFF0000u)};
+			if (ACT != 0) { v.x = ohl_act<ACT, true>(v.x, alpha); v.y = ohl_act<ACT, true>(v.y, alpha); }
+			a[j] = __builtin_convertvector(v, bf16x2);
+		}
+		#pragma unroll
+		for (int m = 0; m < 16; m++) {
+			const u32x4 wv4 = s_tw[m * PER_ROW + 16 * c + q];
+			// (components into scalars first: __builtin_bit_cast applied to `wv4.y` itself reads component x -- seen in the ISA, all
+			// four dots had the same B operand and one ds_read_b32 fed them)
+			const uint32_t w0 = wv4.x, w1 = wv4.y, w2 = wv4.z, w3 = wv4.w;
+			acc[m] = __builtin_amdgcn_fdot2_f32_bf16(a[0], __builtin_bit_cast(bf16x2, w0), acc[m], false);
+			acc[m] = __builtin_amdgcn_fdot2_f32_bf16(a[1], __builtin_bit_cast(bf16x2, w1), acc[m], false);
+			acc[m] = __builtin_amdgcn_fdot2_f32_bf16(a[2], __builtin_bit_cast(bf16x2, w2), acc[m], false);
+			acc[m] = __builtin_amdgcn_fdot2_f32_bf16(a[3], __builtin_bit_cast(bf16x2, w3), acc[m], false);
+		}
+	}
+	float mine = 0.0f;                                                  // output q of this lane's row
+	#pragma unroll
+	for (int m = 0; m < 16; m++) {
+		float v = acc[m];
+		v += row_ror_f<8>(v); v += row_ror_f<4>(v); v += row_ror_f<2>(v); v += row_ror_f<1>(v);   // every lane of the row: the row's sum
+		if (q == m) mine = v;
+	}
+	if (row < n && q < M) out[row * (size_t)M + q] = f32_to_bf16_rne(mine + bias);
+}
+
 }  // namespace rk
 
 using namespace rk;
@@ -551,6 +625,30 @@ int rk_ohl_forward(rk_ohl_t *h, const int8_t *d_states, void *d_out, int out_dty
 	#undef RK_OHL_MFMA_GO
 	#undef RK_OHL_MFMA_WIDE
 	#undef RK_OHL_GATHER_GO
+	RK_HIP(hipGetLastError());
+	return RK_OK;
+}
+
+int rk_tail_linear(const void *d_x, size_t n, int K, size_t ldx, const void *d_weight, const void *d_bias, int M, int act, float alpha,
+                   void *d_out, void *stream)
+{
+	if (n == 0) return RK_OK;
+	if (!d_x || !d_weight || !d_out) return fail(RK_EINVAL, "rk_tail_linear: null pointer");
+	if (K != 512 && K != 1024 && K != 2048) return fail(RK_EINVAL, "rk_tail_linear: in_features %d (512, 1024 and 2048 are built)", K);
+	if (M < 1 || M > 16) return fail(RK_EINVAL, "rk_tail_linear: out_features %d must be 1 .. 16", M);
+	if (ldx < (size_t)K || (ldx & 7) || (reinterpret_cast<uintptr_t>(d_x) & 15) || (reinterpret_cast<uintptr_t>(d_weight) & 15) || (reinterpret_cast<uintptr_t>(d_out) & 1))
+		return fail(RK_EINVAL, "rk_tail_linear: rows of x and the weight must be 16-byte aligned (row stride a multiple of 8 elements)");
+	if (act != RK_OHL_ACT_NONE && act != RK_OHL_ACT_ELU && act != RK_OHL_ACT_RELU) return fail(RK_EINVAL, "rk_tail_linear: unknown activation %d", act);
+	if ((n + 15) / 16 > 0x7FFFFFFFull) return fail(RK_EINVAL, "rk_tail_linear: %zu rows are too many for one launch", n);
+	hipStream_t st = (hipStream_t)stream;
+	const dim3 grid((unsigned)((n + 15) / 16));
+	const size_t lds = (size_t)16 * (size_t)(K / 8) * 16;                // 16 rows (M of them the weights, the rest zero): 16 / 32 / 64 KB
+	#define RK_TAIL_GO(CH, ACT) hipLaunchKernelGGL((k_tail_linear<CH, ACT>), grid, dim3(256), lds, st, (const uint16_t *)d_x, n, ldx, \
+		(const u32x4 *)d_weight, (const uint16_t *)d_bias, M, alpha, (uint16_t *)d_out)
+	#define RK_TAIL_BY_ACT(CH) do { if (act == RK_OHL_ACT_ELU) RK_TAIL_GO(CH, 1); else if (act == RK_OHL_ACT_RELU) RK_TAIL_GO(CH, 2); else RK_TAIL_GO(CH, 0); } while (0)
+	if (K == 512) RK_TAIL_BY_ACT(4); else if (K == 1024) RK_TAIL_BY_ACT(8); else RK_TAIL_BY_ACT(16);
+	#undef RK_TAIL_BY_ACT
+	#undef RK_TAIL_GO
 	RK_HIP(hipGetLastError());
 	return RK_OK;
 }

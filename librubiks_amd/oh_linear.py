@@ -11,6 +11,10 @@ forms -- few rows / many rows, same bits -- which `"mfma"` picks by the batch si
 reference's shape (`shared_net` = Sequential starting with a Linear, `policy_net`, `value_net`) into a callable that takes
 states instead of one-hot rows: `AStar(..., fused_first_layer=True)` and `adi_traindata(..., fused_first_layer=True)` use it.
 
+`TailLinear` is the same idea at the net's other end: a head's last, narrow Linear (12 logits, 1 value, or both heads' 13 columns
+side by side) with the activation in front of it as ONE launch (`rk_tail_linear`) instead of an elementwise kernel over (n, K) and a
+GEMM with a 13-column output; `fuse_first_linear(..., fold_batchnorm=True)` uses it for bfloat16 nets (`FUSE_TAIL`).
+
 `fuse_first_linear(net, epilogue=True)` also moves the activation and the eval-mode BatchNorm1d that follow the layer
 (model.py:157-159) into the kernel's epilogue, `fold_batchnorm=True` folds the remaining eval-mode BatchNorm1d layers into
 the Linear layers behind them: the same function in exact arithmetic, different float rounding (so not the default).
@@ -22,6 +26,8 @@ import ctypes as C
 import torch
 
 from librubiks_amd import _ffi
+
+FUSE_TAIL = True       # "folded" nets: the heads' last Linear with its activation as one launch (benchmarks switch it off for A/B)
 
 _ROUTES = {"gather": _ffi.OHL_GATHER, "mfma": _ffi.OHL_MFMA, "mfma_direct": _ffi.OHL_MFMA_DIRECT, "mfma_tiled": _ffi.OHL_MFMA_TILED}
 _CODES = {torch.float32: _ffi.OH_F32, torch.bfloat16: _ffi.OH_BF16}
@@ -85,6 +91,57 @@ class OhLinear:
 			out = torch.empty((n, self.out_features), dtype=dtype, device=device or "cuda")
 		_ffi.check(_ffi.lib().rk_ohl_forward(self._h, d_states, out.data_ptr(), _CODES[out.dtype], n, _ROUTES[route], _ffi.stream_ptr()))
 		return out
+
+
+def _act_code(activation):
+	if activation is None:
+		return _ffi.OHL_ACT_NONE, 1.0
+	if isinstance(activation, torch.nn.ELU):
+		return _ffi.OHL_ACT_ELU, float(activation.alpha)
+	if isinstance(activation, torch.nn.ReLU):
+		return _ffi.OHL_ACT_RELU, 1.0
+	return None
+
+
+class TailLinear(torch.nn.Module):
+	"""
+	activation -> Linear(K, M) for the narrow last layer of a head (reference: librubiks/model.py:124-125,128-129; M = 12 logits, 1 value,
+	or 13 for both heads side by side) as one launch, `rk_tail_linear`: bfloat16 in and out, the activation in float32 rounded to
+	bfloat16 as torch's own activation kernel stores it, float32 accumulation.  Same function as the two modules it replaces, another
+	summation order (so it belongs to the "folded" mode, which says so).  Snapshots the layer's parameters like the other fused pieces.
+	"""
+	IN_FEATURES = (512, 1024, 2048)
+
+	@staticmethod
+	def fits(activation, linear) -> bool:
+		return isinstance(linear, torch.nn.Linear) and linear.weight.is_cuda and linear.weight.dtype == torch.bfloat16 \
+		       and linear.in_features in TailLinear.IN_FEATURES and 1 <= linear.out_features <= 16 and _act_code(activation) is not None
+
+	def __init__(self, activation, linear: torch.nn.Linear):
+		super().__init__()
+		if not TailLinear.fits(activation, linear):
+			raise ValueError("TailLinear replaces [ELU | ReLU | nothing] -> nn.Linear(512 | 1024 | 2048, <= 16) in bfloat16 on the GPU")
+		self.act, self.alpha = _act_code(activation)
+		self.in_features, self.out_features = linear.in_features, linear.out_features
+		self.weight = linear.weight.detach().clone().contiguous()
+		self.bias = linear.bias.detach().clone().contiguous() if linear.bias is not None else None
+
+	def forward(self, x: torch.Tensor) -> torch.Tensor:
+		if x.dtype != torch.bfloat16 or not x.is_cuda or x.dim() != 2 or x.shape[1] != self.in_features or x.stride(1) != 1 \
+		   or x.stride(0) % 8 or x.data_ptr() % 16:
+			raise ValueError(f"TailLinear takes (n, {self.in_features}) bfloat16 rows on the GPU, 16-byte aligned")
+		out = torch.empty((len(x), self.out_features), dtype=torch.bfloat16, device=x.device)
+		_ffi.check(_ffi.lib().rk_tail_linear(x.data_ptr(), len(x), self.in_features, x.stride(0), self.weight.data_ptr(),
+		                                     self.bias.data_ptr() if self.bias is not None else None, self.out_features, self.act, self.alpha,
+		                                     out.data_ptr(), _ffi.stream_ptr()))
+		return out
+
+
+def _fuse_tail(mods: list) -> list:
+	"""mods with [activation, Linear(K, <= 16)] at the end replaced by a TailLinear where that is built (else mods as they are)"""
+	if len(mods) >= 2 and isinstance(mods[-2], (torch.nn.ELU, torch.nn.ReLU)) and TailLinear.fits(mods[-2], mods[-1]):
+		return list(mods[:-2]) + [TailLinear(mods[-2], mods[-1])]
+	return list(mods)
 
 
 def batchnorm_affine(bn: torch.nn.BatchNorm1d):
@@ -213,8 +270,12 @@ def fuse_first_linear(net, route: str = None, epilogue: bool = False, fold_batch
 		val, left_v = _fold(list(value_net), pending)
 		if left_p is not None: pol.append(_Affine(left_p[0], left_p[1], dtype))
 		if left_v is not None: val.append(_Affine(left_v[0], left_v[1], dtype))
-		policy_net, value_net = torch.nn.Sequential(*pol), torch.nn.Sequential(*val)
 		merged = _merge_heads(pol, val)                # both heads as one stack, used when both are asked for (MCTS)
+		if FUSE_TAIL:                                  # the last, narrow Linear of every stack with its activation: one launch instead of two
+			pol, val = _fuse_tail(pol), _fuse_tail(val)
+			if merged is not None:
+				merged = (torch.nn.Sequential(*_fuse_tail(list(merged[0]))), merged[1])
+		policy_net, value_net = torch.nn.Sequential(*pol), torch.nn.Sequential(*val)
 	else:
 		merged = None
 

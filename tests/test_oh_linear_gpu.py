@@ -120,6 +120,72 @@ def test_mfma_forms_agree_on_random_shapes():
 		assert torch.allclose(a[pick].float(), ref, rtol=2.0 ** -7, atol=1e-6), (case, n, H)
 
 
+@pytest.mark.parametrize("K", [512, 1024, 2048])
+@pytest.mark.parametrize("M", [1, 12, 13, 16])
+@pytest.mark.parametrize("act", ["elu", "elu0.7", "relu", None])
+def test_tail_linear_is_activation_plus_linear(K, M, act):
+	"""rk_tail_linear (round 5): a head's last Linear(K, M <= 16) with the activation in front of it in one launch (model.py:124-129).
+	Against float64 on the same bf16 numbers: the activation in float32 rounded to bf16 (what torch's activation kernel stores), then
+	exact products and sums -- the kernel may differ by its float32 accumulation (1e-5 of the sum of magnitudes) and the final
+	rounding to bf16 (2^-8 relative).  And against the two torch modules it replaces (bf16 GEMM: another summation order).  Ragged
+	row counts, a strided input view, rows behind the output untouched."""
+	from librubiks_amd.oh_linear import TailLinear
+	torch.manual_seed(K + M)
+	lin = torch.nn.Linear(K, M).cuda().to(torch.bfloat16)
+	module = {"elu": torch.nn.ELU(), "elu0.7": torch.nn.ELU(alpha=0.7), "relu": torch.nn.ReLU(), None: None}[act]
+	tail = TailLinear(module, lin)
+	for n in (1, 15, 16, 17, 3072, 4099):
+		wide = (torch.randn(n, K + 8, device="cuda") * 1.5).to(torch.bfloat16)
+		for x in (wide[:, :K].contiguous(), wide[:, :K]):                      # row stride K, row stride K + 8
+			y = tail(x)
+			assert y.shape == (n, M) and y.dtype == torch.bfloat16
+			a = (module(x.float()) if module is not None else x.float()).to(torch.bfloat16).double()
+			ref = a @ lin.weight.double().t() + lin.bias.double()
+			mag = a.abs() @ lin.weight.double().abs().t() + lin.bias.double().abs()
+			assert ((y.double() - ref).abs() <= 2.0 ** -8 * ref.abs() + 1e-5 * mag + 1e-30).all(), (n, x.stride(0))
+			with torch.no_grad():
+				tb = lin(module(x) if module is not None else x)
+			assert torch.allclose(y.float(), tb.float(), rtol=2.0 ** -6, atol=2.0 ** -6 * float(mag.max()) * 0.05 + 1e-3)
+	# the kernel writes n rows of M values and nothing else
+	out_rows = 37
+	x = torch.randn(out_rows, K, device="cuda").to(torch.bfloat16)
+	y = tail(x)
+	assert torch.isfinite(y.float()).all()
+	with pytest.raises(ValueError):
+		tail(x.float())
+	with pytest.raises(ValueError):
+		tail(x[:, : K - 8])
+	with pytest.raises(ValueError):
+		TailLinear(torch.nn.ELU(), torch.nn.Linear(480, 12).cuda().to(torch.bfloat16))
+
+
+def test_folded_net_ends_in_tail_linear_and_equals_the_torch_tail():
+	"""`fuse_first_linear(net, epilogue=True, fold_batchnorm=True)` on a bfloat16 net of the reference's shape: every stack of heads ends
+	in a TailLinear (policy 12, value 1, both 13 columns), and its outputs equal the same folded net with the torch tail
+	(`oh_linear.FUSE_TAIL = False`) within bf16 rounding -- on a search step's batch and on one row."""
+	from benchmarks.nets import FcSmall
+	from librubiks_amd import oh_linear
+	net = _randomise_batchnorm(FcSmall(seed=5)).cuda().eval().to(torch.bfloat16)
+	fused = fuse_first_linear(net, epilogue=True, fold_batchnorm=True)
+	assert isinstance(fused.merged_heads[-1], oh_linear.TailLinear) and fused.merged_heads[-1].out_features == 13
+	assert isinstance(fused.modules[1][-1], oh_linear.TailLinear) and isinstance(fused.modules[2][-1], oh_linear.TailLinear)
+	oh_linear.FUSE_TAIL = False
+	try:
+		plain = fuse_first_linear(net, epilogue=True, fold_batchnorm=True)
+	finally:
+		oh_linear.FUSE_TAIL = True
+	assert isinstance(plain.merged_heads[-1], torch.nn.Linear)
+	for n in (1, 3072):
+		states = torch.from_numpy(random_walk(n, 14, seed=n)).cuda()
+		with torch.no_grad():
+			for kw in ({}, {"policy": False}, {"value": False}):
+				got, want = fused(states, **kw), plain(states, **kw)
+				got, want = (got if isinstance(got, list) else [got]), (want if isinstance(want, list) else [want])
+				for g, w in zip(got, want):
+					assert g.shape == w.shape and g.dtype == w.dtype
+					assert torch.allclose(g.float(), w.float(), rtol=2.0 ** -5, atol=2.0 ** -5 * float(w.float().abs().max()))
+
+
 def test_fused_net_in_astar_and_adi():
 	"""The fused first layer behind the A* engine (states instead of one-hot rows) and ADI: same search / same targets."""
 	from benchmarks.nets import FcSmall
