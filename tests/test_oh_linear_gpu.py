@@ -140,8 +140,9 @@ def test_tail_linear_is_activation_plus_linear(K, M, act):
 			y = tail(x)
 			assert y.shape == (n, M) and y.dtype == torch.bfloat16
 			a = (module(x.float()) if module is not None else x.float()).to(torch.bfloat16).double()
-			ref = a @ lin.weight.double().t() + lin.bias.double()
-			mag = a.abs() @ lin.weight.double().abs().t() + lin.bias.double().abs()
+			W, bias = lin.weight.detach().double(), lin.bias.detach().double()
+			ref = a @ W.t() + bias
+			mag = a.abs() @ W.abs().t() + bias.abs()
 			assert ((y.double() - ref).abs() <= 2.0 ** -8 * ref.abs() + 1e-5 * mag + 1e-30).all(), (n, x.stride(0))
 			with torch.no_grad():
 				tb = lin(module(x) if module is not None else x)
