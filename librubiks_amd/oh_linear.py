@@ -28,6 +28,7 @@ import torch
 from librubiks_amd import _ffi
 
 FUSE_TAIL = True       # "folded" nets: the heads' last Linear with its activation as one launch (benchmarks switch it off for A/B)
+MFMA_FORM = None       # None: route "mfma" picks its form by the batch size; "mfma_direct" / "mfma_tiled": benchmarks force one for A/B
 
 _ROUTES = {"gather": _ffi.OHL_GATHER, "mfma": _ffi.OHL_MFMA, "mfma_direct": _ffi.OHL_MFMA_DIRECT, "mfma_tiled": _ffi.OHL_MFMA_TILED}
 _CODES = {torch.float32: _ffi.OH_F32, torch.bfloat16: _ffi.OH_BF16}
@@ -86,6 +87,8 @@ class OhLinear:
 	def from_pointer(self, d_states: int, n: int, out: torch.Tensor = None, route: str = None, device=None) -> torch.Tensor:
 		"""The layer on n 20-byte states at a device address (an engine's own buffer: rk_mcts_children), no tensor around them."""
 		route = route or self.route
+		if route == "mfma" and MFMA_FORM is not None:
+			route = MFMA_FORM
 		dtype = torch.bfloat16 if route.startswith("mfma") else self.dtype
 		if out is None:
 			out = torch.empty((n, self.out_features), dtype=dtype, device=device or "cuda")
