@@ -138,6 +138,14 @@ def test_error_reporting_without_fallback():
 	assert lib.rk_astar_shard_push_rows(None, None, 5, None, None, None) < 0
 	assert lib.rk_mcts_backup_select_logits_range(None, 0, 1, None, 12, None, 1, 0, None) < 0
 	assert lib.rk_face_definitions(None) == -1
+	# (second session of round 5) the heads' last layer and the first layer's forced forms: validated before any launch
+	assert lib.rk_tail_linear(None, 0, 1024, 1024, None, None, 13, 1, 1.0, None, None) == 0                           # no rows: nothing to do
+	assert lib.rk_tail_linear(None, 5, 1024, 1024, None, None, 13, 1, 1.0, None, None) == -1 and b"null pointer" in lib.rk_last_error()
+	assert lib.rk_tail_linear(16, 5, 480, 480, 16, None, 13, 1, 1.0, 16, None) == -1 and b"in_features" in lib.rk_last_error()
+	assert lib.rk_tail_linear(16, 5, 1024, 1024, 16, None, 17, 1, 1.0, 16, None) == -1 and b"out_features" in lib.rk_last_error()
+	assert lib.rk_tail_linear(16, 5, 1024, 1020, 16, None, 13, 1, 1.0, 16, None) == -1 and b"aligned" in lib.rk_last_error()
+	assert lib.rk_tail_linear(16, 5, 1024, 1024, 16, None, 13, 7, 1.0, 16, None) == -1 and b"activation" in lib.rk_last_error()
+	assert lib.rk_ohl_forward(None, None, None, _ffi.OH_BF16, 5, _ffi.OHL_MFMA_DIRECT, None) == -1
 	assert lib.rk_stream_register(None) == 0 and lib.rk_stream_forget(None) == 0 and lib.rk_get_pacing(None, None, None) == 0
 	if not torch.cuda.is_available():
 		assert lib.rk_init(0) == -2          # no device: an error, never a CPU path
