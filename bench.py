@@ -236,7 +236,7 @@ def search_legs():
 		"astar_engine_us_per_iteration": eng / max(n_it, 1) * 1e3, "astar_net_share": netp / max(whole, 1e-12),
 		"astar_engine_us_per_iteration_less_event_overhead": eng / max(n_it, 1) * 1e3 - 2 * empty_us,       # two event pairs per iteration
 		"astar_iterations": tot_iter, "astar_states": tot_states, "astar_games": games, "astar_solved": solved,
-		"astar_config": f"configs[2]: depth-{depth} scrambles, lambda={lam}, N={N}, {budget} states per game, fc_small bf16 random init, first layer fused + folded",
+		"astar_config": f"configs[2]: depth-{depth} scrambles, lambda={lam}, N={N}, {budget} states per game, fc_small bf16 random init, first layer fused + folded, heads' last layer fused (rk_tail_linear)",
 	})
 	del agent
 	# ---- configs[3]: MCTS -----------------------------------------------------------------------------------------
@@ -279,7 +279,7 @@ def search_legs():
 		"mcts_select_us": sum(sel) / max(len(sel), 1) * 1e3, "mcts_select_us_less_event_overhead": sum(sel) / max(len(sel), 1) * 1e3 - empty_us,
 		"mcts_steps": best_steps, "mcts_tree_sims": int(best_status[:, 3].sum()),
 		"mcts_solved": int(best_ok.sum()),
-		"mcts_config": f"configs[3]: {T} trees x {sims} simulations, depth-{depth} scrambles, c={c}, fc_small bf16 random init, first layer fused + folded, step replayed as a hipGraph "
+		"mcts_config": f"configs[3]: {T} trees x {sims} simulations, depth-{depth} scrambles, c={c}, fc_small bf16 random init, first layer fused + folded, heads' last layer fused (rk_tail_linear), step replayed as a hipGraph "
 		               "(mcts_ms_per_step = the faster of the one-stream step and the two-halves step, both timed here: mcts_ms_per_step_one_stream / _two_halves)",
 	})
 	return out

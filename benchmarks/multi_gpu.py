@@ -64,7 +64,7 @@ def search_net(kind: str = None):
 	net = FcSmall(seed=0).cuda().eval()
 	if kind.endswith("bf16"):
 		net = net.to(torch.bfloat16)
-	return net, "folded", f"{kind} random init, first layer fused + folded"
+	return net, "folded", f"{kind} random init, first layer fused + folded, heads' last layer fused"
 
 
 def _max_over_ranks(seconds: float, dist, backend) -> float:
