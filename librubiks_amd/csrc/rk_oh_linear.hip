@@ -18,9 +18,9 @@
 //                       a ds_read_b128 group hit 16 different bank quads); accumulators start at the bias; the epilogue
 //                       rounds to bf16 (nearest even) and goes through LDS so that a wave stores whole 128-byte rows.
 //
-//   MFMA, few rows      (round 5) the LDS tile pays when many row tiles reuse it.  A search step's batch is a few hundred rows
-//                       (256 trees of an MCTS step, a sharded rank's 1 344): there 64 workgroups each spend most of their
-//                       time filling 61 KB of LDS for one pass.  k_ohl_mfma_direct gives every WAVE one 32 x 32 output tile
+//   MFMA, few rows      (round 5) the LDS tile pays when many row tiles reuse it.  A search step's batch can be a few rows (one MCTS
+//                       tree: 12; A* at the reference's N = 27: 324; up to 768 take this form): there 64 workgroups each fill
+//                       61 KB of LDS for one pass.  k_ohl_mfma_direct gives every WAVE one 32 x 32 output tile
 //                       and loads its thirty B fragments straight from a fragment-major copy of W (one contiguous 1 KB per
 //                       wave instruction, all thirty in flight at once): no W in LDS, no barrier behind a load loop, 4 x as
 //                       many workgroups.  Same MFMA, same k order, same epilogue arithmetic: bit-identical to the tiled form.
