@@ -77,3 +77,20 @@ def test_merged_heads_are_the_two_heads_side_by_side():
 	assert _merge_heads(pol, val[:2]) is None
 	assert _merge_heads(pol, [torch.nn.Linear(16, 8), torch.nn.ReLU(), torch.nn.Linear(8, 1)]) is None
 	assert _merge_heads(pol, [torch.nn.Linear(20, 8), torch.nn.ELU(), torch.nn.Linear(8, 1)]) is None
+
+
+def test_tail_fusion_is_for_bfloat16_gpu_stacks_only_and_the_knobs_ship_neutral():
+	"""The heads' last layer becomes an `rk_tail_linear` launch only where that kernel is built (bfloat16 on the GPU, K in 512 / 1024 /
+	2048, at most 16 outputs, ELU / ReLU in front): any other stack comes back as it is.  The two benchmark knobs ship in their
+	neutral positions."""
+	import torch
+	from librubiks_amd import oh_linear
+	assert oh_linear.FUSE_TAIL is True and oh_linear.MFMA_FORM is None
+	for mods in ([torch.nn.Linear(2048, 512), torch.nn.ELU(), torch.nn.Linear(512, 12)],                               # float32 on the CPU
+	             [torch.nn.Linear(2048, 512).to(torch.bfloat16), torch.nn.ELU(), torch.nn.Linear(512, 12).to(torch.bfloat16)],   # bf16, CPU
+	             [torch.nn.Linear(64, 480), torch.nn.Tanh(), torch.nn.Linear(480, 12)],
+	             [torch.nn.Linear(512, 12)], []):
+		out = oh_linear._fuse_tail(mods)
+		assert len(out) == len(mods) and all(a is b for a, b in zip(out, mods))
+	assert not oh_linear.TailLinear.fits(torch.nn.ELU(), torch.nn.Linear(512, 12))
+	assert oh_linear._act_code(torch.nn.ELU(alpha=0.5)) == (1, 0.5) and oh_linear._act_code(None) == (0, 1.0) and oh_linear._act_code(torch.nn.Tanh()) is None
